@@ -1,0 +1,210 @@
+/*
+ * rato_saa.h — C ABI of the MI355X-native SAA inner loop (librato_saa.so).
+ *
+ * Drop-in boundary for the hot path of StanfordASL/RiskAverseTrajOpt: the
+ * per-SCP-iteration batched rollout, control-Jacobian linearization, sample
+ * mean and Monte-Carlo VaR/CVaR evaluation over M samples x S steps.  The
+ * reference has no FFI for this path (it is pure Python on JAX-CPU); each entry
+ * point below names the reference method (file:line under /root/reference) it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every data pointer is a CALLER-OWNED DEVICE pointer (fp32 unless noted),
+ *     e.g. torch.Tensor.data_ptr(); nothing is allocated or freed here.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
+ *     are asynchronous and stream-ordered; nothing synchronises the device.
+ *   - no global state: safe to call concurrently from one host thread per GPU.
+ *   - return value: 0 ok; RATO_EINVAL bad argument; RATO_EHIP-<hipError_t>
+ *     when a launch fails.
+ *   - the sample index m is ALWAYS the fastest-varying index (SoA), so every
+ *     wave reads/writes 256 contiguous bytes per instruction.
+ *
+ * Packed causal layout of the obstacle/separation Jacobian: d g_t / d u_s is
+ * identically zero unless s <= t-1 (position lags control by two steps), so
+ * only the pairs (t, s), 0 <= s < t < S are stored, row-major in t:
+ *     pair(t, s) = t*(t-1)/2 + s,   n_pairs = S*(S-1)/2.
+ */
+#ifndef RATO_SAA_H
+#define RATO_SAA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RATO_OK 0
+#define RATO_EINVAL (-1)
+#define RATO_EHIP (-1000)
+
+#define RATO_DRONE_NOBS 3   /* drone_params.py:34-43: n_obs = 3 */
+#define RATO_HOPPER_NFEAT 30 /* hopper.py:69: num_mu_features = 30 */
+
+/* ABI version, bumped on any signature/layout change. */
+int rato_abi_version(void);
+
+/* ------------------------------------------------------------------ drone */
+
+/* Constants of drone_params.py:1-45 / Model.__init__ drone_risk.py:71-93. */
+typedef struct rato_drone_params {
+  int32_t M;            /* samples in this shard */
+  int32_t S;            /* control intervals; dt = T/S (drone_risk.py:82) */
+  float dt;
+  float beta;           /* diffusion magnitude, 1e-2 */
+  float drag;           /* drag_coefficient, 0.2 */
+  float kp, kd;         /* -feedback_gain: 0.05, 0.25 */
+  float tol;            /* OSQP_TOL subtracted from the max constraint (1e-3) */
+  float x_init[6];
+  float x_final[6];
+  float obs_xy[RATO_DRONE_NOBS][2];  /* obs_positions[:, :2] */
+} rato_drone_params;
+
+/*
+ * Replaces Model.us_to_state_trajectories (drone_risk.py:139-162) fused with
+ * obstacle_avoidance_constraints (:169-213) and the Monte-Carlo closure
+ * monte_carlo_no_collisions_constraint_verification (:656-662).
+ *   us    [S][3]            controls
+ *   dW    [S][3][M]         velocity rows 3..5 of the reference's DWs (M,S,6)
+ *   mass  [M]
+ *   Qsym  [3 obs][3][M]     (Q00, Q01+Q10, Q11) of obs_Q[:, :2, :2]
+ * outputs (any may be NULL):
+ *   Z     [M]               max_{j,t} g - tol
+ *   xs    [S+1][6][M]       state trajectories (SoA of the reference's (M,S+1,6))
+ *   g     [3 obs][S][M]     constraint values
+ */
+int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW,
+                    const float* mass, const float* Qsym,
+                    float* Z, float* xs, float* g, void* stream);
+
+/* Grid shape used by rato_drone_linearize for (M, S): number of sample blocks
+ * (rows of the partial-sum buffers).  Returns <0 on bad arguments. */
+int rato_drone_linearize_nblocks(int32_t M);
+
+/*
+ * Replaces vmap(Model.get_all_constraints_coeffs) (drone_risk.py:239-290) and
+ * the per-block stage of the sample mean (:294-296).
+ * outputs:
+ *   G        [n_pairs][2 axes][3 obs][M]  d g[j,t] / d u[s,axis] for s<t
+ *                                         (the z-control column is identically 0)
+ *   g_up     [3 obs][S][M]                -g + grad g . u   (:278)
+ *   Z        [M] or NULL                  max_{j,t} g - tol at this iterate
+ *   part_du  [nblocks][S][6]              per-block sums of d x_S / d u_{s,axis}:
+ *                                         entries (P_x,P_y,P_z,V_x,V_y,V_z)
+ *   part_rhs [nblocks][6]                 per-block sums of -v_final + v_final_du.u (:271)
+ * cols_per_thread: 0 = choose from M; else one of 4, 8, 16, 32.
+ */
+int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
+                         const float* mass, const float* Qsym,
+                         float* G, float* g_up, float* Z,
+                         float* part_du, float* part_rhs,
+                         int32_t cols_per_thread, void* stream);
+
+/* Model.obstacle_avoidance_constraints on given trajectories (drone_risk.py:198-213).
+ *   xs [S+1][6][M] -> g [3 obs][S][M] */
+int rato_drone_obstacle_constraints(const rato_drone_params* p, const float* xs,
+                                    const float* Qsym, float* g, void* stream);
+
+/* ---------------------------------------------------------------- driving */
+
+/* Constants of driving_params.py:1-42 / Model.__init__ driving.py:84-120. */
+typedef struct rato_car_params {
+  int32_t M;
+  int32_t S;
+  float dt;
+  float beta;            /* 3e-2 */
+  float speed_ped_des;   /* 1.3 */
+  float d_min;           /* min_separation_distance */
+  float tol;             /* OSQP_TOL (3e-4) */
+  float ego_init[4];     /* state_init[0:4] (sample independent) */
+  float ego_goal[4];     /* driving.py:217-220 */
+} rato_car_params;
+
+/* Scratch floats needed by the driving entry points for the shared ego
+ * trajectory and ego sensitivities (sample-independent, recomputed per call). */
+size_t rato_car_ego_scratch_floats(int32_t S);
+
+/*
+ * Replaces Model.us_to_state_trajectories (driving.py:186-214) fused with
+ * separation_distances_at_all_times (:223-236) and
+ * monte_carlo_separation_constraints_verification (:630-638).
+ *   us      [S][2]
+ *   dW      [S][2][M]       rows 6..7 of the reference's DWs (M,S,8)
+ *   x0_ped  [4][M]          states_init[:, 4:8]
+ *   w_speed [M], w_rep [M]  omegas_speed, omegas_repulsive
+ *   ego_scratch             rato_car_ego_scratch_floats(S) floats
+ * outputs (any may be NULL):
+ *   Z   [M]                 max_t(-distance_t) - tol
+ *   xs  [S+1][8][M]
+ *   g   [S][M]              -distance_t
+ */
+int rato_car_eval(const rato_car_params* p, const float* us, const float* dW,
+                  const float* x0_ped, const float* w_speed, const float* w_rep,
+                  float* ego_scratch, float* Z, float* xs, float* g, void* stream);
+
+/*
+ * Replaces vmap(Model.get_all_constraints_coeffs) (driving.py:260-307).
+ * outputs:
+ *   G        [n_pairs][2 controls][M]   d g_t / d u[s,i] for s<t
+ *   g_up     [S][M]
+ *   Z        [M] or NULL
+ *   final_du [4][2S]   d x_S[0:4] / d u  (sample independent, so already the mean; :311)
+ *   final_rhs[4]       -v_final + v_final_du.u (:288)
+ */
+int rato_car_linearize(const rato_car_params* p, const float* us, const float* dW,
+                       const float* x0_ped, const float* w_speed, const float* w_rep,
+                       float* ego_scratch, float* G, float* g_up, float* Z,
+                       float* final_du, float* final_rhs,
+                       int32_t cols_per_thread, void* stream);
+
+/* ----------------------------------------------------------------- hopper */
+
+/*
+ * Replaces the sample-dependent part of Model.slip_risk_constraints
+ * (hopper.py:300-367), friction_at_px (:75-81), its Jacobian/Hessian slices
+ * (jacrev/hessian at :569,:577-580) and no_slip_constraints_verification
+ * (:901-925).  C = number of contact steps ([0,time_jump) U [time_land,S)).
+ *   px [C], fx [C], fz [C]        contact inputs gathered as at :305-311
+ *   a, theta, tau [30][M]         friction-field features (SoA of (M,30))
+ *   lam [C][M] or NULL            multipliers of the slip rows (for the Hessian sums)
+ * outputs (any may be NULL):
+ *   Z      [M]                    max_c (fx - mu fz)
+ *   h      [C][M]                 fx - mu_i(px_c) fz
+ *   dh_dfz [C][M]                 -mu_i(px_c)
+ *   dh_dpx [C][M]                 -mu_i'(px_c) fz
+ *   part_hess [nblocks][C][2]     per-block sums of lam*d2h/(dpx dfz), lam*d2h/dpx^2
+ */
+int rato_hopper_nblocks(int32_t M);
+int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,
+                     const float* a, const float* theta, const float* tau, const float* lam,
+                     float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
+                     void* stream);
+
+/* ------------------------------------------------------------- statistics */
+
+/* Deterministic second stage of the sample mean (drone_risk.py:294-296,
+ * driving.py:311-313): out[c] = scale * sum_b part[b][c], accumulated in fp64
+ * in a fixed order.  out is double[ncols]. */
+int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale,
+                      double* out, void* stream);
+
+/* Workspace bytes needed by rato_risk_stats for M samples. */
+size_t rato_risk_stats_workspace_bytes(int64_t M);
+
+/*
+ * Replaces the Monte-Carlo statistics: fraction satisfied (drone_risk.py:661,719),
+ * empirical VaR (drone_main_plot.py:640-652: sort(Z)[M - floor(alpha M) - 1])
+ * and AVaR/CVaR (drone_risk.py:663-695; the OSQP LP there is replaced by exact
+ * selection of the Rockafellar-Uryasev minimiser followed by the closed form :694).
+ *   Z [M]; thr = 1e-6 (the B_satisfied threshold)
+ *   out: double[8] = { VaR, CVaR, fraction(Z<=thr), mean(Z), max(Z),
+ *                      count(Z<=thr), sum(max(Z-VaR,0)), k (selected ascending rank) }
+ */
+int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
+                    void* workspace, size_t workspace_bytes, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RATO_SAA_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of include/rato_saa.h.  There is NO CPU fallback: if the HIP
+library is missing, loading fails loudly."""
+import ctypes as C
+import os
+
+from . import _build
+
+_LIB = None
+
+c_float_p = C.c_void_p   # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class DroneParams(C.Structure):
+    _fields_ = [("M", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
+                ("drag", C.c_float), ("kp", C.c_float), ("kd", C.c_float), ("tol", C.c_float),
+                ("x_init", C.c_float * 6), ("x_final", C.c_float * 6),
+                ("obs_xy", (C.c_float * 2) * 3)]
+
+
+class CarParams(C.Structure):
+    _fields_ = [("M", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
+                ("speed_ped_des", C.c_float), ("d_min", C.c_float), ("tol", C.c_float),
+                ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4)]
+
+
+# name -> (restype, argtypes); mirrors include/rato_saa.h one to one
+SIGNATURES = {
+    "rato_abi_version": (C.c_int, []),
+    "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
+    "rato_drone_linearize_nblocks": (C.c_int, [C.c_int32]),
+    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [C.c_int32, c_stream]),
+    "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
+    "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
+    "rato_car_eval": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 9 + [c_stream]),
+    "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
+    "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
+    "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
+    "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
+                                  c_float_p, c_stream]),
+}
+
+
+class RatoError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load librato_saa.so (built by ``__graft_entry__.build()`` /
+    ``python -m riskaversetrajopt_amd._build``).  Raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RatoError(
+            f"HIP extension {path} is missing — run `python -m riskaversetrajopt_amd._build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the SAA hot path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so is stale: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RatoError(f"{what} failed with status {status}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

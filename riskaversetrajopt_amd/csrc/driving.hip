@@ -1,0 +1,326 @@
+// Driving (ego car + pedestrian) SAA kernels (gfx950).  Replaces
+// driving.py:145-236 (social-force dynamics, rollout, separation distance),
+// :260-313 (control-Jacobian + mean) and :630-638 (Monte-Carlo closure).
+//
+// Structure exploited (verified in tests/test_oracle_driving.py): the ego
+// sub-state x[0:4] and its control sensitivity E_t = d x_ego,t / d u are bit-
+// identical across samples, so one small prologue kernel computes them once per
+// call into `ego_scratch`; the sample kernels read them through wave-uniform
+// (scalar) loads.  Only the pedestrian's 4-state sensitivity is per sample:
+//   dpp+ = dpp + dt dvp
+//   dvp+ = dvp + dt [ w_r H (dpp - dE_pos) - w_s dvy (1,1)^T ],  H = (I - n n^T)/r
+//   d g_t / d u_c = -n_{t+1}^T (E_{t+1}[pos, c] - dpp_{t+1})
+// Lane = sample; grid.y = groups of control steps s (both controls of a step
+// share one slot because they share the activity window t > s).
+#include "rato_common.h"
+
+namespace {
+
+// ego_scratch layout (floats):
+//   ego   [(S+1)][4]          ego trajectory
+//   Eu    [(S+1)][2]          E_t[pos,:] . u   (tangent of the ego position along u)
+//   Epos  [(S+1)][2][2S]      E_t[pos, c],  c = s*2 + i
+__host__ __device__ inline size_t ego_off_Eu(int S) { return (size_t)(S + 1) * 4; }
+__host__ __device__ inline size_t ego_off_Epos(int S) { return ego_off_Eu(S) + (size_t)(S + 1) * 2; }
+__host__ __device__ inline size_t ego_total(int S) { return ego_off_Epos(S) + (size_t)(S + 1) * 2 * 2 * S; }
+
+// One block.  Thread 0 rolls the ego out (driving.py:166-173); then one thread per
+// control column propagates E (4 rows) through A^e_t = d ego_{t+1} / d ego_t.
+__global__ __launch_bounds__(RATO_BLOCK) void car_ego_kernel(rato_car_params P, const float* __restrict__ us,
+                                                            float* __restrict__ scratch,
+                                                            float* __restrict__ final_du,
+                                                            float* __restrict__ final_rhs) {
+  const int S = P.S, NC = 2 * S;
+  float* ego = scratch;
+  float* Eu = scratch + ego_off_Eu(S);
+  float* Epos = scratch + ego_off_Epos(S);
+  if (threadIdx.x == 0) {
+    float x = P.ego_init[0], y = P.ego_init[1], v = P.ego_init[2], ph = P.ego_init[3];
+    ego[0] = x; ego[1] = y; ego[2] = v; ego[3] = ph;
+    for (int t = 0; t < S; ++t) {
+      float sn, cs;
+      sincosf(ph, &sn, &cs);
+      const float xn = x + P.dt * v * cs, yn = y + P.dt * v * sn;
+      const float vn = v + P.dt * us[t * 2 + 0], pn = ph + P.dt * us[t * 2 + 1];
+      x = xn; y = yn; v = vn; ph = pn;
+      ego[(t + 1) * 4 + 0] = x; ego[(t + 1) * 4 + 1] = y; ego[(t + 1) * 4 + 2] = v; ego[(t + 1) * 4 + 3] = ph;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  __shared__ float red[RATO_BLOCK / RATO_WAVE][4];
+  float rhs_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = threadIdx.x; c < NC; c += RATO_BLOCK) {
+    const int s = c >> 1, i = c & 1;
+    const float uc = us[c];
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    Epos[(size_t)(0 * 2 + 0) * NC + c] = 0.f;
+    Epos[(size_t)(0 * 2 + 1) * NC + c] = 0.f;
+    for (int t = 0; t < S; ++t) {
+      const float v = ego[t * 4 + 2], ph = ego[t * 4 + 3];
+      float sn, cs;
+      sincosf(ph, &sn, &cs);
+      const float n0 = e0 + P.dt * cs * e2 - P.dt * v * sn * e3;
+      const float n1 = e1 + P.dt * sn * e2 + P.dt * v * cs * e3;
+      float n2 = e2, n3 = e3;
+      if (t == s) {
+        if (i == 0) n2 += P.dt; else n3 += P.dt;
+      }
+      e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+      Epos[(size_t)((t + 1) * 2 + 0) * NC + c] = e0;
+      Epos[(size_t)((t + 1) * 2 + 1) * NC + c] = e1;
+    }
+    if (final_du) {
+      final_du[0 * NC + c] = e0; final_du[1 * NC + c] = e1; final_du[2 * NC + c] = e2; final_du[3 * NC + c] = e3;
+    }
+    rhs_acc[0] += e0 * uc; rhs_acc[1] += e1 * uc; rhs_acc[2] += e2 * uc; rhs_acc[3] += e3 * uc;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float sres = rato::wave_sum(rhs_acc[r]);
+    if (lane == 0) red[wave][r] = sres;
+  }
+  __syncthreads();
+  if (final_rhs && threadIdx.x < 4) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += red[w][threadIdx.x];
+    // val_final = -(x_S[:4] - goal) + v_final_du . u   (driving.py:288)
+    final_rhs[threadIdx.x] = -(ego[S * 4 + threadIdx.x] - P.ego_goal[threadIdx.x]) + acc;
+  }
+  // Eu[t] = Epos[t] . u  (one thread per (t, axis); fixed summation order)
+  for (int idx = threadIdx.x; idx < (S + 1) * 2; idx += RATO_BLOCK) {
+    float acc = 0.f;
+    for (int c = 0; c < NC; ++c) acc += Epos[(size_t)idx * NC + c] * us[c];
+    Eu[idx] = acc;
+  }
+}
+
+struct PedConsts {
+  float w_s, w_r, cn;
+};
+
+// Pedestrian step (driving.py:145-158,160-178,196-203) given the ego position at t.
+// Also returns the unit normal / inverse distance at time t for the Jacobian.
+__device__ __forceinline__ void ped_step(const rato_car_params& P, const PedConsts& c, float ex, float ey,
+                                         float xi0, float xi1, float& px, float& py, float& vx, float& vy,
+                                         float& n0, float& n1, float& rinv) {
+  const float dx = ex - px, dy = ey - py;
+  const float r2 = dx * dx + dy * dy;
+  rinv = 1.0f / sqrtf(r2);
+  n0 = dx * rinv;
+  n1 = dy * rinv;
+  const float common = c.w_s * (P.speed_ped_des - vy);  // added to BOTH components (:156-157)
+  const float F0 = -c.w_r * n0 + common, F1 = -c.w_r * n1 + common;
+  const float pxn = px + P.dt * vx, pyn = py + P.dt * vy;
+  const float vxn = vx + P.dt * F0 + c.cn * xi0, vyn = vy + P.dt * F1 + c.cn * xi1;
+  px = pxn; py = pyn; vx = vxn; vy = vyn;
+}
+
+__global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
+    rato_car_params P, const float* __restrict__ dW, const float* __restrict__ x0_ped,
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const float* __restrict__ scratch,
+    float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ g) {
+  const size_t M = (size_t)P.M;
+  const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  if (m >= M) return;
+  const int S = P.S;
+  const float* __restrict__ ego = scratch;
+  PedConsts c;
+  c.w_s = w_speed[m];
+  c.w_r = w_rep[m];
+  c.cn = sqrtf(P.dt) * P.beta;  // sqrt(dt) * beta: driving.py:183,200
+  float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+  if (xs) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xs[(size_t)k * M + m] = ego[k];
+    xs[(size_t)4 * M + m] = px; xs[(size_t)5 * M + m] = py; xs[(size_t)6 * M + m] = vx; xs[(size_t)7 * M + m] = vy;
+  }
+  float zmax = -INFINITY;
+  float xi0 = dW[m], xi1 = dW[M + m];
+  for (int t = 0; t < S; ++t) {
+    const int tn = (t + 1 < S) ? t + 1 : t;
+    const float nx0 = dW[(size_t)(tn * 2 + 0) * M + m], nx1 = dW[(size_t)(tn * 2 + 1) * M + m];
+    float n0, n1, rinv;
+    ped_step(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy, n0, n1, rinv);
+    const float dx = ego[(t + 1) * 4 + 0] - px, dy = ego[(t + 1) * 4 + 1] - py;
+    const float gt = -(sqrtf(dx * dx + dy * dy) - P.d_min);  // driving.py:223-230,269
+    zmax = fmaxf(zmax, gt);
+    if (g) g[(size_t)t * M + m] = gt;
+    if (xs) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xs[((size_t)(t + 1) * 8 + k) * M + m] = ego[(t + 1) * 4 + k];
+      xs[((size_t)(t + 1) * 8 + 4) * M + m] = px; xs[((size_t)(t + 1) * 8 + 5) * M + m] = py;
+      xs[((size_t)(t + 1) * 8 + 6) * M + m] = vx; xs[((size_t)(t + 1) * 8 + 7) * M + m] = vy;
+    }
+    xi0 = nx0; xi1 = nx1;
+  }
+  if (Z) Z[m] = zmax - P.tol;
+}
+
+__device__ __forceinline__ int step_of(int k, int grp, int ngroups) {
+  return k * ngroups + ((k & 1) ? (ngroups - 1 - grp) : grp);
+}
+
+// SPT = control steps per thread (each carries both controls: 2 x 4 sensitivities).
+template <int SPT>
+__global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
+    rato_car_params P, const float* __restrict__ dW, const float* __restrict__ x0_ped,
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const float* __restrict__ scratch,
+    float* __restrict__ G, float* __restrict__ g_up, float* __restrict__ Z) {
+  const size_t M = (size_t)P.M;
+  const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;
+  const int S = P.S, NC = 2 * S;
+  const int grp = blockIdx.y, ngroups = gridDim.y;
+  const bool lead = (grp == 0);
+  const float* __restrict__ ego = scratch;
+  const float* __restrict__ Eu = scratch + ego_off_Eu(S);
+  const float* __restrict__ Epos = scratch + ego_off_Epos(S);
+  PedConsts c;
+  c.w_s = w_speed[m];
+  c.w_r = w_rep[m];
+  c.cn = sqrtf(P.dt) * P.beta;
+  float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+
+  int stp[SPT];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    const int s = step_of(k, grp, ngroups);
+    stp[k] = (s < S) ? s : 0x7fffffff;
+  }
+  // sens[k][i] = d(ped px,py,vx,vy)_t / d u_{stp[k], i}
+  float spx[SPT][2], spy[SPT][2], svx[SPT][2], svy[SPT][2];
+#pragma unroll
+  for (int k = 0; k < SPT; ++k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) spx[k][i] = spy[k][i] = svx[k][i] = svy[k][i] = 0.0f;
+  float tpx = 0.f, tpy = 0.f, tvx = 0.f, tvy = 0.f;  // tangent along u
+
+  float zmax = -INFINITY;
+  float xi0 = dW[m], xi1 = dW[M + m];
+  for (int t = 0; t < S; ++t) {
+    const int tn = (t + 1 < S) ? t + 1 : t;
+    const float nx0 = dW[(size_t)(tn * 2 + 0) * M + m], nx1 = dW[(size_t)(tn * 2 + 1) * M + m];
+    float n0, n1, rinv;
+    ped_step(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy, n0, n1, rinv);
+    // dt * w_r * H at time t
+    const float k00 = P.dt * c.w_r * (1.0f - n0 * n0) * rinv;
+    const float k01 = -P.dt * c.w_r * n0 * n1 * rinv;
+    const float k11 = P.dt * c.w_r * (1.0f - n1 * n1) * rinv;
+    const float ks = P.dt * c.w_s;
+    {  // tangent along u, forced by Eu[t]
+      const float ax = tpx - Eu[t * 2 + 0], ay = tpy - Eu[t * 2 + 1];
+      const float npx = tpx + P.dt * tvx, npy = tpy + P.dt * tvy;
+      const float nvx = tvx + (k00 * ax + k01 * ay) - ks * tvy;
+      const float nvy = tvy + (k01 * ax + k11 * ay) - ks * tvy;
+      tpx = npx; tpy = npy; tvx = nvx; tvy = nvy;
+    }
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      if (stp[k] + 1 < t) {  // wave-uniform: E_t[pos, (s,i)] is nonzero only for t >= s+2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int col = stp[k] * 2 + i;
+          const float ax = spx[k][i] - Epos[(size_t)(t * 2 + 0) * NC + col];
+          const float ay = spy[k][i] - Epos[(size_t)(t * 2 + 1) * NC + col];
+          const float npx = spx[k][i] + P.dt * svx[k][i], npy = spy[k][i] + P.dt * svy[k][i];
+          const float nvx = svx[k][i] + (k00 * ax + k01 * ay) - ks * svy[k][i];
+          const float nvy = svy[k][i] + (k01 * ax + k11 * ay) - ks * svy[k][i];
+          spx[k][i] = npx; spy[k][i] = npy; svx[k][i] = nvx; svy[k][i] = nvy;
+        }
+      }
+    }
+    // row t: g_t = -(|p_e - p_p|_{t+1} - d_min), gradient -n_{t+1}
+    const float dx = ego[(t + 1) * 4 + 0] - px, dy = ego[(t + 1) * 4 + 1] - py;
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float m0 = dx / r, m1 = dy / r;
+    const float gt = -(r - P.d_min);
+    zmax = fmaxf(zmax, gt);
+    if (lead && valid) {
+      const float dirv = -(m0 * (Eu[(t + 1) * 2 + 0] - tpx) + m1 * (Eu[(t + 1) * 2 + 1] - tpy));
+      g_up[(size_t)t * M + m] = -gt + dirv;  // driving.py:295
+    }
+    const size_t row = (size_t)rato::pair_row_offset(t);
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      if (stp[k] < t) {  // wave-uniform
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int col = stp[k] * 2 + i;
+            const float e0 = Epos[(size_t)((t + 1) * 2 + 0) * NC + col];
+            const float e1 = Epos[(size_t)((t + 1) * 2 + 1) * NC + col];
+            G[((row + (size_t)stp[k]) * 2 + i) * M + m] = -(m0 * (e0 - spx[k][i]) + m1 * (e1 - spy[k][i]));
+          }
+        }
+      }
+    }
+    xi0 = nx0; xi1 = nx1;
+  }
+  if (lead && valid && Z) Z[m] = zmax - P.tol;
+}
+
+bool params_ok(const rato_car_params* p) {
+  return p && p->M > 0 && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
+}
+
+template <int SPT>
+int launch_car_linearize(const rato_car_params* p, const float* dW, const float* x0_ped, const float* w_speed,
+                         const float* w_rep, const float* scratch, float* G, float* g_up, float* Z,
+                         hipStream_t st) {
+  const int ngroups = (p->S + SPT - 1) / SPT;
+  dim3 grid(rato::nblocks_for(p->M), ngroups), block(RATO_BLOCK);
+  hipLaunchKernelGGL(car_linearize_kernel<SPT>, grid, block, 0, st, *p, dW, x0_ped, w_speed, w_rep, scratch, G,
+                     g_up, Z);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+}  // namespace
+
+extern "C" size_t rato_car_ego_scratch_floats(int32_t S) { return S > 0 ? ego_total(S) : 0; }
+
+extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const float* dW, const float* x0_ped,
+                             const float* w_speed, const float* w_rep, float* ego_scratch, float* Z, float* xs,
+                             float* g, void* stream) {
+  if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, (float*)nullptr,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(car_eval_kernel, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW, x0_ped,
+                     w_speed, w_rep, ego_scratch, Z, xs, g);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, const float* dW,
+                                  const float* x0_ped, const float* w_speed, const float* w_rep,
+                                  float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
+                                  float* final_rhs, int32_t cols_per_thread, void* stream) {
+  if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
+    return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, final_du, final_rhs);
+  int spt = cols_per_thread;
+  if (spt == 0) {
+    const long waves_per_group = (long)rato::nblocks_for(p->M) * (RATO_BLOCK / RATO_WAVE);
+    spt = 4;
+    const int cands[2] = {16, 8};
+    for (int i = 0; i < 2; ++i) {
+      const int ng = (p->S + cands[i] - 1) / cands[i];
+      if (waves_per_group * ng >= 2048) {
+        spt = cands[i];
+        break;
+      }
+    }
+  }
+  switch (spt) {
+    case 4: return launch_car_linearize<4>(p, dW, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, st);
+    case 8: return launch_car_linearize<8>(p, dW, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, st);
+    case 16: return launch_car_linearize<16>(p, dW, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, st);
+    default: return RATO_EINVAL;
+  }
+}

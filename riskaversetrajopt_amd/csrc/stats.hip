@@ -1,0 +1,262 @@
+// Sample-mean second stage and Monte-Carlo risk statistics (gfx950).
+// Replaces drone_risk.py:294-296 (mean), :661/:719 (fraction satisfied),
+// drone_main_plot.py:640-652 (VaR by sorting) and drone_risk.py:663-695 (AVaR;
+// the reference's dense 2M x (M+1) OSQP LP becomes an exact 3-pass radix
+// select of the Rockafellar-Uryasev minimiser + the closed form of :694).
+//
+// Everything is deterministic: no floating-point atomics; integer histogram
+// atomics commute.  Passes are separate launches on the caller's stream, so the
+// kernel boundary provides inter-workgroup visibility (no in-launch hand-off).
+#include "rato_common.h"
+
+namespace {
+
+// ------------------------------------------------------------ sum partials
+constexpr int SP_COLS = 32, SP_ROWS = 32;  // 1024 threads: 32 columns x 32 row lanes
+
+__global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const float* __restrict__ part, int nblocks,
+                                                                       int ncols, double scale,
+                                                                       double* __restrict__ out) {
+  __shared__ double red[SP_ROWS][SP_COLS + 1];
+  const int cx = threadIdx.x % SP_COLS, ry = threadIdx.x / SP_COLS;
+  const int c = blockIdx.x * SP_COLS + cx;
+  double acc = 0.0;
+  if (c < ncols)
+    for (int b = ry; b < nblocks; b += SP_ROWS) acc += (double)part[(size_t)b * ncols + c];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < ncols) {
+    double s = 0.0;
+    for (int r = 0; r < SP_ROWS; ++r) s += red[r][cx];  // fixed order
+    out[c] = s * scale;
+  }
+}
+
+// ------------------------------------------------------------- risk stats
+constexpr int B1 = 2048, B2 = 2048, B3 = 1024;  // 11 + 11 + 10 key bits
+constexpr int RS_MAX_BLOCKS = 1024;
+
+struct Workspace {
+  unsigned hist1[B1];
+  unsigned hist2[B2];
+  unsigned hist3[B3];
+  double blockpart[RS_MAX_BLOCKS][4];  // sum Z, count(Z<=thr), max Z, tail sum
+  float tstar;
+  unsigned nblocks;
+};
+
+// order-preserving map float -> uint32 (ascending)
+__device__ __forceinline__ unsigned key_of(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float value_of(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// Whole block: find the bin containing ascending rank k in hist[0..NB) and the
+// rank remaining inside that bin.  Result is returned to every thread.
+template <int NB>
+__device__ void find_bin(const unsigned* __restrict__ hist, unsigned k, unsigned& bin, unsigned& krem) {
+  constexpr int PER = NB / RATO_BLOCK;
+  __shared__ unsigned wsum[RATO_BLOCK / RATO_WAVE];
+  __shared__ unsigned res[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned local[PER], tot = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    local[i] = hist[tid * PER + i];
+    tot += local[i];
+  }
+  unsigned incl = tot;  // inclusive scan across the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned n = __shfl_up(incl, off, RATO_WAVE);
+    if (lane >= off) incl += n;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  unsigned excl = base + incl - tot;
+  if (k >= excl && k < excl + tot) {
+    unsigned run = excl;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (k >= run && k < run + local[i]) {
+        res[0] = tid * PER + i;
+        res[1] = k - run;
+      }
+      run += local[i];
+    }
+  }
+  __syncthreads();
+  bin = res[0];
+  krem = res[1];
+  __syncthreads();
+}
+
+template <int NB>
+__device__ void flush_hist(unsigned* lds_hist, unsigned* __restrict__ ghist) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += RATO_BLOCK) {
+    const unsigned c = lds_hist[i];
+    if (c) atomicAdd(&ghist[i], c);
+  }
+}
+
+__global__ __launch_bounds__(RATO_BLOCK) void rs_pass1(const float* __restrict__ Z, long M, float thr,
+                                                       Workspace* __restrict__ ws) {
+  __shared__ unsigned h[B1];
+  __shared__ double red[3][RATO_BLOCK / RATO_WAVE];
+  for (int i = threadIdx.x; i < B1; i += RATO_BLOCK) h[i] = 0;
+  __syncthreads();
+  double sum = 0.0, cnt = 0.0;
+  float mx = -INFINITY;
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < M; i += (long)gridDim.x * RATO_BLOCK) {
+    const float z = Z[i];
+    atomicAdd(&h[key_of(z) >> 21], 1u);
+    sum += (double)z;
+    cnt += (z <= thr) ? 1.0 : 0.0;
+    mx = fmaxf(mx, z);
+  }
+  flush_hist<B1>(h, ws->hist1);
+  sum = rato::wave_sum(sum);
+  cnt = rato::wave_sum(cnt);
+  mx = rato::wave_max(mx);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = sum;
+    red[1][wave] = cnt;
+    red[2][wave] = (double)mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0, c = 0, m = -INFINITY;
+    for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) {
+      s += red[0][w];
+      c += red[1][w];
+      m = fmax(m, red[2][w]);
+    }
+    ws->blockpart[blockIdx.x][0] = s;
+    ws->blockpart[blockIdx.x][1] = c;
+    ws->blockpart[blockIdx.x][2] = m;
+  }
+}
+
+__global__ __launch_bounds__(RATO_BLOCK) void rs_pass2(const float* __restrict__ Z, long M, unsigned k,
+                                                       Workspace* __restrict__ ws) {
+  __shared__ unsigned h[B2];
+  for (int i = threadIdx.x; i < B2; i += RATO_BLOCK) h[i] = 0;
+  unsigned b1, k1;
+  find_bin<B1>(ws->hist1, k, b1, k1);
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < M; i += (long)gridDim.x * RATO_BLOCK) {
+    const unsigned key = key_of(Z[i]);
+    if ((key >> 21) == b1) atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u);
+  }
+  flush_hist<B2>(h, ws->hist2);
+}
+
+__global__ __launch_bounds__(RATO_BLOCK) void rs_pass3(const float* __restrict__ Z, long M, unsigned k,
+                                                       Workspace* __restrict__ ws) {
+  __shared__ unsigned h[B3];
+  for (int i = threadIdx.x; i < B3; i += RATO_BLOCK) h[i] = 0;
+  unsigned b1, k1, b2, k2;
+  find_bin<B1>(ws->hist1, k, b1, k1);
+  find_bin<B2>(ws->hist2, k1, b2, k2);
+  const unsigned prefix = (b1 << 11) | b2;
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < M; i += (long)gridDim.x * RATO_BLOCK) {
+    const unsigned key = key_of(Z[i]);
+    if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
+  }
+  flush_hist<B3>(h, ws->hist3);
+}
+
+__global__ __launch_bounds__(RATO_BLOCK) void rs_tail(const float* __restrict__ Z, long M, unsigned k,
+                                                      Workspace* __restrict__ ws) {
+  __shared__ double red[RATO_BLOCK / RATO_WAVE];
+  unsigned b1, k1, b2, k2, b3, k3;
+  find_bin<B1>(ws->hist1, k, b1, k1);
+  find_bin<B2>(ws->hist2, k1, b2, k2);
+  find_bin<B3>(ws->hist3, k2, b3, k3);
+  const float t = value_of((b1 << 21) | (b2 << 10) | b3);
+  double tail = 0.0;
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < M; i += (long)gridDim.x * RATO_BLOCK) {
+    const float z = Z[i];
+    tail += (z > t) ? ((double)z - (double)t) : 0.0;
+  }
+  tail = rato::wave_sum(tail);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tail;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) s += red[w];
+    ws->blockpart[blockIdx.x][3] = s;
+    if (blockIdx.x == 0) ws->tstar = t;
+  }
+}
+
+__global__ void rs_final(long M, double alpha, unsigned k, int nblocks, const Workspace* __restrict__ ws,
+                         double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0, c = 0, m = -INFINITY, tail = 0;
+  for (int b = 0; b < nblocks; ++b) {  // fixed order
+    s += ws->blockpart[b][0];
+    c += ws->blockpart[b][1];
+    m = fmax(m, ws->blockpart[b][2]);
+    tail += ws->blockpart[b][3];
+  }
+  const double t = (double)ws->tstar;
+  out[0] = t;                                  // VaR
+  out[1] = t + (tail / (double)M) / alpha;     // CVaR (drone_risk.py:694)
+  out[2] = c / (double)M;                      // fraction satisfied
+  out[3] = s / (double)M;
+  out[4] = m;
+  out[5] = c;
+  out[6] = tail;
+  out[7] = (double)k;
+}
+
+}  // namespace
+
+extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale, double* out,
+                                 void* stream) {
+  if (!part || !out || nblocks <= 0 || ncols <= 0) return RATO_EINVAL;
+  dim3 grid((ncols + SP_COLS - 1) / SP_COLS), block(SP_COLS * SP_ROWS);
+  hipLaunchKernelGGL(sum_partials_kernel, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
+  (void)M;
+  return sizeof(Workspace);
+}
+
+extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                               size_t workspace_bytes, double* out, void* stream) {
+  if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
+    return RATO_EINVAL;
+  if (workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
+  // ascending 0-based rank of sort(Z)[M - floor(alpha*M) - 1]  (drone_main_plot.py:649-651)
+  long xth = (long)floor(alpha * (double)M);
+  long kk = (long)M - xth - 1;
+  if (kk < 0) kk = 0;
+  const unsigned k = (unsigned)kk;
+  Workspace* ws = static_cast<Workspace*>(workspace);
+  hipStream_t st = rato::as_stream(stream);
+  long nb = (M + RATO_BLOCK * 4 - 1) / (RATO_BLOCK * 4);
+  if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipError_t e = hipMemsetAsync(ws, 0, offsetof(Workspace, blockpart), st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  dim3 grid((unsigned)nb), block(RATO_BLOCK);
+  hipLaunchKernelGGL(rs_pass1, grid, block, 0, st, Z, (long)M, thr, ws);
+  hipLaunchKernelGGL(rs_pass2, grid, block, 0, st, Z, (long)M, k, ws);
+  hipLaunchKernelGGL(rs_pass3, grid, block, 0, st, Z, (long)M, k, ws);
+  hipLaunchKernelGGL(rs_tail, grid, block, 0, st, Z, (long)M, k, ws);
+  hipLaunchKernelGGL(rs_final, dim3(1), dim3(64), 0, st, (long)M, alpha, k, (int)nb, ws, out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}

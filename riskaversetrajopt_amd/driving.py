@@ -1,0 +1,249 @@
+"""Driving SAA model — the reference's ``class Model`` (car/driving.py:83-456)
+with its sample-axis hot path on the MI355X.
+
+``Model(M, method, alpha)`` samples its own uncertain parameters from the global
+``np.random`` stream in the reference's draw order (driving.py:84-120).  The
+reference fixes S as a module constant; here it is a keyword (default 20).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, stats
+from . import driving_params as P
+
+n_x, n_u = P.n_x, P.n_u
+OSQP_TOL = P.OSQP_TOL
+std_matrix_ped_initial_state = np.sqrt(P.variance_ped_initial_state)   # driving.py:50-51
+BETA = 3e-2                                                            # driving.py:94
+
+
+def num_pairs(S):
+    return S * (S - 1) // 2
+
+
+def sample_uncertain_parameters(M, method='saa', S=P.S, rng=None):
+    """The sampling half of ``Model.__init__`` (driving.py:95-120), vectorised
+    with the reference's draw order -> (states_init (M,8), omegas_speed (M,),
+    omegas_repulsive (M,), DWs (M,S,8))."""
+    rng = np.random if rng is None else rng
+    dt = P.T / S
+    omegas_speed = rng.uniform(P.omega_speed_nom - P.omega_speed_del,
+                               P.omega_speed_nom + P.omega_speed_del, M)
+    omegas_repulsive = rng.uniform(P.omega_repulsive_nom - P.omega_repulsive_del,
+                                   P.omega_repulsive_nom + P.omega_repulsive_del, M)
+    states_init = np.repeat(P.state_init[None, :], M, axis=0)
+    if method == 'saa':
+        states_init[:, 4:] += rng.randn(M, 4) * np.diag(std_matrix_ped_initial_state)[None, :]
+    DWs = np.sqrt(dt) * rng.randn(M, S, n_x)
+    if method == 'baseline':
+        DWs = 0 * DWs
+        omegas_speed = 0 * omegas_speed
+        omegas_repulsive = 0 * omegas_repulsive
+    return states_init, omegas_speed, omegas_repulsive, DWs
+
+
+def sample_uncertain_parameters_device(M, S, seed=0, device='cuda:0'):
+    """Synthetic batch drawn in HBM in kernel layout: dW [S][2][M], x0_ped [4][M],
+    w_speed [M], w_rep [M] (fp32)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    dt = P.T / S
+    dW = torch.randn((S, 2, M), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(dt))
+    u = lambda: 2 * torch.rand(M, generator=g, device=device, dtype=torch.float32) - 1
+    w_speed = P.omega_speed_nom + P.omega_speed_del * u()
+    w_rep = P.omega_repulsive_nom + P.omega_repulsive_del * u()
+    std = torch.tensor([1e-1, 1e-1, 1e-4, 1e-4], device=device)[:, None]
+    x0 = torch.tensor(P.state_init[4:], dtype=torch.float32, device=device)[:, None] + \
+        std * torch.randn((4, M), generator=g, device=device, dtype=torch.float32)
+    return dW, x0.contiguous(), w_speed, w_rep
+
+
+def to_soa_inputs(states_init, omegas_speed, omegas_repulsive, DWs, device):
+    """Reference layouts -> kernel layouts (fp32, sample fastest).  Only rows 6..7
+    of DWs are used by sigma (driving.py:180-184)."""
+    DWs = torch.as_tensor(np.asarray(DWs), device=device)
+    dW = DWs[:, :, 6:8].permute(1, 2, 0).contiguous().float()
+    x0 = torch.as_tensor(np.asarray(states_init), device=device)
+    x0_ped = x0[:, 4:8].t().contiguous().float()
+    ws = torch.as_tensor(np.asarray(omegas_speed), device=device).contiguous().float()
+    wr = torch.as_tensor(np.asarray(omegas_repulsive), device=device).contiguous().float()
+    return dW, x0_ped, ws, wr
+
+
+class Model:
+    def __init__(self, M, method='saa', alpha=0.05, S=P.S, device='cuda:0', rng=None,
+                 samples=None, verbose=False):
+        if verbose:
+            print("Initializing Model with")
+            print("> method =", method)
+            print("> alpha  =", alpha)
+        self.method = method
+        self.u_max = P.u_max
+        self.u_min = -self.u_max
+        self.alpha = alpha
+        self.beta = BETA
+        self.S, self.dt, self.M = S, P.T / S, M
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        if samples is None:
+            samples = sample_uncertain_parameters(M, method, S, rng)
+        if samples != 'device':
+            self.states_init, self.omegas_speed, self.omegas_repulsive, self.DWs = samples
+            ego0 = np.asarray(self.states_init)[:, :4]
+            if not np.all(ego0 == ego0[0:1]):
+                raise ValueError("the ego initial state must be sample-independent (driving.py:104-110)")
+            self._ego_init = ego0[0].astype(np.float64)
+            self._dW, self._x0, self._ws, self._wr = to_soa_inputs(*samples, self.device)
+        self._scratch = torch.empty(self._lib.rato_car_ego_scratch_floats(S), dtype=torch.float32,
+                                    device=self.device)
+
+    @classmethod
+    def from_device(cls, S, dW, x0_ped, w_speed, w_rep, method='saa', alpha=0.05):
+        self = cls(w_speed.numel(), method, alpha, S=S, device=dW.device, samples='device')
+        self._ego_init = P.state_init[:4].astype(np.float64)
+        self._dW, self._x0, self._ws, self._wr = (t.contiguous() for t in (dW, x0_ped, w_speed, w_rep))
+        return self
+
+    # ---- layout helpers (driving.py:122-143) -------------------------------
+    def convert_us_vec_to_us_mat(self, us_vec):
+        return np.reshape(np.asarray(us_vec), (n_u, self.S), 'F').T.copy()
+
+    def convert_us_mat_to_us_jaxvec(self, us_mat):
+        return np.reshape(np.asarray(us_mat), (self.S * n_u), 'C')
+
+    def initial_guess_us_mat(self):
+        return np.zeros((self.S, n_u)) + (self.u_max + self.u_min) / 2.0 + 1e-2
+
+    # ---- plumbing ----------------------------------------------------------
+    def _params(self, M):
+        p = _lib.CarParams()
+        p.M, p.S, p.dt, p.beta = M, self.S, self.dt, self.beta
+        p.speed_ped_des = P.speed_ped_des
+        p.d_min = float(P.min_separation_distance)
+        p.tol = OSQP_TOL
+        goal = np.concatenate((P.position_ego_goal, P.velocity_ego_goal))
+        for i in range(4):
+            p.ego_init[i] = float(self._ego_init[i])
+            p.ego_goal[i] = float(goal[i])
+        return p
+
+    def _us_device(self, us_mat):
+        if isinstance(us_mat, torch.Tensor) and us_mat.is_cuda:
+            us = us_mat.float().contiguous()
+        else:
+            us = torch.as_tensor(np.ascontiguousarray(np.asarray(us_mat), dtype=np.float32), device=self.device)
+        if tuple(us.shape) != (self.S, n_u):
+            raise ValueError(f"us_mat must be ({self.S},{n_u}), got {tuple(us.shape)}")
+        return us
+
+    def _empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ---- rollout + separation distances (K3) -------------------------------
+    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
+        dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
+        M = ws.numel()
+        us = self._us_device(us_mat)
+        Z = self._empty(M)
+        xs = self._empty(self.S + 1, n_x, M) if want_xs else None
+        g = self._empty(self.S, M) if want_g else None
+        p = self._params(M)
+        _lib.check(self._lib.rato_car_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws),
+                                           _lib.ptr(wr), _lib.ptr(self._scratch), _lib.ptr(Z), _lib.ptr(xs),
+                                           _lib.ptr(g), _lib.current_stream()), "rato_car_eval")
+        return Z, xs, g
+
+    def us_to_state_trajectories(self, us_mat):
+        """driving.py:205-214 -> (M, S+1, n_x)."""
+        _, xs, _ = self.eval_device(us_mat, want_xs=True)
+        return xs.permute(2, 0, 1).double().cpu().numpy()
+
+    def us_to_state_trajectory(self, us_mat, state_init, omega_speed, omega_repulsive, dWs):
+        """driving.py:186-203, one sample -> (S+1, n_x)."""
+        state_init = np.asarray(state_init, dtype=np.float64)
+        if not np.array_equal(state_init[:4], self._ego_init):
+            raise ValueError("ego initial state differs from the model's")
+        inputs = to_soa_inputs(state_init[None], [omega_speed], [omega_repulsive], np.asarray(dWs)[None], self.device)
+        _, xs, _ = self.eval_device(us_mat, want_xs=True, inputs=inputs)
+        return xs[:, :, 0].double().cpu().numpy()
+
+    def final_constraints(self, xs):
+        goal = np.concatenate((P.position_ego_goal, P.velocity_ego_goal))
+        return np.asarray(xs)[..., -1, :4] - goal
+
+    def separation_distances_at_all_times(self, us_mat):
+        """Batched driving.py:232-236 at the model's samples -> (M, S)  (= -g)."""
+        _, _, g = self.eval_device(us_mat, want_g=True)
+        return -g.t().double().cpu().numpy()
+
+    # ---- linearization (K4) ------------------------------------------------
+    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True):
+        """-> dict: G [n_pairs][2][M], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
+        (device, fp32; final_* are sample-independent, i.e. already the mean)."""
+        dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
+        M, S = ws.numel(), self.S
+        us = self._us_device(us_mat)
+        o = out if out is not None else {}
+        G = o.get("G") if "G" in o else self._empty(max(num_pairs(S), 1), 2, M)
+        g_up = o.get("g_up") if "g_up" in o else self._empty(S, M)
+        Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
+        final_du = o.get("final_du") if "final_du" in o else self._empty(4, n_u * S)
+        final_rhs = o.get("final_rhs") if "final_rhs" in o else self._empty(4)
+        p = self._params(M)
+        _lib.check(self._lib.rato_car_linearize(
+            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+            _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
+            _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
+        return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M}
+
+    def expand_g_obs_du(self, G):
+        """packed G [n_pairs][2][M] (host ndarray) -> dense (M, S, n_u*S)."""
+        S = self.S
+        M = G.shape[-1]
+        dense = np.zeros((M, S, n_u * S))
+        for t in range(1, S):
+            off = t * (t - 1) // 2
+            blk = G[off:off + t]                        # (t, 2, M)
+            dense[:, t, :n_u * t] = np.transpose(blk, (2, 0, 1)).reshape(M, n_u * t)
+        return dense
+
+    def sample_means(self, us_mat):
+        """driving.py:311-313 -> (final_du (4,2S), final_low (4,), final_up (4,))."""
+        r = self.linearize_device(us_mat)
+        rhs = r["final_rhs"].double().cpu().numpy()
+        return r["final_du"].double().cpu().numpy(), rhs, rhs.copy()
+
+    def get_all_constraints_coeffs(self, us_mat, state_init, omega_speed, omega_repulsive, dWs):
+        """driving.py:260-298 for ONE sample -> (v_final_du (4,2S), val_final_lower (4,),
+        val_final_upper (4,), g_obs_du (S,2S), g_up (S,))."""
+        inputs = to_soa_inputs(np.asarray(state_init)[None], [omega_speed], [omega_repulsive],
+                               np.asarray(dWs)[None], self.device)
+        r = self.linearize_device(us_mat, inputs=inputs)
+        rhs = r["final_rhs"].double().cpu().numpy()
+        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())[0]
+        return (r["final_du"].double().cpu().numpy(), rhs, rhs.copy(), g_obs_du,
+                r["g_up"][:, 0].double().cpu().numpy())
+
+    def get_all_constraints_coeffs_batched(self, us_mat):
+        """vmap over the model's samples (driving.py:305-307), dense; small M only."""
+        r = self.linearize_device(us_mat)
+        return (self.expand_g_obs_du(r["G"].double().cpu().numpy()),
+                r["g_up"].t().double().cpu().numpy())
+
+    # ---- Monte-Carlo validation (driving.py:623-671) -----------------------
+    def monte_carlo_cost(self, us_mat):
+        us = np.asarray(us_mat)
+        return P.dt * float(np.sum(np.diag(P.R)[None, :] * us * us))
+
+    def monte_carlo_separation_constraints_verification(self, us_mat):
+        Z, _, _ = self.eval_device(us_mat)
+        Zh = Z.double().cpu().numpy()
+        return Zh <= 1e-6, Zh
+
+    def monte_carlo_statistics(self, us_mat, alpha=None):
+        Z, _, _ = self.eval_device(us_mat)
+        return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
+
+    monte_carlo_avar = staticmethod(stats.monte_carlo_avar)

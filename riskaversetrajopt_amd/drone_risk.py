@@ -1,0 +1,257 @@
+"""Drone SAA model — the reference's ``class Model`` (drone/drone_risk.py:70-469)
+with its sample-axis hot path on the MI355X.
+
+Same constructor, method names, argument meaning and return shapes as the
+reference for the L2 layer (rollout, constraints, per-sample linearization,
+Monte-Carlo closures).  Device work goes through the C ABI of
+``include/rato_saa.h``; torch is used for device memory and streams only.
+Host-facing methods return NumPy arrays in the reference's shapes; ``*_device``
+methods return the kernels' SoA tensors (sample index fastest).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, stats
+from . import drone_params as P
+
+n_x, n_u, n_obs = P.n_x, P.n_u, P.n_obs
+OSQP_TOL = P.OSQP_TOL
+
+
+def num_pairs(S):
+    return S * (S - 1) // 2
+
+
+def to_soa_inputs(DWs, masses, obs_Qs, device):
+    """Reference layouts -> kernel layouts (fp32, sample index fastest).
+    DWs (M,S,6) -> dW [S][3][M] (only rows 3..5 are used by sigma, drone_risk.py:136);
+    obs_Qs (M,n_obs,3,3) -> Qsym [n_obs][3][M] = (Q00, Q01+Q10, Q11) of [:2,:2] (:174)."""
+    DWs = torch.as_tensor(np.asarray(DWs), device=device)
+    dW = DWs[:, :, 3:6].permute(1, 2, 0).contiguous().float()
+    mass = torch.as_tensor(np.asarray(masses), device=device).contiguous().float()
+    Q = torch.as_tensor(np.asarray(obs_Qs), device=device)
+    Qsym = torch.stack([Q[:, :, 0, 0], Q[:, :, 0, 1] + Q[:, :, 1, 0], Q[:, :, 1, 1]], dim=1)  # (M,3,n_obs)
+    Qsym = Qsym.permute(2, 1, 0).contiguous().float()
+    return dW, mass, Qsym
+
+
+class Model:
+    def __init__(self, S, DWs, masses, obs_Qs, method='saa', alpha=0.1, device='cuda:0',
+                 verbose=False):
+        # drone_risk.py:71-93
+        if verbose:
+            print("Initializing Model with")
+            print("> method =", method)
+            print("> alpha  =", alpha)
+            print("> S      =", S)
+        self.method = method
+        self.S = S
+        self.dt = P.T / S
+        self.u_max = P.u_max
+        self.u_min = -self.u_max
+        self.alpha = alpha
+        self.beta = P.beta
+        self.drag_coefficient = P.drag_coefficient
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        if DWs is not None:
+            self.DWs, self.masses, self.obs_Qs = DWs, masses, obs_Qs
+            self._dW, self._mass, self._Qsym = to_soa_inputs(DWs, masses, obs_Qs, self.device)
+            self.M = self._mass.numel()
+            if self._dW.shape[0] != S:
+                raise ValueError(f"DWs has {self._dW.shape[0]} steps, Model has S={S}")
+
+    @classmethod
+    def from_device(cls, S, dW, mass, Qsym, method='saa', alpha=0.1):
+        """Batch already resident in HBM in kernel layout (throughput runs)."""
+        self = cls(S, None, None, None, method, alpha, device=dW.device)
+        self.DWs = self.masses = self.obs_Qs = None
+        self._dW, self._mass, self._Qsym = dW.contiguous(), mass.contiguous(), Qsym.contiguous()
+        self.M = mass.numel()
+        return self
+
+    # ---- layout helpers (drone_risk.py:95-120) -----------------------------
+    def convert_us_vec_to_us_mat(self, us_vec):
+        return np.reshape(np.asarray(us_vec), (n_u, self.S), 'F').T.copy()
+
+    def convert_us_mat_to_us_jaxvec(self, us_mat):
+        return np.reshape(np.asarray(us_mat), (self.S * n_u), 'C')
+
+    def initial_guess_us_mat(self):
+        us = np.zeros((self.S, n_u))
+        us[:, :(n_u - 1)] = (self.u_max + self.u_min) / 2.0 + 1e-2
+        return us
+
+    # ---- plumbing ----------------------------------------------------------
+    def _params(self, M=None):
+        p = _lib.DroneParams()
+        p.M, p.S = (self.M if M is None else M), self.S
+        p.dt, p.beta, p.drag = self.dt, self.beta, self.drag_coefficient
+        p.kp, p.kd = -float(P.feedback_gain[0, 0]), -float(P.feedback_gain[0, 3])
+        p.tol = OSQP_TOL
+        for i in range(6):
+            p.x_init[i] = float(P.x_init[i])
+            p.x_final[i] = float(P.x_final[i])
+        for j in range(n_obs):
+            p.obs_xy[j][0] = float(P.obs_positions[j, 0])
+            p.obs_xy[j][1] = float(P.obs_positions[j, 1])
+        return p
+
+    def _us_device(self, us_mat):
+        if isinstance(us_mat, torch.Tensor) and us_mat.is_cuda:
+            us = us_mat.float().contiguous()
+        else:
+            us = torch.as_tensor(np.ascontiguousarray(np.asarray(us_mat), dtype=np.float32), device=self.device)
+        if tuple(us.shape) != (self.S, n_u):
+            raise ValueError(f"us_mat must be ({self.S},{n_u}), got {tuple(us.shape)}")
+        return us
+
+    def _empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ---- rollout + constraint values (K1) ----------------------------------
+    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
+        """-> (Z [M], xs [S+1][6][M] or None, g [n_obs][S][M] or None), device tensors."""
+        dW, mass, Qsym = inputs if inputs is not None else (self._dW, self._mass, self._Qsym)
+        M = mass.numel()
+        us = self._us_device(us_mat)
+        Z = self._empty(M)
+        xs = self._empty(self.S + 1, n_x, M) if want_xs else None
+        g = self._empty(n_obs, self.S, M) if want_g else None
+        p = self._params(M)
+        _lib.check(self._lib.rato_drone_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass),
+                                             _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
+                                             _lib.current_stream()), "rato_drone_eval")
+        return Z, xs, g
+
+    def us_to_state_trajectories(self, us_mat):
+        """drone_risk.py:157-162 -> (M, S+1, n_x)."""
+        _, xs, _ = self.eval_device(us_mat, want_xs=True)
+        return xs.permute(2, 0, 1).double().cpu().numpy()
+
+    def us_to_state_trajectory(self, us_mat, mass, dWs):
+        """drone_risk.py:139-155, one sample -> (S+1, n_x)."""
+        Q = np.zeros((1, n_obs, 3, 3))
+        inputs = to_soa_inputs(np.asarray(dWs)[None], np.asarray([mass]), Q, self.device)
+        _, xs, _ = self.eval_device(us_mat, want_xs=True, inputs=inputs)
+        return xs[:, :, 0].double().cpu().numpy()
+
+    def final_constraints(self, xs):
+        return np.asarray(xs)[..., -1, :] - P.x_final
+
+    def obstacle_avoidance_constraints(self, xs, obs_Q):
+        """drone_risk.py:198-213: xs (S+1,n_x), obs_Q (n_obs,3,3) -> (n_obs,S);
+        also batched: (M,S+1,n_x), (M,n_obs,3,3) -> (M,n_obs,S)."""
+        xs, obs_Q = np.asarray(xs), np.asarray(obs_Q)
+        single = xs.ndim == 2
+        if single:
+            xs, obs_Q = xs[None], obs_Q[None]
+        M = xs.shape[0]
+        xs_d = torch.as_tensor(xs, device=self.device).permute(1, 2, 0).contiguous().float()
+        _, _, Qsym = to_soa_inputs(np.zeros((M, 1, 6)), np.ones(M), obs_Q, self.device)
+        g = self._empty(n_obs, self.S, M)
+        p = self._params(M)
+        _lib.check(self._lib.rato_drone_obstacle_constraints(C.byref(p), _lib.ptr(xs_d), _lib.ptr(Qsym),
+                                                             _lib.ptr(g), _lib.current_stream()),
+                   "rato_drone_obstacle_constraints")
+        out = g.permute(2, 0, 1).double().cpu().numpy()
+        return out[0] if single else out
+
+    # ---- linearization (K2 + K6) -------------------------------------------
+    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True):
+        """One SAA linearization pass on the device (drone_risk.py:239-296).
+
+        -> dict of device tensors:
+           G  [n_pairs][2][n_obs][M]  packed causal Jacobian (see rato_saa.h)
+           g_up [n_obs][S][M], Z [M],
+           du_sum [S][6] (float64: sums over samples of dx_S/du_{s,axis}),
+           rhs_sum [6]   (float64: sums of -v_final + v_final_du.u)
+        """
+        dW, mass, Qsym = inputs if inputs is not None else (self._dW, self._mass, self._Qsym)
+        M, S = mass.numel(), self.S
+        us = self._us_device(us_mat)
+        nblk = self._lib.rato_drone_linearize_nblocks(M)
+        o = out if out is not None else {}
+        G = o.get("G") if "G" in o else self._empty(max(num_pairs(S), 1), 2, n_obs, M)
+        g_up = o.get("g_up") if "g_up" in o else self._empty(n_obs, S, M)
+        Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
+        part_du = o.get("part_du") if "part_du" in o else self._empty(nblk, S, 6)
+        part_rhs = o.get("part_rhs") if "part_rhs" in o else self._empty(nblk, 6)
+        p = self._params(M)
+        _lib.check(self._lib.rato_drone_linearize(
+            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
+            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part_du), _lib.ptr(part_rhs), int(cols_per_thread),
+            _lib.current_stream()), "rato_drone_linearize")
+        du_sum = stats.sum_partials(part_du, out=o.get("du_sum"))
+        rhs_sum = stats.sum_partials(part_rhs, out=o.get("rhs_sum"))
+        return {"G": G, "g_up": g_up, "Z": Z, "du_sum": du_sum, "rhs_sum": rhs_sum,
+                "part_du": part_du, "part_rhs": part_rhs, "M": M}
+
+    def expand_final_du(self, du_sum, scale):
+        """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
+        S = self.S
+        d = np.asarray(du_sum, dtype=np.float64) * scale
+        out = np.zeros((n_x, n_u * S))
+        for a in range(3):
+            out[a, a::n_u] = d[:, a]
+            out[3 + a, a::n_u] = d[:, 3 + a]
+        return out
+
+    def expand_g_obs_du(self, G):
+        """packed G [n_pairs][2][n_obs][M] (host ndarray) -> dense (M,n_obs,S,n_u*S)."""
+        S = self.S
+        M = G.shape[-1]
+        dense = np.zeros((M, n_obs, S, n_u * S))
+        for t in range(1, S):
+            off = t * (t - 1) // 2
+            blk = G[off:off + t]                       # (t, 2, n_obs, M) over s < t
+            for a in range(2):
+                dense[:, :, t, a:n_u * t:n_u] = np.transpose(blk[:, a], (2, 1, 0))
+        return dense
+
+    def sample_means(self, us_mat):
+        """drone_risk.py:294-296 -> (final_du (6,3S), final_low (6,), final_up (6,))."""
+        r = self.linearize_device(us_mat)
+        final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / r["M"])
+        rhs = r["rhs_sum"].cpu().numpy() / r["M"]
+        return final_du, rhs, rhs.copy()
+
+    def get_all_constraints_coeffs(self, us_mat, mass, dWs, obs_Q):
+        """drone_risk.py:239-280 for ONE sample -> (v_final_du (6,3S),
+        val_final_lower (6,), val_final_upper (6,), g_obs_du (n_obs,S,3S), g_up (n_obs,S))."""
+        inputs = to_soa_inputs(np.asarray(dWs)[None], np.asarray([mass]), np.asarray(obs_Q)[None], self.device)
+        r = self.linearize_device(us_mat, inputs=inputs)
+        v_final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0)
+        rhs = r["rhs_sum"].cpu().numpy()
+        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())[0]
+        g_up = r["g_up"][:, :, 0].double().cpu().numpy()
+        return v_final_du, rhs, rhs.copy(), g_obs_du, g_up
+
+    def get_all_constraints_coeffs_batched(self, us_mat):
+        """vmap of the above over the model's samples (drone_risk.py:288-290), dense;
+        small M only.  -> (g_obs_du (M,n_obs,S,3S), g_up (M,n_obs,S))."""
+        r = self.linearize_device(us_mat)
+        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())
+        g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
+        return g_obs_du, g_up
+
+    # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------
+    def monte_carlo_cost(self, us_mat):
+        us = np.asarray(us_mat)
+        return P.dt * float(np.sum(np.diag(P.R)[None, :] * us * us))
+
+    def monte_carlo_no_collisions_constraint_verification(self, us_mat):
+        """vmap of drone_risk.py:656-662 -> (B_satisfied (M,) bool, max_constraint (M,))."""
+        Z, _, _ = self.eval_device(us_mat)
+        Zh = Z.double().cpu().numpy()
+        return Zh <= 1e-6, Zh
+
+    def monte_carlo_statistics(self, us_mat, alpha=None):
+        """Fused device path: rollout -> Z -> fraction satisfied, VaR, CVaR."""
+        Z, _, _ = self.eval_device(us_mat)
+        return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
+
+    monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
+    monte_carlo_var = staticmethod(stats.monte_carlo_var)

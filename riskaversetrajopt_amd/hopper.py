@@ -1,0 +1,160 @@
+"""Hopper uncertain-friction SAA constraint — the sample-dependent part of the
+reference's ``class Model`` (hopper/hopper.py:68-81,90-171,300-367,901-958) on
+the MI355X.  The sample-independent NLP rows and the IPOPT glue stay on the
+host and are out of scope."""
+import numpy as np
+import torch
+
+from . import _lib, stats
+
+# hopper.py:44-69
+S = 30
+M = 30
+T = 2.0
+n_x = 8
+n_u = 4
+mu_nom = 0.10
+num_mu_features = 30
+
+
+def phase_times(S):
+    """time_jump, time_land (hopper.py:48-49: 10, 20 at S=30)."""
+    return S // 3, (2 * S) // 3
+
+
+def sample_friction_fields(M, rng=None):
+    """hopper.py:70-74 / :975-979, same draw order on the global stream."""
+    rng = np.random if rng is None else rng
+    intensities = rng.uniform(0, 1, (M, num_mu_features))
+    intensities = np.sqrt(2 / num_mu_features) * intensities
+    intensities = 0.025 * intensities
+    thetas = rng.uniform(0, np.pi, (M, num_mu_features))
+    taus = rng.uniform(0, 2 * np.pi, (M, num_mu_features))
+    return intensities, thetas, taus
+
+
+def sample_friction_fields_device(M, seed=1, device='cuda:0'):
+    """Synthetic fields drawn in HBM in kernel layout [30][M] (fp32)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    r = lambda: torch.rand((num_mu_features, M), generator=g, device=device, dtype=torch.float32)
+    return (0.025 * float(np.sqrt(2 / num_mu_features))) * r(), float(np.pi) * r(), float(2 * np.pi) * r()
+
+
+class Model:
+    def __init__(self, M, method='baseline', alpha=0.1, S=S, fields=None, device='cuda:0', rng=None,
+                 verbose=False):
+        # hopper.py:91-104
+        if verbose:
+            print("Initializing Model with")
+            print("> method =", method)
+            print("> alpha  =", alpha)
+        self.method, self.alpha, self.S, self.M = method, alpha, S, M
+        self.time_jump, self.time_land = phase_times(S)
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        self.num_vars = (S + 1) * n_x + S * n_u + M + 2
+        if fields is None:
+            fields = sample_friction_fields(M, rng)
+        if fields != 'device':
+            z = 0.0 if method == 'baseline' else 1.0
+            self.intensities, self.thetas, self.taus = (z * np.asarray(f, dtype=np.float64) for f in fields)
+            self._a, self._th, self._tau = (
+                torch.as_tensor(f, device=self.device).t().contiguous().float()
+                for f in (self.intensities, self.thetas, self.taus))
+
+    @classmethod
+    def from_device(cls, a, theta, tau, method='saa', alpha=0.1, S=S):
+        self = cls(a.shape[1], method, alpha, S=S, fields='device', device=a.device)
+        self._a, self._th, self._tau = a.contiguous(), theta.contiguous(), tau.contiguous()
+        return self
+
+    # ---- variable layout (hopper.py:105-132) -------------------------------
+    def convert_z_to_variables(self, z):
+        nx, nu = (self.S + 1) * n_x, self.S * n_u
+        return z[:nx], z[nx:nx + nu], z[nx + nu:-2], z[-2], z[-1]
+
+    def convert_z_to_xs_us_mats(self, z):
+        xs_vec, us_vec, _, _, _ = self.convert_z_to_variables(np.asarray(z))
+        return (np.reshape(xs_vec, (n_x, self.S + 1), 'F').T.copy(),
+                np.reshape(us_vec, (n_u, self.S), 'F').T.copy())
+
+    def end_effector_position(self, x):
+        x = np.asarray(x)
+        return np.stack([x[..., 0] + x[..., 3] * np.sin(x[..., 2]),
+                         x[..., 1] - x[..., 3] * np.cos(x[..., 2])], axis=-1)
+
+    def contact_inputs(self, Z):
+        """Contact-phase mask of hopper.py:305-311 -> (px (C,), forces (C,2))."""
+        xs_mat, us_mat = self.convert_z_to_xs_us_mats(Z)
+        ee_x = self.end_effector_position(xs_mat)[:, 0]
+        px = np.concatenate([ee_x[:self.time_jump], ee_x[self.time_land:-1]])
+        forces = np.concatenate([us_mat[:self.time_jump, 2:], us_mat[self.time_land:, 2:]])
+        return px, forces
+
+    # ---- device path (K5) --------------------------------------------------
+    def slip_device(self, px, forces, lam=None, want_Z=True, want_h=True, want_deriv=False):
+        """lam: [C][M] multipliers or None.
+        -> dict of device tensors: Z [M], h/dh_dfz/dh_dpx [C][M], hess [C][2] (float64)."""
+        px = np.asarray(px, dtype=np.float32)
+        forces = np.asarray(forces, dtype=np.float32)
+        Cn, M = px.shape[0], self._a.shape[1]
+        dev = self.device
+        pxd = torch.as_tensor(px, device=dev)
+        fxd = torch.as_tensor(np.ascontiguousarray(forces[:, 0]), device=dev)
+        fzd = torch.as_tensor(np.ascontiguousarray(forces[:, 1]), device=dev)
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        Z = e(M) if want_Z else None
+        h = e(Cn, M) if want_h else None
+        dfz = e(Cn, M) if want_deriv else None
+        dpx = e(Cn, M) if want_deriv else None
+        lamd = part = None
+        if lam is not None:
+            lamd = (lam if isinstance(lam, torch.Tensor) else torch.as_tensor(np.asarray(lam), device=dev))
+            lamd = lamd.float().contiguous()
+            if tuple(lamd.shape) != (Cn, M):
+                raise ValueError(f"lam must be [C][M] = ({Cn},{M}), got {tuple(lamd.shape)}")
+            part = e(self._lib.rato_hopper_nblocks(M), Cn, 2)
+        _lib.check(self._lib.rato_hopper_slip(
+            M, Cn, _lib.ptr(pxd), _lib.ptr(fxd), _lib.ptr(fzd), _lib.ptr(self._a), _lib.ptr(self._th),
+            _lib.ptr(self._tau), _lib.ptr(lamd), _lib.ptr(Z), _lib.ptr(h), _lib.ptr(dfz), _lib.ptr(dpx),
+            _lib.ptr(part), _lib.current_stream()), "rato_hopper_slip")
+        hess = stats.sum_partials(part) if part is not None else None
+        return {"Z": Z, "h": h, "dh_dfz": dfz, "dh_dpx": dpx, "hess": hess}
+
+    def slip_risk_constraints(self, Z):
+        """hopper.py:300-367 -> gs (1 + M + M*C + 1,) ['saa'] or (M*C,) ['baseline']."""
+        Z = np.asarray(Z, dtype=np.float64)
+        _, _, ys, slack_var, t_risk = self.convert_z_to_variables(Z)
+        px, forces = self.contact_inputs(Z)
+        h = self.slip_device(px, forces, want_Z=False)["h"].t().double().cpu().numpy()   # (M,C)
+        M, Cn = h.shape
+        if self.method == 'baseline':
+            return (h - slack_var).reshape(M * Cn)
+        gs = np.zeros(1 + M + M * Cn + 1)
+        gs[0] = (M * self.alpha) * t_risk + np.sum(ys)
+        gs[1:1 + M] = -ys
+        gs[1 + M:1 + M + M * Cn] = (h - t_risk - ys[:, None] - slack_var).reshape(M * Cn)
+        return gs
+
+    def slip_partials(self, px, forces):
+        """(h, dh/dfz, dh/dpx), each (M,C) — the sample-dependent slices of jac_g."""
+        r = self.slip_device(px, forces, want_Z=False, want_deriv=True)
+        return tuple(r[k].t().double().cpu().numpy() for k in ("h", "dh_dfz", "dh_dpx"))
+
+    def slip_hessian_sums(self, px, forces, lam):
+        """(D1 (C,), D2 (C,)): lambda-weighted d2h/(dpx dfz), d2h/dpx^2 summed over samples."""
+        hess = self.slip_device(px, forces, lam=np.asarray(lam).T, want_Z=False, want_h=False,
+                                want_deriv=True)["hess"].cpu().numpy()
+        return hess[:, 0], hess[:, 1]
+
+    # ---- Monte-Carlo validation (hopper.py:901-958) ------------------------
+    def no_slip_constraints_verification(self, px, forces):
+        Zh = self.slip_device(px, forces, want_h=False)["Z"].double().cpu().numpy()
+        return Zh <= 1e-6, Zh
+
+    def monte_carlo_statistics(self, px, forces, alpha=None):
+        Z = self.slip_device(px, forces, want_h=False)["Z"]
+        return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
+
+    avar = staticmethod(stats.monte_carlo_avar)

@@ -1,0 +1,67 @@
+"""Monte-Carlo risk statistics on the device (``rato_risk_stats``) and the
+deterministic second stage of the sample mean (``rato_sum_partials``).
+
+Mirrors ``monte_carlo_avar`` (drone_risk.py:663-695, driving.py:639-671,
+hopper.py:926-958) and ``monte_carlo_var`` (drone_main_plot.py:640-652)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+SATISFIED_THRESHOLD = 1e-6   # ``B_satisfied = max_constraint <= 1e-6`` (drone_risk.py:661)
+
+_STAT_NAMES = ("var", "cvar", "frac_satisfied", "mean", "max", "count_satisfied", "tail_sum", "rank")
+
+
+def _as_device_f32(Z, device=None):
+    if isinstance(Z, torch.Tensor):
+        if not Z.is_cuda:
+            raise _lib.RatoError("risk statistics need a device tensor (no CPU fallback)")
+        return Z.contiguous().float()
+    return torch.as_tensor(np.asarray(Z, dtype=np.float32), device=device or 'cuda:0')
+
+
+def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None):
+    """Z: device tensor (M,) fp32 -> device tensor double[8] (see rato_saa.h).
+    Asynchronous on the current stream."""
+    lib = _lib.load()
+    Z = _as_device_f32(Z)
+    M = Z.numel()
+    nbytes = lib.rato_risk_stats_workspace_bytes(M)
+    if workspace is None:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=Z.device)
+    if out is None:
+        out = torch.empty(8, dtype=torch.float64, device=Z.device)
+    _lib.check(lib.rato_risk_stats(_lib.ptr(Z), M, float(alpha), float(thr), _lib.ptr(workspace),
+                                   workspace.numel(), _lib.ptr(out), _lib.current_stream()),
+               "rato_risk_stats")
+    return out
+
+
+def risk_stats(Z, alpha, thr=SATISFIED_THRESHOLD):
+    """-> dict with var, cvar, frac_satisfied, mean, max, ... (host floats)."""
+    out = risk_stats_device(Z, alpha, thr).cpu().numpy()
+    return dict(zip(_STAT_NAMES, out.tolist()))
+
+
+def monte_carlo_var(Z_samples, alpha):
+    """drone_main_plot.py:640-652."""
+    return risk_stats(Z_samples, alpha)["var"]
+
+
+def monte_carlo_avar(Z_samples, alpha):
+    """drone_risk.py:663-695 (exact minimiser instead of the OSQP LP)."""
+    return risk_stats(Z_samples, alpha)["cvar"]
+
+
+def sum_partials(part, scale=1.0, out=None):
+    """part: device (nblocks, ...) fp32 -> device double tensor of shape part.shape[1:]
+    holding scale * sum over blocks (fixed order, fp64)."""
+    lib = _lib.load()
+    nblocks = part.shape[0]
+    ncols = part[0].numel()
+    if out is None:
+        out = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
+    _lib.check(lib.rato_sum_partials(_lib.ptr(part), nblocks, ncols, float(scale), _lib.ptr(out),
+                                     _lib.current_stream()), "rato_sum_partials")
+    return out

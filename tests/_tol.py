@@ -1,0 +1,25 @@
+"""fp64 (reference / oracle) -> fp32 (device) tolerances, per quantity.  The
+reference computes in fp64 end to end (drone_risk.py:17); the kernels compute in
+fp32 on fp32-rounded inputs.  SURVEY.md §7 hard part 2."""
+import numpy as np
+
+STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the car)
+G_RTOL, G_ATOL = 2e-5, 1e-4                # constraint values (drone g reaches ~ -90)
+JAC_REL_ROWMAX = 1e-4                      # Jacobian entries, relative to the row's max |entry|
+MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
+RISK_ATOL = 1e-4                           # VaR / CVaR
+NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this
+
+
+def assert_jac_close(actual, desired, rel=JAC_REL_ROWMAX, axis=-1, what="jacobian"):
+    desired = np.asarray(desired)
+    scale = np.max(np.abs(desired), axis=axis, keepdims=True)
+    err = np.abs(np.asarray(actual) - desired)
+    bad = err > rel * np.maximum(scale, 1e-30) + 1e-12
+    assert not bad.any(), f"{what}: {bad.sum()} entries off; max err {err.max():.3e} vs row scale {scale.max():.3e}"
+
+
+def assert_satisfied_close(flags, Z_ref, thr=1e-6):
+    ref = Z_ref <= thr
+    diff = flags != ref
+    assert np.all(np.abs(Z_ref[diff] - thr) < NEAR_THRESHOLD), "satisfied flags differ away from the threshold"

@@ -1,0 +1,70 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950,
+loads, and exports every symbol include/rato_saa.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rato_saa.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rato_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from riskaversetrajopt_amd import _build, _lib
+    _build.build()
+    return _lib.load()
+
+
+def test_header_declares_expected_entry_points():
+    fns = header_functions()
+    for name in ("rato_drone_eval", "rato_drone_linearize", "rato_car_eval", "rato_car_linearize",
+                 "rato_hopper_slip", "rato_sum_partials", "rato_risk_stats"):
+        assert name in fns
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from riskaversetrajopt_amd import _lib
+    raw = ctypes.CDLL(_lib.lib_path())
+    for name in header_functions():
+        assert hasattr(raw, name), f"{name} declared in rato_saa.h but not exported"
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_abi_version_and_size_queries(lib):
+    assert lib.rato_abi_version() == 1
+    assert lib.rato_drone_linearize_nblocks(1000) == 4
+    assert lib.rato_drone_linearize_nblocks(0) < 0
+    S = 40
+    assert lib.rato_car_ego_scratch_floats(S) == (S + 1) * 4 + (S + 1) * 2 + (S + 1) * 2 * 2 * S
+    assert lib.rato_risk_stats_workspace_bytes(10000) > 5120 * 4
+
+
+def test_params_struct_layout_matches_header():
+    from riskaversetrajopt_amd import _lib
+    # 2 int32 + 6 float + 6 + 6 + 6 floats
+    assert ctypes.sizeof(_lib.DroneParams) == 4 * (2 + 6 + 18)
+    assert ctypes.sizeof(_lib.CarParams) == 4 * (2 + 5 + 8)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from riskaversetrajopt_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib._build, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.RatoError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "riskaversetrajopt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

@@ -1,0 +1,142 @@
+"""GPU parity: driving HIP path vs the fp64 oracle and golden fixtures;
+full-size properties at BASELINE config C3 (M=1e4, S=40)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _tol as tol
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _models(S, M, seed=0, method='saa'):
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving
+    samples = ocar.sample_uncertain_parameters(np.random.RandomState(seed), M, method, S)
+    return ocar.Model(*samples, method=method), driving.Model(M, method, 0.05, S=S, samples=samples)
+
+
+def swerve(S):
+    t = np.arange(S)[:, None]
+    return np.hstack([0.4 * np.cos(0.4 * t) - 0.2, 0.05 * np.sin(0.35 * t) + 0.01]) * (20.0 / S)
+
+
+def test_sampler_draw_order_matches_oracle():
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving
+    for method in ("saa", "baseline"):
+        a = ocar.sample_uncertain_parameters(np.random.RandomState(0), 6, method, 20)
+        np.random.seed(0)
+        m = driving.Model(6, method, 0.05)
+        for x, y in zip(a, (m.states_init, m.omegas_speed, m.omegas_repulsive, m.DWs)):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (40, 257), (11, 1)])
+def test_rollout_and_distances_vs_oracle(S, M):
+    o, d = _models(S, M)
+    us = swerve(S)
+    xs_o = o.us_to_state_trajectories(us)
+    np.testing.assert_allclose(d.us_to_state_trajectories(us), xs_o, rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+    np.testing.assert_allclose(d.separation_distances_at_all_times(us), o.separation_distances_at_all_times(xs_o),
+                               rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    np.testing.assert_allclose(
+        d.us_to_state_trajectory(us, o.states_init[0], o.omegas_speed[0], o.omegas_repulsive[0], o.DWs[0]),
+        xs_o[0], rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+    ok_o, Z_o = o.monte_carlo_separation_constraints_verification(us)
+    ok, Z = d.monte_carlo_separation_constraints_verification(us)
+    np.testing.assert_allclose(Z, Z_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    tol.assert_satisfied_close(ok, Z_o)
+
+
+@pytest.mark.parametrize("S,M,spt", [(20, 300, 0), (20, 100, 4), (20, 100, 8), (20, 100, 16), (40, 130, 0),
+                                      (40, 70, 16), (33, 65, 8), (2, 5, 4), (1, 3, 0)])
+def test_linearization_vs_oracle(S, M, spt):
+    o, d = _models(S, M)
+    us = swerve(S)
+    fdu_o, flo_o, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
+    r = d.linearize_device(us, cols_per_thread=spt)
+    gdu = d.expand_g_obs_du(r["G"].double().cpu().numpy())
+    tol.assert_jac_close(gdu, gdu_o, what="g_obs_du")
+    assert np.all(gdu[gdu_o == 0.0] == 0.0)
+    np.testing.assert_allclose(r["g_up"].t().cpu().numpy(), gup_o, rtol=5e-5, atol=2e-4)
+    tol.assert_jac_close(r["final_du"].cpu().numpy(), fdu_o[0], what="final_du")
+    np.testing.assert_allclose(r["final_rhs"].cpu().numpy(), flo_o[0], rtol=1e-5, atol=5e-5)
+    _, Z_o = o.monte_carlo_separation_constraints_verification(us)
+    np.testing.assert_allclose(r["Z"].cpu().numpy(), Z_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+
+
+def test_grouping_is_bitwise_consistent_and_deterministic():
+    _, d = _models(40, 200)
+    us = swerve(40)
+    ref = d.linearize_device(us, cols_per_thread=4)
+    for spt in (8, 16, 4):
+        r = d.linearize_device(us, cols_per_thread=spt)
+        assert bool((r["G"] == ref["G"]).all()) and bool((r["g_up"] == ref["g_up"]).all())
+
+
+def test_single_sample_api_and_baseline():
+    S = 20
+    o, d = _models(S, 4)
+    us = swerve(S)
+    fdu_o, flo_o, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
+    i = 3
+    out = d.get_all_constraints_coeffs(us, o.states_init[i], o.omegas_speed[i], o.omegas_repulsive[i], o.DWs[i])
+    assert out[0].shape == (4, 2 * S) and out[3].shape == (S, 2 * S) and out[4].shape == (S,)
+    tol.assert_jac_close(out[3], gdu_o[i], what="g_obs_du")
+    np.testing.assert_allclose(out[4], gup_o[i], rtol=5e-5, atol=2e-4)
+    ob, db = _models(S, 5, method='baseline')
+    np.testing.assert_allclose(db.us_to_state_trajectories(us), ob.us_to_state_trajectories(us),
+                               rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+
+
+@pytest.mark.parametrize("name", ["driving_S20_M16", "driving_S40_M8"])
+def test_golden_fixture(name):
+    from riskaversetrajopt_amd import driving
+    f = np.load(os.path.join(G, name + ".npz"))
+    S, M = int(f["S"]), int(f["M"])
+    d = driving.Model(M, 'saa', 0.05, S=S,
+                      samples=(f["states_init"], f["omegas_speed"], f["omegas_repulsive"], f["DWs"]))
+    for kind in ("init", "swerve"):
+        us = f[f"{kind}_us"]
+        np.testing.assert_allclose(d.us_to_state_trajectories(us), f[f"{kind}_xs"],
+                                   rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+        gdu, gup = d.get_all_constraints_coeffs_batched(us)
+        tol.assert_jac_close(gdu, f[f"{kind}_g_obs_du"], what="g_obs_du")
+        np.testing.assert_allclose(gup, f[f"{kind}_g_up"], rtol=5e-5, atol=2e-4)
+        fdu, flo, _ = d.sample_means(us)
+        tol.assert_jac_close(fdu, f[f"{kind}_final_du"][0], what="final_du")
+        np.testing.assert_allclose(flo, f[f"{kind}_final_low"][0], rtol=1e-5, atol=5e-5)
+        st = d.monte_carlo_statistics(us, alpha=0.3)
+        assert abs(st["var"] - f[f"{kind}_var"]) < tol.RISK_ATOL * max(1.0, abs(f[f"{kind}_var"]))
+        assert abs(st["cvar"] - f[f"{kind}_avar"]) < tol.RISK_ATOL * max(1.0, abs(f[f"{kind}_avar"]))
+
+
+def test_full_size_C3_properties():
+    import torch
+    from oracle import driving as ocar, stats as ostats
+    S, M = 40, 10000
+    o, d = _models(S, M)
+    us = swerve(S)
+    r = d.linearize_device(us)
+    _, _, g = d.eval_device(us, want_g=True)
+    u = torch.as_tensor(us, dtype=torch.float32, device=g.device)
+    Gu = torch.zeros_like(g)
+    for t in range(1, S):
+        off = t * (t - 1) // 2
+        Gu[t] = (r["G"][off:off + t] * u[:t, :, None]).sum(dim=(0, 1))
+    assert (r["g_up"] + g - Gu).abs().max().item() < 2e-3
+    Z_eval, _, _ = d.eval_device(us)
+    assert bool((Z_eval == r["Z"]).all())
+    ok_o, Z_o = o.monte_carlo_separation_constraints_verification(us)
+    st = d.monte_carlo_statistics(us, alpha=0.05)
+    assert abs(st["frac_satisfied"] - ok_o.mean()) <= np.sum(np.abs(Z_o - 1e-6) < tol.NEAR_THRESHOLD) / M + 1e-12
+    assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.05)) < 2e-4
+    assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.05)) < 2e-4
+    idx = np.arange(0, M, 997)
+    sub = ocar.Model(o.states_init[idx], o.omegas_speed[idx], o.omegas_repulsive[idx], o.DWs[idx])
+    _, _, _, gdu_o, _ = sub.get_all_constraints_coeffs(us)
+    gdu = d.expand_g_obs_du(r["G"][..., torch.as_tensor(idx, device=g.device)].double().cpu().numpy())
+    tol.assert_jac_close(gdu, gdu_o, what="g_obs_du (sampled)")

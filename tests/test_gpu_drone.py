@@ -1,0 +1,187 @@
+"""GPU parity: drone HIP path (through the C ABI) vs the fp64 oracle and the
+committed golden fixtures; full-size properties at BASELINE config C2."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _tol as tol
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _models(S, M, seed=0, method='saa', alpha=0.1):
+    from oracle import drone as od
+    from riskaversetrajopt_amd import drone_risk
+    rng = np.random.RandomState(seed)
+    DWs, masses, obs_Qs = od.sample_uncertain_parameters(rng, method, M=M, S=S)
+    return od.Model(S, DWs, masses, obs_Qs, method, alpha), drone_risk.Model(S, DWs, masses, obs_Qs, method, alpha)
+
+
+def graze(S):
+    t = np.arange(S)[:, None]
+    return np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+
+
+def test_sampler_draw_order_matches_oracle():
+    from oracle import drone as od
+    from riskaversetrajopt_amd import drone_utils
+    a = od.sample_uncertain_parameters(np.random.RandomState(0), 'saa', M=7, S=20)
+    np.random.seed(0)
+    b = drone_utils.sample_uncertain_parameters('saa', M=7)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    a = od.sample_uncertain_parameters(np.random.RandomState(3), 'baseline', M=5, S=20)
+    b = drone_utils.sample_uncertain_parameters('baseline', M=5, rng=np.random.RandomState(3))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (50, 257), (30, 64), (7, 1)])
+def test_rollout_and_constraints_vs_oracle(S, M):
+    o, d = _models(S, M)
+    us = graze(S)
+    xs_o = o.us_to_state_trajectories(us)
+    np.testing.assert_allclose(d.us_to_state_trajectories(us), xs_o, rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+    g_o = o.obstacle_avoidance_constraints(xs_o, o.obs_Qs)
+    _, _, g = d.eval_device(us, want_g=True)
+    np.testing.assert_allclose(g.permute(2, 0, 1).cpu().numpy(), g_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    # obstacle_avoidance_constraints on given trajectories (single-sample and batched forms)
+    np.testing.assert_allclose(d.obstacle_avoidance_constraints(xs_o, o.obs_Qs), g_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    np.testing.assert_allclose(d.obstacle_avoidance_constraints(xs_o[0], o.obs_Qs[0]), g_o[0],
+                               rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    # single-sample rollout API
+    np.testing.assert_allclose(d.us_to_state_trajectory(us, o.masses[0], o.DWs[0]), xs_o[0],
+                               rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+    ok_o, Z_o = o.monte_carlo_no_collisions_constraint_verification(us)
+    ok, Z = d.monte_carlo_no_collisions_constraint_verification(us)
+    np.testing.assert_allclose(Z, Z_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    tol.assert_satisfied_close(ok, Z_o)
+
+
+@pytest.mark.parametrize("S,M,cpt", [(20, 300, 0), (20, 100, 4), (20, 100, 8), (20, 100, 16), (20, 100, 32),
+                                      (50, 130, 0), (50, 70, 16), (50, 70, 32), (33, 65, 8), (2, 5, 4), (1, 3, 0)])
+def test_linearization_vs_oracle(S, M, cpt):
+    o, d = _models(S, M)
+    us = graze(S)
+    fdu_o, flo_o, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
+    r = d.linearize_device(us, cols_per_thread=cpt)
+    gdu = d.expand_g_obs_du(r["G"].double().cpu().numpy())
+    tol.assert_jac_close(gdu, gdu_o, what="g_obs_du")
+    # exact structural zeros survive the packing
+    assert np.all(gdu[gdu_o == 0.0] == 0.0)
+    np.testing.assert_allclose(r["g_up"].permute(2, 0, 1).cpu().numpy(), gup_o, rtol=5e-5, atol=2e-4)
+    _, Z_o = o.monte_carlo_no_collisions_constraint_verification(us)
+    np.testing.assert_allclose(r["Z"].cpu().numpy(), Z_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    fdu = d.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
+    np.testing.assert_allclose(fdu, fdu_o.mean(0), rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)
+    np.testing.assert_allclose(r["rhs_sum"].cpu().numpy() / M, flo_o.mean(0), rtol=tol.MEAN_RTOL, atol=2e-5)
+
+
+def test_column_grouping_is_bitwise_consistent():
+    """every cols_per_thread variant runs the same per-column arithmetic"""
+    _, d = _models(50, 200)
+    us = graze(50)
+    ref = d.linearize_device(us, cols_per_thread=4)
+    for cpt in (8, 16, 32):
+        r = d.linearize_device(us, cols_per_thread=cpt)
+        assert bool((r["G"] == ref["G"]).all()) and bool((r["g_up"] == ref["g_up"]).all())
+        np.testing.assert_array_equal(r["du_sum"].cpu().numpy(), ref["du_sum"].cpu().numpy())
+    again = d.linearize_device(us, cols_per_thread=4)       # run-to-run determinism
+    assert bool((again["G"] == ref["G"]).all())
+    np.testing.assert_array_equal(again["rhs_sum"].cpu().numpy(), ref["rhs_sum"].cpu().numpy())
+
+
+def test_single_sample_api_matches_reference_shapes():
+    S = 20
+    o, d = _models(S, 4)
+    us = graze(S)
+    fdu_o, flo_o, fup_o, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
+    i = 2
+    v_final_du, lo, up, g_obs_du, g_up = d.get_all_constraints_coeffs(us, o.masses[i], o.DWs[i], o.obs_Qs[i])
+    assert v_final_du.shape == (6, 3 * S) and g_obs_du.shape == (3, S, 3 * S) and g_up.shape == (3, S)
+    tol.assert_jac_close(v_final_du, fdu_o[i], what="v_final_du")
+    tol.assert_jac_close(g_obs_du, gdu_o[i], what="g_obs_du")
+    np.testing.assert_allclose(lo, flo_o[i], rtol=1e-5, atol=2e-5)
+    assert np.array_equal(lo, up)
+    np.testing.assert_allclose(g_up, gup_o[i], rtol=5e-5, atol=2e-4)
+
+
+def test_baseline_method_is_nominal_rollout():
+    o, d = _models(20, 9, method='baseline')
+    us = graze(20)
+    xs = d.us_to_state_trajectories(us)
+    assert np.all(xs == xs[0:1])
+    np.testing.assert_allclose(xs, o.us_to_state_trajectories(us), rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+
+
+@pytest.mark.parametrize("name", ["drone_S20_M16", "drone_S50_M8"])
+def test_golden_fixture(name):
+    from riskaversetrajopt_amd import drone_risk
+    f = np.load(os.path.join(G, name + ".npz"))
+    S, M = int(f["S"]), int(f["M"])
+    d = drone_risk.Model(S, f["DWs"], f["masses"], f["obs_Qs"], 'saa', float(f["alpha"]))
+    for kind in ("init", "graze"):
+        us = f[f"{kind}_us"]
+        np.testing.assert_allclose(d.us_to_state_trajectories(us), f[f"{kind}_xs"],
+                                   rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
+        gdu, gup = d.get_all_constraints_coeffs_batched(us)
+        tol.assert_jac_close(gdu, f[f"{kind}_g_obs_du"], what="g_obs_du")
+        np.testing.assert_allclose(gup, f[f"{kind}_g_up"], rtol=5e-5, atol=2e-4)
+        fdu, flo, fup = d.sample_means(us)
+        np.testing.assert_allclose(fdu, f[f"{kind}_final_du_mean"], rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)
+        np.testing.assert_allclose(flo, f[f"{kind}_final_low_mean"], rtol=tol.MEAN_RTOL, atol=2e-5)
+        ok, Z = d.monte_carlo_no_collisions_constraint_verification(us)
+        np.testing.assert_allclose(Z, f[f"{kind}_Z"], rtol=tol.G_RTOL, atol=tol.G_ATOL)
+        st = d.monte_carlo_statistics(us, alpha=0.3)
+        assert abs(st["var"] - f[f"{kind}_var"]) < tol.RISK_ATOL * max(1.0, abs(f[f"{kind}_var"]))
+        assert abs(st["cvar"] - f[f"{kind}_avar"]) < tol.RISK_ATOL * max(1.0, abs(f[f"{kind}_avar"]))
+
+
+def test_full_size_C2_properties():
+    """BASELINE config 2 (M=1e4, S=50): size-independent properties + a sampled
+    comparison with the oracle."""
+    import torch
+    from oracle import drone as od, stats as ostats
+    S, M = 50, 10000
+    o, d = _models(S, M, seed=0)
+    us = graze(S)
+    r = d.linearize_device(us)
+    G_dev = r["G"]
+    # linearity of the linearization: g_up + g == G.u (row sums through the packed layout)
+    _, _, g = d.eval_device(us, want_g=True)
+    u = torch.as_tensor(us, dtype=torch.float32, device=G_dev.device)
+    Gu = torch.zeros_like(g)
+    for t in range(1, S):
+        off = t * (t - 1) // 2
+        blk = G_dev[off:off + t]                                    # (t,2,3,M)
+        Gu[:, t, :] = (blk * u[:t, :2, None, None]).sum(dim=(0, 1))
+    resid = (r["g_up"] + g - Gu).abs().max().item()
+    assert resid < 5e-3 * max(1.0, g.abs().max().item() * 1e-2), resid
+    # Z from linearize == Z from eval, bitwise (same arithmetic)
+    Z_eval, _, _ = d.eval_device(us)
+    assert bool((Z_eval == r["Z"]).all())
+    # statistics vs the oracle on all 1e4 samples
+    ok_o, Z_o = o.monte_carlo_no_collisions_constraint_verification(us)
+    st = d.monte_carlo_statistics(us, alpha=0.1)
+    assert abs(st["frac_satisfied"] - ok_o.mean()) <= np.sum(np.abs(Z_o - 1e-6) < tol.NEAR_THRESHOLD) / M + 1e-12
+    assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.1)) < 2e-4 * max(1.0, abs(st["var"]))
+    assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.1)) < 2e-4 * max(1.0, abs(st["cvar"]))
+    # sampled Jacobian comparison
+    idx = np.arange(0, M, 997)
+    sub = od.Model(S, o.DWs[idx], o.masses[idx], o.obs_Qs[idx])
+    _, _, _, gdu_o, _ = sub.get_all_constraints_coeffs(us)
+    gdu = d.expand_g_obs_du(G_dev[..., torch.as_tensor(idx, device=G_dev.device)].double().cpu().numpy())
+    tol.assert_jac_close(gdu, gdu_o, what="g_obs_du (sampled)")
+    # means vs the oracle over the full batch (oracle evaluated in chunks of 1000 samples)
+    acc = np.zeros((6, 3 * S))
+    for lo in range(0, M, 1000):
+        sl = slice(lo, lo + 1000)
+        part = od.Model(S, o.DWs[sl], o.masses[sl], o.obs_Qs[sl])
+        Phi = part.sensitivities(us, part.us_to_state_trajectories(us))
+        for a in range(3):
+            acc[a, a::3] += Phi[:, S, a, :, 0].sum(0)
+            acc[3 + a, a::3] += Phi[:, S, a, :, 1].sum(0)
+    np.testing.assert_allclose(d.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M), acc / M,
+                               rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)

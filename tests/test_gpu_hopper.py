@@ -1,0 +1,124 @@
+"""GPU parity: hopper slip kernels vs the fp64 oracle and golden fixtures;
+full-size properties at BASELINE config C4 (M=5e4, S=60, 40 contacts)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+H_ATOL = 2e-5      # h = fx - mu fz with fz ~ 32, mu ~ 0.1: fp32 rounding of mu*fz ~ 4e-7, 30-term sums
+MU_ATOL = 2e-6
+
+
+def _models(S, M, seed=1, method='saa', alpha=0.2):
+    from oracle import hopper as oh
+    from riskaversetrajopt_amd import hopper
+    fields = oh.sample_friction_fields(np.random.RandomState(seed), M)
+    return oh.Model(*fields, method=method, alpha=alpha, S=S), hopper.Model(M, method, alpha, S=S, fields=fields)
+
+
+def synthetic_Z(model, seed=5):
+    rng = np.random.RandomState(seed)
+    S, M = model.S, model.M
+    Z = np.zeros(model.num_vars)
+    xs = np.zeros((S + 1, 8))
+    xs[:, 0] = np.linspace(0, 0.15, S + 1)
+    xs[:, 1] = 1.0
+    xs[:, 2] = 0.2 * np.sin(np.linspace(0, 3, S + 1))
+    xs[:, 3] = 0.9 + 0.1 * np.cos(np.linspace(0, 2, S + 1))
+    us = np.zeros((S, 4))
+    us[:, 3] = 32.0 + rng.randn(S)
+    us[:, 2] = 0.08 * us[:, 3] + 0.3 * rng.randn(S)
+    Z[:(S + 1) * 8] = xs.reshape(-1)
+    Z[(S + 1) * 8:(S + 1) * 8 + S * 4] = us.reshape(-1)
+    Z[(S + 1) * 8 + S * 4:-2] = 0.1 * rng.rand(M)
+    Z[-2], Z[-1] = 0.03, -0.4
+    return Z
+
+
+def test_sampler_draw_order_matches_oracle():
+    from oracle import hopper as oh
+    from riskaversetrajopt_amd import hopper
+    a = oh.sample_friction_fields(np.random.RandomState(1), 30)
+    np.random.seed(1)
+    b = hopper.sample_friction_fields(30)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("S,M", [(30, 30), (60, 700), (30, 1), (60, 257)])
+@pytest.mark.parametrize("method", ["saa", "baseline"])
+def test_slip_rows_vs_oracle(S, M, method):
+    o, d = _models(S, M, method=method)
+    Z = synthetic_Z(o)
+    np.testing.assert_allclose(d.slip_risk_constraints(Z), o.slip_risk_constraints(Z), rtol=0, atol=H_ATOL)
+    px, forces = o.contact_inputs(Z)
+    pxd, forcesd = d.contact_inputs(Z)
+    assert np.array_equal(px, pxd) and np.array_equal(forces, forcesd)
+    ok_o, Z_o = o.no_slip_constraints_verification(px, forces)
+    ok, Zs = d.no_slip_constraints_verification(px, forces)
+    np.testing.assert_allclose(Zs, Z_o, rtol=0, atol=H_ATOL)
+    assert np.all(np.abs(Z_o[ok != ok_o] - 1e-6) < 1e-4)
+
+
+@pytest.mark.parametrize("S,M", [(30, 30), (60, 300)])
+def test_partials_and_hessian_sums_vs_oracle(S, M):
+    o, d = _models(S, M)
+    Z = synthetic_Z(o)
+    px, forces = o.contact_inputs(Z)
+    h_o, dfz_o, dpx_o = o.slip_partials(px, forces)
+    h, dfz, dpx = d.slip_partials(px, forces)
+    np.testing.assert_allclose(h, h_o, rtol=0, atol=H_ATOL)
+    np.testing.assert_allclose(dfz, dfz_o, rtol=0, atol=MU_ATOL)
+    np.testing.assert_allclose(dpx, dpx_o, rtol=1e-5, atol=2e-5)
+    lam = np.random.RandomState(2).rand(*h_o.shape)
+    D1_o, D2_o = o.slip_hessian_sums(px, forces, lam)
+    D1, D2 = d.slip_hessian_sums(px, forces, lam)
+    np.testing.assert_allclose(D1, D1_o, rtol=2e-5, atol=1e-5 * np.sqrt(M))
+    np.testing.assert_allclose(D2, D2_o, rtol=2e-5, atol=1e-4 * np.sqrt(M))
+
+
+@pytest.mark.parametrize("name", ["hopper_S30_M30", "hopper_S60_M24"])
+def test_golden_fixture(name):
+    from riskaversetrajopt_amd import hopper
+    f = np.load(os.path.join(G, name + ".npz"))
+    S, M = int(f["S"]), int(f["M"])
+    fields = (f["intensities"], f["thetas"], f["taus"])
+    d = hopper.Model(M, 'saa', float(f["alpha"]), S=S, fields=fields)
+    np.testing.assert_allclose(d.slip_risk_constraints(f["Z"]), f["gs"], rtol=0, atol=H_ATOL)
+    db = hopper.Model(M, 'baseline', float(f["alpha"]), S=S, fields=fields)
+    np.testing.assert_allclose(db.slip_risk_constraints(f["Z"]), f["gs_baseline"], rtol=0, atol=H_ATOL)
+    h, dfz, dpx = d.slip_partials(f["px"], f["forces"])
+    np.testing.assert_allclose(dfz, f["dh_dfz"], rtol=0, atol=MU_ATOL)
+    np.testing.assert_allclose(dpx, f["dh_dpx"], rtol=1e-5, atol=2e-5)
+    D1, D2 = d.slip_hessian_sums(f["px"], f["forces"], f["lam"])
+    np.testing.assert_allclose(D1, f["D1"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(D2, f["D2"], rtol=2e-5, atol=1e-4)
+    st = d.monte_carlo_statistics(f["px"], f["forces"], alpha=0.2)
+    assert abs(st["var"] - f["var"]) < 5e-5 and abs(st["cvar"] - f["avar"]) < 5e-5
+
+
+def test_full_size_C4_properties():
+    """M=5e4, S=60 (40 contacts; the contact-phase mask is the 'hybrid branch')."""
+    from oracle import stats as ostats
+    S, M = 60, 50000
+    o, d = _models(S, M)
+    Z = synthetic_Z(o)
+    px, forces = o.contact_inputs(Z)
+    assert px.shape == (40,)
+    r = d.slip_device(px, forces, want_Z=True, want_h=True, want_deriv=True)
+    # Z is the max over contacts of h (atomic-max path == direct path)
+    assert bool((r["h"].max(dim=0).values == r["Z"]).all())
+    # dh/dfz == -mu and h == fx + dh_dfz*fz  (linearity in the forces)
+    import torch
+    fx = torch.as_tensor(forces[:, 0], dtype=torch.float32, device=r["h"].device)[:, None]
+    fz = torch.as_tensor(forces[:, 1], dtype=torch.float32, device=r["h"].device)[:, None]
+    assert (r["h"] - (fx + r["dh_dfz"] * fz)).abs().max().item() < 1e-5
+    # statistics against the oracle on all samples
+    ok_o, Z_o = o.no_slip_constraints_verification(px, forces)
+    np.testing.assert_allclose(r["Z"].cpu().numpy(), Z_o, rtol=0, atol=H_ATOL)
+    st = d.monte_carlo_statistics(px, forces, alpha=0.1)
+    assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.1)) < 5e-5
+    assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.1)) < 5e-5
