@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""bench.py — SAA inner-loop throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic samples
+resident in HBM: batched rollout -> control-Jacobian linearization -> sample
+mean -> chance-constraint / VaR / CVaR statistics (what one SCP iteration asks
+of the SAA inner loop).  Default workload = the configuration the metric is
+quoted on: drone_risk, M = 1e5 samples per GPU, S = 50 steps, fp32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — the dominant kernel's algorithmic HBM bytes / its launch time
+                 measured live with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline — the NumPy fp64 oracle ("port") timed on this box's host, on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+Other workloads (--workload driving|hopper, --M, --S, --mode eval) are for
+sweeps; they print the same line shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+B = 4                       # fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="drone", choices=["drone", "driving", "hopper"])
+    ap.add_argument("--mode", default="linearize", choices=["linearize", "eval"])
+    ap.add_argument("--M", type=int, default=0, help="samples per GPU (default: 1e5 drone/driving, 5e4 hopper)")
+    ap.add_argument("--S", type=int, default=0, help="steps (default: 50 drone, 40 driving, 60 hopper)")
+    ap.add_argument("--alpha", type=float, default=0.1)
+    ap.add_argument("--cols-per-thread", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=0)
+    return ap.parse_args()
+
+
+def graze_us(S, n_u):
+    t = np.arange(S)[:, None]
+    if n_u == 3:
+        return (np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S))
+    return np.hstack([0.4 * np.cos(0.4 * t) - 0.2, 0.05 * np.sin(0.35 * t) + 0.01]) * (20.0 / S)
+
+
+# ----------------------------------------------------------------- workloads
+class DroneWork:
+    name = "drone_risk"
+    kernel = "drone_linearize_kernel"
+
+    def __init__(self, args, device, seed):
+        from riskaversetrajopt_amd import drone_risk, drone_utils
+        self.S = args.S or 50
+        self.M = args.M or 100000
+        self.mode = args.mode
+        self.cpt = args.cols_per_thread
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
+        self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha)
+        self.us = self.model._us_device(graze_us(self.S, 3))
+        self.out = None
+        if self.mode == "linearize":
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt)   # allocates outputs once
+            self.out = {k: r[k] for k in ("G", "g_up", "Z", "part_du", "part_rhs", "du_sum", "rhs_sum")}
+        else:
+            self.kernel = "drone_eval_kernel"
+
+    def hot_kernel(self):
+        """Launch only the dominant kernel (between the timing events)."""
+        if self.mode == "linearize":
+            return self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
+        Z, _, _ = self.model.eval_device(self.us)
+        return {"Z": Z, "du_sum": None}
+
+    def sums(self, r):
+        import torch
+        if r["du_sum"] is None:
+            return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+        return torch.cat([r["du_sum"].reshape(-1), r["rhs_sum"].reshape(-1)])
+
+    def algorithmic_bytes(self):
+        M, S = self.M, self.S
+        eval_in = M * B * (3 * S + 1 + 9 + 1) + 3 * S * B          # dW, mass, Qsym, Z | us
+        if self.mode == "eval":
+            return eval_in
+        nblk = (M + 255) // 256
+        return eval_in + M * B * (3 * S + 3 * S * (S - 1)) + nblk * (6 * S + 6) * B   # g_up, G nnz | partials
+
+    def cpu_baseline(self, n, alpha):
+        from oracle import drone as od, stats as ostats
+        rng = np.random.RandomState(0)
+        DWs, masses, obs_Qs = od.sample_uncertain_parameters(rng, 'saa', M=n, S=self.S)
+        o = od.Model(self.S, DWs, masses, obs_Qs, 'saa', alpha)
+        us = graze_us(self.S, 3)
+
+        def step():
+            if self.mode == "linearize":
+                fdu, flo, _, gdu, gup = o.get_all_constraints_coeffs(us)
+                fdu.mean(0), flo.mean(0)
+            _, Z = o.monte_carlo_no_collisions_constraint_verification(us)
+            return ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha), np.mean(Z <= 1e-6)
+        return step
+
+
+class DrivingWork:
+    name = "driving"
+    kernel = "car_linearize_kernel"
+
+    def __init__(self, args, device, seed):
+        from riskaversetrajopt_amd import driving
+        self.S = args.S or 40
+        self.M = args.M or 100000
+        self.mode = args.mode
+        self.cpt = args.cols_per_thread
+        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
+        self.model = driving.Model.from_device(self.S, dW, x0, ws, wr, 'saa', args.alpha)
+        self.us = self.model._us_device(graze_us(self.S, 2))
+        self.out = None
+        if self.mode == "linearize":
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt)
+            self.out = {k: r[k] for k in ("G", "g_up", "Z", "final_du", "final_rhs")}
+        else:
+            self.kernel = "car_eval_kernel"
+
+    def hot_kernel(self):
+        if self.mode == "linearize":
+            return self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
+        Z, _, _ = self.model.eval_device(self.us)
+        return {"Z": Z}
+
+    def sums(self, r):
+        import torch
+        return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)   # final rows are sample independent
+
+    def algorithmic_bytes(self):
+        M, S = self.M, self.S
+        eval_in = M * B * (2 * S + 6 + 1) + 2 * S * B
+        if self.mode == "eval":
+            return eval_in
+        return eval_in + M * B * (S + S * (S - 1))
+
+    def cpu_baseline(self, n, alpha):
+        from oracle import driving as ocar, stats as ostats
+        o = ocar.Model(*ocar.sample_uncertain_parameters(np.random.RandomState(0), n, 'saa', self.S))
+        us = graze_us(self.S, 2)
+
+        def step():
+            if self.mode == "linearize":
+                o.get_all_constraints_coeffs(us)
+            _, Z = o.monte_carlo_separation_constraints_verification(us)
+            return ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha)
+        return step
+
+
+class HopperWork:
+    name = "hopper"
+    kernel = "hopper_slip_kernel"
+
+    def __init__(self, args, device, seed):
+        from riskaversetrajopt_amd import hopper
+        self.S = args.S or 60
+        self.M = args.M or 50000
+        self.mode = args.mode
+        a, th, tau = hopper.sample_friction_fields_device(self.M, seed=seed + 1, device=device)
+        self.model = hopper.Model.from_device(a, th, tau, 'saa', args.alpha, S=self.S)
+        tj, tl = hopper.phase_times(self.S)
+        self.C = tj + (self.S - tl)
+        rng = np.random.RandomState(5)
+        self.px = np.linspace(0.0, 0.2, self.C)
+        fz = 32.0 + rng.randn(self.C)
+        self.forces = np.stack([0.08 * fz + 0.3 * rng.randn(self.C), fz], axis=1)
+        import torch
+        self.lam = torch.rand((self.C, self.M), device=device)
+
+    def hot_kernel(self):
+        if self.mode == "linearize":
+            return self.model.slip_device(self.px, self.forces, lam=self.lam, want_deriv=True)
+        return self.model.slip_device(self.px, self.forces, want_h=False)
+
+    def sums(self, r):
+        import torch
+        if r.get("hess") is None:
+            return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+        return r["hess"].reshape(-1)
+
+    def algorithmic_bytes(self):
+        M, C = self.M, self.C
+        if self.mode == "eval":
+            return M * B * (90 + 1)
+        return M * B * (90 + 1) + M * C * 4 * B       # h, dh_dfz, dh_dpx out + lam in
+
+    def cpu_baseline(self, n, alpha):
+        from oracle import hopper as oh, stats as ostats
+        o = oh.Model(*oh.sample_friction_fields(np.random.RandomState(1), n), method='saa', alpha=alpha, S=self.S)
+        lam = np.random.RandomState(2).rand(n, self.C)
+
+        def step():
+            if self.mode == "linearize":
+                o.slip_partials(self.px, self.forces)
+                o.slip_hessian_sums(self.px, self.forces, lam)
+            _, Z = o.no_slip_constraints_verification(self.px, self.forces)
+            return ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha)
+        return step
+
+
+WORKLOADS = {"drone": DroneWork, "driving": DrivingWork, "hopper": HopperWork}
+CPU_SAMPLES = {"drone": 4000, "driving": 3000, "hopper": 50000}
+
+
+def pmc_traffic(workload, mode, M, S):
+    """HBM bytes per launch from the committed PMC profile, if one matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        for rec in json.load(open(path)):
+            if (rec["workload"], rec["mode"], rec["M"], rec["S"]) == (workload, mode, M, S):
+                return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, stats
+
+    rank, world, local = rdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    work = WORKLOADS[args.workload](args, device, seed=1000 * rank + 7)
+    M, S = work.M, work.S
+    unit_steps = getattr(work, "C", S)        # hopper: the unit is a sample-contact
+    ws_bytes = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(M * world), dtype=torch.uint8, device=device)
+    stats_out = torch.empty(8, dtype=torch.float64, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        r = work.hot_kernel()
+        if i is not None:
+            ev[i][1].record()
+        sums, Z_all = rdist.exchange(work.sums(r), r["Z"])        # the one collective (no-op at N=1)
+        stats.risk_stats_device(Z_all, args.alpha, workspace=ws_bytes, out=stats_out)
+        return sums
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    final_stats = stats_out.cpu().numpy()
+
+    if rank == 0:
+        value = world * M * unit_steps * args.steps / elapsed
+        alg = work.algorithmic_bytes()
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "SAA constraint-eval throughput",
+            "value": value,
+            "unit": "samples*steps/s" if args.workload != "hopper" else "samples*contacts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{work.name} {args.mode}: rollout+Jacobian+mean+VaR/CVaR, "
+                                   f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}",
+                       "M_per_gpu": M, "S": S, "M_total": world * M,
+                       "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step"},
+            "roofline": {"bound": "hbm", "kernel": work.kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "frac_of_measured_copy_6290": achieved / 6290.0,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
+                         "traffic": pmc_traffic(args.workload, args.mode, M, S)},
+            "stats": {"VaR": final_stats[0], "CVaR": final_stats[1], "frac_satisfied": final_stats[2]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n = args.cpu_samples or CPU_SAMPLES[args.workload]
+            cpu_step = work.cpu_baseline(n, args.alpha)
+            cpu_step()                                     # warm-up
+            reps, t_cpu = 0, 0.0
+            while t_cpu < 10.0 and reps < 5:
+                t1 = time.perf_counter()
+                cpu_step()
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            cpu_val = n * unit_steps * reps / t_cpu
+            line["cpu_baseline"] = {
+                "value": cpu_val, "unit": line["unit"], "cores": 1, "kind": "port",
+                "sample": f"NumPy fp64 oracle (restatement of the reference's path; the reference's JAX/XLA-CPU "
+                          f"path is not installable here), same workload at M={n}, {reps} rep(s), "
+                          f"{t_cpu:.1f} s; host has {os.cpu_count()} cores",
+                "gpu_over_cpu": value / cpu_val}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

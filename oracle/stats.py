@@ -26,7 +26,10 @@ def monte_carlo_avar(Z_samples, alpha):
     value is <= the reference's (equal up to OSQP's tolerance).
     """
     Z = np.asarray(Z_samples, dtype=np.float64)
-    t_risk = monte_carlo_var(Z, alpha)
+    M = len(Z)
+    # index M - floor(alpha M) - 1, clamped at 0: when floor(alpha M) == M the
+    # minimiser is min(Z) (monte_carlo_var's own index would wrap to max(Z) there)
+    t_risk = np.sort(Z)[max(M - int(np.floor(alpha * M)) - 1, 0)]
     return t_risk + np.mean(np.maximum(Z - t_risk, 0.0)) / alpha
 
 

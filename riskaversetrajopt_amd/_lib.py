@@ -57,6 +57,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64; it must be the HIP runtime already in the
+    # process when our library binds, or launches land in a second runtime that owns
+    # none of torch's device allocations (seen as hipErrorNoDevice).
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise RatoError(
@@ -84,3 +88,15 @@ def ptr(t):
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_f32_device(t, name):
+    """Kernels read raw fp32 device memory: reject anything else loudly."""
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RatoError(f"{name} must be a device tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RatoError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RatoError(f"{name} must be contiguous")
+    return t

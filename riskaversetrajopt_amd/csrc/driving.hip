@@ -286,6 +286,7 @@ extern "C" size_t rato_car_ego_scratch_floats(int32_t S) { return S > 0 ? ego_to
 extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const float* dW, const float* x0_ped,
                              const float* w_speed, const float* w_rep, float* ego_scratch, float* Z, float* xs,
                              float* g, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
   hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, (float*)nullptr,
@@ -300,6 +301,7 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
                                   const float* x0_ped, const float* w_speed, const float* w_rep,
                                   float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
                                   float* final_rhs, int32_t cols_per_thread, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
     return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);

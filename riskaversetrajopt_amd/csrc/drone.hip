@@ -283,6 +283,7 @@ bool params_ok(const rato_drone_params* p) {
 
 extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW, const float* mass,
                                const float* Qsym, float* Z, float* xs, float* g, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_eval_kernel, grid, block, 0, rato::as_stream(stream), *p, us, dW, mass, Qsym, Z, xs, g);
@@ -292,6 +293,7 @@ extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, cons
 
 extern "C" int rato_drone_obstacle_constraints(const rato_drone_params* p, const float* xs, const float* Qsym,
                                                float* g, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!params_ok(p) || !xs || !Qsym || !g) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M), p->S), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_obstacle_kernel, grid, block, 0, rato::as_stream(stream), *p, xs, Qsym, g);
@@ -318,6 +320,7 @@ int launch_linearize(const rato_drone_params* p, const float* us, const float* d
 extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym, float* G, float* g_up, float* Z,
                                     float* part_du, float* part_rhs, int32_t cols_per_thread, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part_du || !part_rhs) return RATO_EINVAL;
   int cpt = cols_per_thread;
   if (cpt == 0) {

@@ -101,6 +101,7 @@ extern "C" int rato_hopper_slip(int32_t M, int32_t C, const float* px, const flo
                                 const float* a, const float* theta, const float* tau, const float* lam,
                                 float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
                                 void* stream) {
+  RATO_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || !px || !fx || !fz || !a || !theta || !tau) return RATO_EINVAL;
   if (part_hess && !lam) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);

@@ -8,6 +8,10 @@
 #define RATO_BLOCK 256           // 4 waves per workgroup
 #define RATO_WAVE 64
 
+// hipGetLastError() is sticky per host thread: clear anything left behind by an
+// earlier, unrelated runtime call before launching, then check our own launches.
+#define RATO_CLEAR_ERROR() (void)hipGetLastError()
+
 #define RATO_LAUNCH_CHECK()                              \
   do {                                                   \
     hipError_t e__ = hipGetLastError();                  \

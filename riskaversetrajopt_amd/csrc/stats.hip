@@ -197,8 +197,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_tail(const float* __restrict__ 
   }
 }
 
-__global__ void rs_final(long M, double alpha, unsigned k, int nblocks, const Workspace* __restrict__ ws,
-                         double* __restrict__ out) {
+__global__ void rs_final(long M, double alpha, unsigned k, int var_is_max, int nblocks,
+                         const Workspace* __restrict__ ws, double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double s = 0, c = 0, m = -INFINITY, tail = 0;
   for (int b = 0; b < nblocks; ++b) {  // fixed order
@@ -208,7 +208,9 @@ __global__ void rs_final(long M, double alpha, unsigned k, int nblocks, const Wo
     tail += ws->blockpart[b][3];
   }
   const double t = (double)ws->tstar;
-  out[0] = t;                                  // VaR
+  // VaR = sort(Z)[M - floor(alpha M) - 1]; when floor(alpha M) == M the reference's
+  // index is -1, which NumPy wraps to the LAST element (drone_main_plot.py:651).
+  out[0] = var_is_max ? m : t;
   out[1] = t + (tail / (double)M) / alpha;     // CVaR (drone_risk.py:694)
   out[2] = c / (double)M;                      // fraction satisfied
   out[3] = s / (double)M;
@@ -222,6 +224,7 @@ __global__ void rs_final(long M, double alpha, unsigned k, int nblocks, const Wo
 
 extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale, double* out,
                                  void* stream) {
+  RATO_CLEAR_ERROR();
   if (!part || !out || nblocks <= 0 || ncols <= 0) return RATO_EINVAL;
   dim3 grid((ncols + SP_COLS - 1) / SP_COLS), block(SP_COLS * SP_ROWS);
   hipLaunchKernelGGL(sum_partials_kernel, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
@@ -236,13 +239,15 @@ extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
 
 extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
                                size_t workspace_bytes, double* out, void* stream) {
+  RATO_CLEAR_ERROR();
   if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
     return RATO_EINVAL;
   if (workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
   // ascending 0-based rank of sort(Z)[M - floor(alpha*M) - 1]  (drone_main_plot.py:649-651)
   long xth = (long)floor(alpha * (double)M);
   long kk = (long)M - xth - 1;
-  if (kk < 0) kk = 0;
+  const int var_is_max = kk < 0;
+  if (kk < 0) kk = 0;  // the Rockafellar-Uryasev minimiser is then min(Z)
   const unsigned k = (unsigned)kk;
   Workspace* ws = static_cast<Workspace*>(workspace);
   hipStream_t st = rato::as_stream(stream);
@@ -256,7 +261,7 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
   hipLaunchKernelGGL(rs_pass2, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_pass3, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_tail, grid, block, 0, st, Z, (long)M, k, ws);
-  hipLaunchKernelGGL(rs_final, dim3(1), dim3(64), 0, st, (long)M, alpha, k, (int)nb, ws, out);
+  hipLaunchKernelGGL(rs_final, dim3(1), dim3(64), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -1,0 +1,80 @@
+"""Sample-axis sharding across GPUs (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm).
+
+Every ★ function of the hot path is independent per sample, so each rank owns a
+contiguous block of samples and all per-sample outputs (G, g_up, Z) stay
+sharded.  The only cross-sample quantities are (1) the mean of the final-
+constraint linearization (drone_risk.py:294-296) and (2) the Monte-Carlo
+statistics (fraction satisfied, VaR, CVaR).  Both are served by ONE collective
+per evaluation: an all-gather of the packed record
+
+    [ fp64 partial sums (n_sums) | fp32 Z shard (M_local) ]
+
+after which every rank sums the partial sums in rank order (deterministic) and
+runs the same exact selection on the full Z.  The payload is tiny (4 MB at
+M = 1e6), i.e. latency-bound; an all-gather uses all point-to-point xGMI links
+at once, which suits this size better than a ring all-reduce of histograms.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank).  Single process -> (0, 1, 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(M_total, rank, world):
+    """Contiguous block of samples owned by ``rank`` (remainder spread over the
+    first ranks)."""
+    base, rem = divmod(M_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_record(sums64, Z32):
+    """-> uint8 tensor [8*n_sums + 4*M_local] (sums first: 8-byte aligned)."""
+    a = sums64.contiguous().view(torch.uint8).reshape(-1)
+    b = Z32.contiguous().view(torch.uint8).reshape(-1)
+    return torch.cat([a, b])
+
+
+def unpack_records(buf, world, n_sums, M_local):
+    """buf: uint8 [world * rec] -> (sums (world, n_sums) fp64, Z (world*M_local,) fp32)."""
+    rec = 8 * n_sums + 4 * M_local
+    buf = buf.view(world, rec)
+    sums = buf[:, :8 * n_sums].contiguous().view(torch.float64).view(world, n_sums)
+    Z = buf[:, 8 * n_sums:].contiguous().view(torch.float32).reshape(world * M_local)
+    return sums, Z
+
+
+def exchange(sums64, Z32, group=None):
+    """The single collective of an evaluation.  ``sums64``: rank-local fp64 sums
+    (any shape), ``Z32``: rank-local fp32 Z (M_local,) — equal M_local on all
+    ranks.  Returns (total_sums (like sums64), Z_all (world*M_local,))."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums64, Z32
+    world = dist.get_world_size(group)
+    n_sums, M_local = sums64.numel(), Z32.numel()
+    rec = pack_record(sums64.reshape(-1).to(torch.float64), Z32.to(torch.float32))
+    out = torch.empty(world * rec.numel(), dtype=torch.uint8, device=rec.device)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    sums, Z_all = unpack_records(out, world, n_sums, M_local)
+    total = sums[0].clone()
+    for r in range(1, world):          # fixed (rank) order: bitwise identical on every rank
+        total += sums[r]
+    return total.view(sums64.shape), Z_all

@@ -103,7 +103,8 @@ class Model:
     def from_device(cls, S, dW, x0_ped, w_speed, w_rep, method='saa', alpha=0.05):
         self = cls(w_speed.numel(), method, alpha, S=S, device=dW.device, samples='device')
         self._ego_init = P.state_init[:4].astype(np.float64)
-        self._dW, self._x0, self._ws, self._wr = (t.contiguous() for t in (dW, x0_ped, w_speed, w_rep))
+        self._dW, self._x0, self._ws, self._wr = (_lib.require_f32_device(t, n) for t, n in
+                                                  ((dW, "dW"), (x0_ped, "x0_ped"), (w_speed, "w_speed"), (w_rep, "w_rep")))
         return self
 
     # ---- layout helpers (driving.py:122-143) -------------------------------

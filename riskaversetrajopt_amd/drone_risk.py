@@ -68,7 +68,8 @@ class Model:
         """Batch already resident in HBM in kernel layout (throughput runs)."""
         self = cls(S, None, None, None, method, alpha, device=dW.device)
         self.DWs = self.masses = self.obs_Qs = None
-        self._dW, self._mass, self._Qsym = dW.contiguous(), mass.contiguous(), Qsym.contiguous()
+        self._dW, self._mass, self._Qsym = (_lib.require_f32_device(t, n) for t, n in
+                                            ((dW, "dW"), (mass, "mass"), (Qsym, "Qsym")))
         self.M = mass.numel()
         return self
 

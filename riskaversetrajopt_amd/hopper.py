@@ -66,7 +66,8 @@ class Model:
     @classmethod
     def from_device(cls, a, theta, tau, method='saa', alpha=0.1, S=S):
         self = cls(a.shape[1], method, alpha, S=S, fields='device', device=a.device)
-        self._a, self._th, self._tau = a.contiguous(), theta.contiguous(), tau.contiguous()
+        self._a, self._th, self._tau = (_lib.require_f32_device(t, n) for t, n in
+                                        ((a, "a"), (theta, "theta"), (tau, "tau")))
         return self
 
     # ---- variable layout (hopper.py:105-132) -------------------------------

@@ -58,6 +58,7 @@ def sum_partials(part, scale=1.0, out=None):
     """part: device (nblocks, ...) fp32 -> device double tensor of shape part.shape[1:]
     holding scale * sum over blocks (fixed order, fp64)."""
     lib = _lib.load()
+    _lib.require_f32_device(part, "part")
     nblocks = part.shape[0]
     ncols = part[0].numel()
     if out is None:

@@ -1,0 +1,88 @@
+"""CPU, world_size 2 over gloo: the sample-axis sharding and the single
+all-gather exchange of [partial sums | Z shard] (riskaversetrajopt_amd/dist.py).
+The merged statistics must equal the single-process ones on the concatenated
+batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M_total, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from riskaversetrajopt_amd import dist as rdist
+    r, w, _ = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    rng = np.random.RandomState(11)
+    Z_full = rng.randn(M_total).astype(np.float32)
+    sums_per_sample = rng.randn(M_total, 7)
+    lo, hi = rdist.shard_bounds(M_total, rank, world)
+    Z_local = torch.from_numpy(Z_full[lo:hi].copy())
+    sums_local = torch.from_numpy(sums_per_sample[lo:hi].sum(0))
+    total, Z_all = rdist.exchange(sums_local, Z_local)
+    np.save(os.path.join(tmpdir, f"Z_{rank}.npy"), Z_all.numpy())
+    np.save(os.path.join(tmpdir, f"sums_{rank}.npy"), total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_world2_gloo(tmp_path):
+    world, M_total = 2, 2048
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, M_total, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.RandomState(11)
+    Z_full = rng.randn(M_total).astype(np.float32)
+    sums_per_sample = rng.randn(M_total, 7)
+    Z0, Z1 = np.load(tmp_path / "Z_0.npy"), np.load(tmp_path / "Z_1.npy")
+    s0, s1 = np.load(tmp_path / "sums_0.npy"), np.load(tmp_path / "sums_1.npy")
+    assert np.array_equal(Z0, Z_full) and np.array_equal(Z1, Z_full)       # contiguous shards, rank order
+    assert np.array_equal(s0, s1)                                          # bitwise identical on every rank
+    half = M_total // 2
+    expect = sums_per_sample[:half].sum(0) + sums_per_sample[half:].sum(0)
+    np.testing.assert_array_equal(s0, expect)
+    # merged statistics == single-process statistics on the full batch
+    from oracle import stats as ostats
+    assert ostats.monte_carlo_var(Z0, 0.1) == ostats.monte_carlo_var(Z_full, 0.1)
+    assert ostats.monte_carlo_avar(Z0, 0.1) == ostats.monte_carlo_avar(Z_full, 0.1)
+
+
+def test_shard_bounds_cover_everything():
+    from riskaversetrajopt_amd import dist as rdist
+    for M_total in (1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [rdist.shard_bounds(M_total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == M_total
+            for a, b in zip(edges[:-1], edges[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    from riskaversetrajopt_amd import dist as rdist
+    sums = torch.arange(5, dtype=torch.float64) * 1.5
+    Z = torch.arange(9, dtype=torch.float32) - 3
+    rec = rdist.pack_record(sums, Z)
+    assert rec.dtype == torch.uint8 and rec.numel() == 8 * 5 + 4 * 9
+    s, z = rdist.unpack_records(torch.cat([rec, rec]), 2, 5, 9)
+    assert torch.equal(s[0], sums) and torch.equal(s[1], sums) and torch.equal(z, torch.cat([Z, Z]))
+
+
+def test_single_process_exchange_is_identity():
+    from riskaversetrajopt_amd import dist as rdist
+    sums, Z = torch.ones(3, dtype=torch.float64), torch.zeros(4)
+    a, b = rdist.exchange(sums, Z)
+    assert a is sums and b is Z
