@@ -1,0 +1,6 @@
+#!/bin/bash
+# usage: sweep_cpt.sh <workload> <M> <S> <cpts...>
+w=$1; M=$2; S=$3; shift 3
+for c in "$@"; do
+  python bench.py --workload $w --M $M --S $S --steps 10 --warmup 2 --no-cpu-baseline --cols-per-thread $c 2>/dev/null | python scratch/pline.py "$w M=$M S=$S cpt=$c"
+done
