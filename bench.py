@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--M", type=int, default=0, help="samples per GPU (default: 1e5 drone/driving, 5e4 hopper)")
     ap.add_argument("--S", type=int, default=0, help="steps (default: 50 drone, 40 driving, 60 hopper)")
     ap.add_argument("--alpha", type=float, default=0.1)
-    ap.add_argument("--cols-per-thread", type=int, default=0)
+    ap.add_argument("--cols-per-thread", type=int, default=0, help="0 auto; -1 row-parallel kernel (drone)")
+    ap.add_argument("--samples-per-lane", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0)
     return ap.parse_args()
@@ -68,21 +69,23 @@ class DroneWork:
         self.S = args.S or 50
         self.M = args.M or 100000
         self.mode = args.mode
-        self.cpt = args.cols_per_thread
+        self.cpt, self.spl = args.cols_per_thread, args.samples_per_lane
         dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
-        self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha)
+        self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M)
         self.us = self.model._us_device(graze_us(self.S, 3))
         self.out = None
         if self.mode == "linearize":
-            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt)   # allocates outputs once
-            self.out = {k: r[k] for k in ("G", "g_up", "Z", "part_du", "part_rhs", "du_sum", "rhs_sum")}
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl)
+            self.out = r                                                       # buffers are reused every step
+            self.variant = "cols_per_thread=%d samples_per_lane=%d" % (r["cols_per_thread"], r["samples_per_lane"])
         else:
             self.kernel = "drone_eval_kernel"
 
     def hot_kernel(self):
         """Launch only the dominant kernel (between the timing events)."""
         if self.mode == "linearize":
-            return self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
+            return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
+                                               out=self.out)
         Z, _, _ = self.model.eval_device(self.us)
         return {"Z": Z, "du_sum": None}
 
@@ -303,7 +306,8 @@ def main():
                                    f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}",
                        "M_per_gpu": M, "S": S, "M_total": world * M,
                        "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step"},
-            "roofline": {"bound": "hbm", "kernel": work.kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "frac_of_measured_copy_6290": achieved / 6290.0,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,

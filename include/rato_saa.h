@@ -24,6 +24,14 @@
  * identically zero unless s <= t-1 (position lags control by two steps), so
  * only the pairs (t, s), 0 <= s < t < S are stored, row-major in t:
  *     pair(t, s) = t*(t-1)/2 + s,   n_pairs = S*(S-1)/2.
+ * The Jacobian buffer G is tile-blocked SoA: samples are grouped in tiles of
+ * TILE consecutive samples and each tile is a contiguous [rows][TILE] block, so
+ * that one wave's / workgroup's output is one contiguous region that it writes
+ * as a stream:
+ *     G[tile][row][lane],  tile = m / TILE, lane = m % TILE,
+ *     n_tiles = ceil(M / TILE); lanes >= M of the last tile are not written.
+ * TILE depends on the kernel variant and is reported by the *_plan() call
+ * (64 for the row-parallel drone kernel, RATO_TILE = 256 otherwise).
  */
 #ifndef RATO_SAA_H
 #define RATO_SAA_H
@@ -39,6 +47,7 @@ extern "C" {
 #define RATO_EINVAL (-1)
 #define RATO_EHIP (-1000)
 
+#define RATO_TILE 256        /* samples per Jacobian tile (= workgroup size) */
 #define RATO_DRONE_NOBS 3   /* drone_params.py:34-43: n_obs = 3 */
 #define RATO_HOPPER_NFEAT 30 /* hopper.py:69: num_mu_features = 30 */
 
@@ -50,6 +59,8 @@ int rato_abi_version(void);
 /* Constants of drone_params.py:1-45 / Model.__init__ drone_risk.py:71-93. */
 typedef struct rato_drone_params {
   int32_t M;            /* samples in this shard */
+  int32_t ld;           /* row stride (floats) of every [..][M] array, ld >= M; a multiple
+                           of samples_per_lane (use a multiple of 4) */
   int32_t S;            /* control intervals; dt = T/S (drone_risk.py:82) */
   float dt;
   float beta;           /* diffusion magnitude, 1e-2 */
@@ -66,9 +77,10 @@ typedef struct rato_drone_params {
  * obstacle_avoidance_constraints (:169-213) and the Monte-Carlo closure
  * monte_carlo_no_collisions_constraint_verification (:656-662).
  *   us    [S][3]            controls
- *   dW    [S][3][M]         velocity rows 3..5 of the reference's DWs (M,S,6)
+ *   dW    [S][3][ld]        velocity rows 3..5 of the reference's DWs (M,S,6)
  *   mass  [M]
  *   Qsym  [3 obs][3][M]     (Q00, Q01+Q10, Q11) of obs_Q[:, :2, :2]
+ * (every "[M]" below is a row of p->ld floats of which the first M are used)
  * outputs (any may be NULL):
  *   Z     [M]               max_{j,t} g - tol
  *   xs    [S+1][6][M]       state trajectories (SoA of the reference's (M,S+1,6))
@@ -78,28 +90,38 @@ int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW
                     const float* mass, const float* Qsym,
                     float* Z, float* xs, float* g, void* stream);
 
-/* Grid shape used by rato_drone_linearize for (M, S): number of sample blocks
- * (rows of the partial-sum buffers).  Returns <0 on bad arguments. */
-int rato_drone_linearize_nblocks(int32_t M);
+/* Kernel variants of rato_drone_linearize:
+ *   cols_per_thread = -1            row-parallel adjoint kernel (default; needs
+ *                                   20*64*S + 16 bytes of LDS <= 160 KB, S >= 2)
+ *   cols_per_thread in {4,8,16,32}  forward column kernel, samples_per_lane 1
+ *   samples_per_lane 2 x cpt {4,8}, samples_per_lane 4 x cpt {2,4}
+ * This call resolves 0 / 0 ("let the library choose") to a concrete pair and
+ * returns the number of sample blocks the launch will use = rows of
+ * part_du / part_rhs.  Returns <0 on bad arguments. */
+int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
+                              int32_t* cols_per_thread, int32_t* samples_per_lane,
+                              int32_t* tile /* out: TILE of the G layout */);
 
 /*
  * Replaces vmap(Model.get_all_constraints_coeffs) (drone_risk.py:239-290) and
  * the per-block stage of the sample mean (:294-296).
  * outputs:
- *   G        [n_pairs][2 axes][3 obs][M]  d g[j,t] / d u[s,axis] for s<t
+ *   G        [n_tiles][n_pairs][2 axes][3 obs][TILE]
+ *                                         d g[j,t] / d u[s,axis] for s<t
  *                                         (the z-control column is identically 0)
  *   g_up     [3 obs][S][M]                -g + grad g . u   (:278)
  *   Z        [M] or NULL                  max_{j,t} g - tol at this iterate
  *   part_du  [nblocks][S][6]              per-block sums of d x_S / d u_{s,axis}:
  *                                         entries (P_x,P_y,P_z,V_x,V_y,V_z)
  *   part_rhs [nblocks][6]                 per-block sums of -v_final + v_final_du.u (:271)
- * cols_per_thread: 0 = choose from M; else one of 4, 8, 16, 32.
+ * cols_per_thread / samples_per_lane: see rato_drone_linearize_plan (0 = choose).
+ * All [..][M] arrays (dW, mass, Qsym, g_up, Z) use the row stride p->ld.
  */
 int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                          const float* mass, const float* Qsym,
                          float* G, float* g_up, float* Z,
                          float* part_du, float* part_rhs,
-                         int32_t cols_per_thread, void* stream);
+                         int32_t cols_per_thread, int32_t samples_per_lane, void* stream);
 
 /* Model.obstacle_avoidance_constraints on given trajectories (drone_risk.py:198-213).
  *   xs [S+1][6][M] -> g [3 obs][S][M] */
@@ -146,7 +168,7 @@ int rato_car_eval(const rato_car_params* p, const float* us, const float* dW,
 /*
  * Replaces vmap(Model.get_all_constraints_coeffs) (driving.py:260-307).
  * outputs:
- *   G        [n_pairs][2 controls][M]   d g_t / d u[s,i] for s<t
+ *   G        [n_tiles][n_pairs][2 controls][RATO_TILE]   d g_t / d u[s,i] for s<t
  *   g_up     [S][M]
  *   Z        [M] or NULL
  *   final_du [4][2S]   d x_S[0:4] / d u  (sample independent, so already the mean; :311)

@@ -12,7 +12,7 @@ c_stream = C.c_void_p
 
 
 class DroneParams(C.Structure):
-    _fields_ = [("M", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
+    _fields_ = [("M", C.c_int32), ("ld", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
                 ("drag", C.c_float), ("kp", C.c_float), ("kd", C.c_float), ("tol", C.c_float),
                 ("x_init", C.c_float * 6), ("x_final", C.c_float * 6),
                 ("obs_xy", (C.c_float * 2) * 3)]
@@ -28,8 +28,9 @@ class CarParams(C.Structure):
 SIGNATURES = {
     "rato_abi_version": (C.c_int, []),
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
-    "rato_drone_linearize_nblocks": (C.c_int, [C.c_int32]),
-    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [C.c_int32, c_stream]),
+    "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [C.c_int32, C.c_int32, c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_eval": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 9 + [c_stream]),
@@ -48,7 +49,8 @@ class RatoError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # RATO_SAA_LIB: alternate build of the same ABI (diagnostic builds under scratch/)
+    return os.environ.get("RATO_SAA_LIB") or _build.LIB_PATH
 
 
 def load():

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
   c.w_r = w_rep[m];
   c.cn = sqrtf(P.dt) * P.beta;
   float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+  // this workgroup's tile of the packed Jacobian: [n_pairs*2 rows][RATO_TILE lanes]
+  float* __restrict__ Gt = G + (size_t)blockIdx.x * ((size_t)rato::pair_row_offset(S) * 2 * RATO_TILE);
 
   int stp[SPT];
 #pragma unroll
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
       const float dirv = -(m0 * (Eu[(t + 1) * 2 + 0] - tpx) + m1 * (Eu[(t + 1) * 2 + 1] - tpy));
       g_up[(size_t)t * M + m] = -gt + dirv;  // driving.py:295
     }
-    const size_t row = (size_t)rato::pair_row_offset(t);
+    const int row = rato::pair_row_offset(t);
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
       if (stp[k] < t) {  // wave-uniform
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
             const int col = stp[k] * 2 + i;
             const float e0 = Epos[(size_t)((t + 1) * 2 + 0) * NC + col];
             const float e1 = Epos[(size_t)((t + 1) * 2 + 1) * NC + col];
-            G[((row + (size_t)stp[k]) * 2 + i) * M + m] = -(m0 * (e0 - spx[k][i]) + m1 * (e1 - spy[k][i]));
+            Gt[((row + stp[k]) * 2 + i) * RATO_TILE + (int)threadIdx.x] =
+                -(m0 * (e0 - spx[k][i]) + m1 * (e1 - spy[k][i]));
           }
         }
       }

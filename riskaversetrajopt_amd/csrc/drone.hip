@@ -21,7 +21,7 @@ struct SampleConsts {
 };
 
 __device__ __forceinline__ SampleConsts load_consts(const rato_drone_params& P, const float* __restrict__ mass,
-                                                    const float* __restrict__ Qsym, size_t M, size_t m) {
+                                                    const float* __restrict__ Qsym, size_t ld, size_t m) {
   SampleConsts c;
   c.inv_m = 1.0f / mass[m];
   c.a21 = -P.kp * P.dt * c.inv_m;
@@ -29,9 +29,9 @@ __device__ __forceinline__ SampleConsts load_consts(const rato_drone_params& P, 
   c.dtm = P.dt * c.inv_m;
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
-    c.q00[j] = Qsym[(size_t)(j * 3 + 0) * M + m];
-    c.qs[j] = Qsym[(size_t)(j * 3 + 1) * M + m];
-    c.q11[j] = Qsym[(size_t)(j * 3 + 2) * M + m];
+    c.q00[j] = Qsym[(size_t)(j * 3 + 0) * ld + m];
+    c.qs[j] = Qsym[(size_t)(j * 3 + 1) * ld + m];
+    c.q11[j] = Qsym[(size_t)(j * 3 + 2) * ld + m];
   }
   return c;
 }
@@ -50,11 +50,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ Z,
     float* __restrict__ xs, float* __restrict__ g) {
-  const size_t M = (size_t)P.M;
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
   if (m >= M) return;
   const int S = P.S;
-  const SampleConsts c = load_consts(P, mass, Qsym, M, m);
+  const SampleConsts c = load_consts(P, mass, Qsym, ld, m);
   float p[3], v[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -64,26 +64,26 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
   if (xs) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      xs[(size_t)a * M + m] = p[a];
-      xs[(size_t)(3 + a) * M + m] = v[a];
+      xs[(size_t)a * ld + m] = p[a];
+      xs[(size_t)(3 + a) * ld + m] = v[a];
     }
   }
   float zmax = -INFINITY;
   float xi[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * M + m];
+  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
   for (int t = 0; t < S; ++t) {
     float nxt[3];
     const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
 #pragma unroll
-    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * M + m];
+    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
 #pragma unroll
     for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
     if (xs) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        xs[((size_t)(t + 1) * 6 + a) * M + m] = p[a];
-        xs[((size_t)(t + 1) * 6 + 3 + a) * M + m] = v[a];
+        xs[((size_t)(t + 1) * 6 + a) * ld + m] = p[a];
+        xs[((size_t)(t + 1) * 6 + 3 + a) * ld + m] = v[a];
       }
     }
 #pragma unroll
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
       const float dx = p[0] - P.obs_xy[j][0], dy = p[1] - P.obs_xy[j][1];
       const float gj = 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
       zmax = fmaxf(zmax, gj);
-      if (g) g[((size_t)j * S + t) * M + m] = gj;
+      if (g) g[((size_t)j * S + t) * ld + m] = gj;
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
@@ -103,18 +103,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_obstacle_kernel(rato_drone_p
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ Qsym,
                                                                     float* __restrict__ g) {
-  const size_t M = (size_t)P.M;
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const int t = blockIdx.y;
   if (m >= M) return;
-  const float px = xs[((size_t)(t + 1) * 6 + 0) * M + m];
-  const float py = xs[((size_t)(t + 1) * 6 + 1) * M + m];
+  const float px = xs[((size_t)(t + 1) * 6 + 0) * ld + m];
+  const float py = xs[((size_t)(t + 1) * 6 + 1) * ld + m];
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
-    const float q00 = Qsym[(size_t)(j * 3 + 0) * M + m], qs = Qsym[(size_t)(j * 3 + 1) * M + m],
-                q11 = Qsym[(size_t)(j * 3 + 2) * M + m];
+    const float q00 = Qsym[(size_t)(j * 3 + 0) * ld + m], qs = Qsym[(size_t)(j * 3 + 1) * ld + m],
+                q11 = Qsym[(size_t)(j * 3 + 2) * ld + m];
     const float dx = px - P.obs_xy[j][0], dy = py - P.obs_xy[j][1];
-    g[((size_t)j * P.S + t) * M + m] = 1.0f - (q00 * dx * dx + qs * dx * dy + q11 * dy * dy);
+    g[((size_t)j * P.S + t) * ld + m] = 1.0f - (q00 * dx * dx + qs * dx * dy + q11 * dy * dy);
   }
 }
 
@@ -124,20 +124,89 @@ __device__ __forceinline__ int column_of(int k, int grp, int ngroups) {
   return k * ngroups + ((k & 1) ? (ngroups - 1 - grp) : grp);
 }
 
-template <int CPT>
+template <int N>
+struct Vec;
+template <>
+struct Vec<1> {
+  typedef float type;
+};
+template <>
+struct Vec<2> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec<4> {
+  typedef float type __attribute__((ext_vector_type(4)));
+};
+
+template <int N>
+__device__ __forceinline__ void vload(const float* __restrict__ src, float (&x)[N]) {
+  if constexpr (N == 1) {
+    x[0] = *src;
+  } else {
+    const typename Vec<N>::type v = *reinterpret_cast<const typename Vec<N>::type*>(src);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = v[i];
+  }
+}
+template <int N>
+__device__ __forceinline__ void vstore(float* __restrict__ dst, const float (&x)[N]) {
+  if constexpr (N == 1) {
+    *dst = x[0];
+  } else {
+    typename Vec<N>::type v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = x[i];
+    *reinterpret_cast<typename Vec<N>::type*>(dst) = v;
+  }
+}
+
+// CPT control columns and SPL consecutive samples per lane.  SPL > 1 turns every
+// global access into an 8/16-byte-per-lane vector access and lets the per-sample
+// arithmetic pair up into packed fp32 instructions (the SPL=1 form spends ~15
+// wave-instructions per stored dword and is issue-bound, not HBM-bound).
+template <int CPT, int SPL>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part_du,
     float* __restrict__ part_rhs) {
-  const size_t M = (size_t)P.M;
-  const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
-  const bool valid = m_raw < M;
-  const size_t m = valid ? m_raw : M - 1;  // clamp loads; stores are predicated
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
+  const size_t m_raw = ((size_t)blockIdx.x * RATO_BLOCK + threadIdx.x) * SPL;  // first sample of this lane
+  const bool any_valid = m_raw < M;
+  // clamp loads to the last in-range lane group; stores are predicated on any_valid
+  const size_t m0 = any_valid ? m_raw : ((M - 1) / SPL) * SPL;
+  bool vld[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) vld[i] = any_valid && (m0 + i < M);
   const int grp = blockIdx.y, ngroups = gridDim.y;
   const bool lead = (grp == 0);  // group 0 also emits g_up, Z and the rhs partial
-  const SampleConsts c = load_consts(P, mass, Qsym, M, m);
+
+  // per-sample constants
+  float inv_m[SPL], a21[SPL], cn[SPL], dtm[SPL];
+  float q00[NOBS][SPL], qs[NOBS][SPL], q11[NOBS][SPL];
+  {
+    float ms[SPL];
+    vload<SPL>(mass + m0, ms);
+    const float sdt_beta = sqrtf(P.dt) * P.beta;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+      inv_m[i] = 1.0f / ms[i];
+      a21[i] = -P.kp * P.dt * inv_m[i];
+      cn[i] = sdt_beta * inv_m[i];
+      dtm[i] = P.dt * inv_m[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) {
+      vload<SPL>(Qsym + (size_t)(j * 3 + 0) * ld + m0, q00[j]);
+      vload<SPL>(Qsym + (size_t)(j * 3 + 1) * ld + m0, qs[j]);
+      vload<SPL>(Qsym + (size_t)(j * 3 + 2) * ld + m0, q11[j]);
+    }
+  }
+  // this lane's slot in the tile-blocked Jacobian: tile = m0 / TILE, lane offset m0 % TILE
+  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * NOBS * RATO_TILE;
+  float* __restrict__ Gt = G + (m0 / RATO_TILE) * tile_floats + (m0 % RATO_TILE);
 
   int col[CPT];
 #pragma unroll
@@ -145,89 +214,135 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
     const int s = column_of(k, grp, ngroups);
     col[k] = (s < S) ? s : 0x7fffffff;
   }
-  // Phi[k][a] = (P, V) = d(p_a, v_a)_t / d u_{col[k], a}
-  float phiP[CPT][3], phiV[CPT][3];
+  // Phi[k][a][i] = (P, V) = d(p_a, v_a)_t / d u_{col[k], a} of sample i
+  float phiP[CPT][3][SPL], phiV[CPT][3][SPL];
 #pragma unroll
   for (int k = 0; k < CPT; ++k)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) phiP[k][a] = phiV[k][a] = 0.0f;
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) phiP[k][a][i] = phiV[k][a][i] = 0.0f;
 
-  float p[3], v[3], dp[3], dv[3];  // state and its tangent in the direction u (for g_up / rhs)
+  float p[3][SPL], v[3][SPL], dp[3][SPL], dv[3][SPL];  // state, and its tangent along u (g_up / rhs)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    p[a] = P.x_init[a];
-    v[a] = P.x_init[3 + a];
-    dp[a] = dv[a] = 0.0f;
-  }
-  float zmax = -INFINITY;
-  float xi[3];
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * M + m];
+    for (int i = 0; i < SPL; ++i) {
+      p[a][i] = P.x_init[a];
+      v[a][i] = P.x_init[3 + a];
+      dp[a][i] = dv[a][i] = 0.0f;
+    }
+  float zmax[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) zmax[i] = -INFINITY;
+  float xi[3][SPL];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) vload<SPL>(dW + (size_t)a * ld + m0, xi[a]);
 
   for (int t = 0; t < S; ++t) {
-    float nxt[3];
-    const int tn = (t + 1 < S) ? t + 1 : t;
+    float nxt[3][SPL];
+    const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
 #pragma unroll
-    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * M + m];
+    for (int a = 0; a < 3; ++a) vload<SPL>(dW + (size_t)(tn * 3 + a) * ld + m0, nxt[a]);
 
-    float a22[3];
+    float a22[3][SPL];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) a22[a] = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v[a])) * c.inv_m;
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < SPL; ++i)
+        a22[a][i] = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v[a][i])) * inv_m[i];
 
-    // tangent along u: d x_{t+1} = A_t d x_t + B u_t
+    if (lead) {  // tangent along u: d x_{t+1} = A_t d x_t + B u_t
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float u = us[t * 3 + a];
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          const float dpn = dp[a][i] + P.dt * dv[a][i];
+          const float dvn = a21[i] * dp[a][i] + a22[a][i] * dv[a][i] + dtm[i] * u;
+          dp[a][i] = dpn;
+          dv[a][i] = dvn;
+        }
+      }
+    }
+    // column sensitivities (columns not yet active hold exact zeros and are skipped)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      if (col[k] <= t) {  // wave-uniform
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            const float Pn = phiP[k][a][i] + P.dt * phiV[k][a][i];
+            const float Vn = a21[i] * phiP[k][a][i] + a22[a][i] * phiV[k][a][i];
+            phiP[k][a][i] = Pn;
+            phiV[k][a][i] = (col[k] == t) ? dtm[i] : Vn;  // Phi_{t+1,t} = B_t
+          }
+      }
+    }
+    // state (drone_risk.py:122-131,148-153)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float u = us[t * 3 + a];
-      const float dpn = dp[a] + P.dt * dv[a];
-      const float dvn = c.a21 * dp[a] + a22[a] * dv[a] + c.dtm * u;
-      dp[a] = dpn;
-      dv[a] = dvn;
-    }
-    // column sensitivities
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float Pn = phiP[k][a] + P.dt * phiV[k][a];
-        const float Vn = c.a21 * phiP[k][a] + a22[a] * phiV[k][a];
-        phiP[k][a] = Pn;
-        phiV[k][a] = (col[k] == t) ? c.dtm : Vn;  // Phi_{t+1,t} = B_t
+      for (int i = 0; i < SPL; ++i) {
+        const float acc = (u - (P.kp * p[a][i] + P.kd * v[a][i])) * inv_m[i] -
+                          P.drag * fabsf(v[a][i]) * v[a][i] * inv_m[i];
+        const float pn = p[a][i] + P.dt * v[a][i];
+        const float vn = v[a][i] + P.dt * acc + cn[i] * xi[a][i];
+        p[a][i] = pn;
+        v[a][i] = vn;
       }
     }
-    // state
-#pragma unroll
-    for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
-
     // constraint row t (uses p_{t+1}) and its gradient w = -(Q+Q^T) d
-    float wx[NOBS], wy[NOBS];
+    float wx[NOBS][SPL], wy[NOBS][SPL];
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
-      const float dx = p[0] - P.obs_xy[j][0], dy = p[1] - P.obs_xy[j][1];
-      const float gj = 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
-      wx[j] = -(2.0f * c.q00[j] * dx + c.qs[j] * dy);
-      wy[j] = -(c.qs[j] * dx + 2.0f * c.q11[j] * dy);
-      zmax = fmaxf(zmax, gj);
-      if (lead && valid) g_up[((size_t)j * S + t) * M + m] = -gj + wx[j] * dp[0] + wy[j] * dp[1];
+      float gu[SPL];
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        const float dx = p[0][i] - P.obs_xy[j][0], dy = p[1][i] - P.obs_xy[j][1];
+        const float gj = 1.0f - (q00[j][i] * dx * dx + qs[j][i] * dx * dy + q11[j][i] * dy * dy);
+        wx[j][i] = -(2.0f * q00[j][i] * dx + qs[j][i] * dy);
+        wy[j][i] = -(qs[j][i] * dx + 2.0f * q11[j][i] * dy);
+        zmax[i] = fmaxf(zmax[i], gj);
+        gu[i] = -gj + wx[j][i] * dp[0][i] + wy[j][i] * dp[1][i];
+      }
+      if (lead && any_valid) vstore<SPL>(g_up + ((size_t)j * S + t) * ld + m0, gu);
     }
-    const size_t row = (size_t)rato::pair_row_offset(t);
+    const int row = rato::pair_row_offset(t);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
       if (col[k] < t) {  // wave-uniform
-        const size_t base = ((row + (size_t)col[k]) * 2) * NOBS;
-        if (valid) {
+        // tile-blocked SoA: row = (pair*2 + axis)*NOBS + j; 32-bit offsets from the lane's tile slot
+        const int base = ((row + col[k]) * 2 * NOBS) * RATO_TILE;
+        if (any_valid) {
 #pragma unroll
           for (int j = 0; j < NOBS; ++j) {
-            G[(base + j) * M + m] = wx[j] * phiP[k][0];
-            G[(base + NOBS + j) * M + m] = wy[j] * phiP[k][1];
+            float ox[SPL], oy[SPL];
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) {
+              ox[i] = wx[j][i] * phiP[k][0][i];
+              oy[i] = wy[j][i] * phiP[k][1][i];
+            }
+            vstore<SPL>(Gt + base + j * RATO_TILE, ox);
+            vstore<SPL>(Gt + base + (NOBS + j) * RATO_TILE, oy);
           }
         }
       }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) xi[a][i] = nxt[a][i];
   }
 
-  if (lead && valid && Z) Z[m] = zmax - P.tol;
+  if (lead && any_valid && Z) {
+    float zo[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) zo[i] = zmax[i] - P.tol;
+    vstore<SPL>(Z + m0, zo);
+  }
 
   // per-block sums for the sample mean of the final-constraint linearization
   __shared__ float red[RATO_BLOCK / RATO_WAVE][CPT * 6 + 6];
@@ -236,8 +351,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
   for (int k = 0; k < CPT; ++k) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float sp = rato::wave_sum(valid ? phiP[k][a] : 0.0f);
-      const float sv = rato::wave_sum(valid ? phiV[k][a] : 0.0f);
+      float lp = 0.0f, lv = 0.0f;
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        lp += vld[i] ? phiP[k][a][i] : 0.0f;
+        lv += vld[i] ? phiV[k][a][i] : 0.0f;
+      }
+      const float sp = rato::wave_sum(lp);
+      const float sv = rato::wave_sum(lv);
       if (lane == 0) {
         red[wave][k * 6 + a] = sp;
         red[wave][k * 6 + 3 + a] = sv;
@@ -248,8 +369,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       // val_final = -(x_S - x_final) + v_final_du . u   (drone_risk.py:271)
-      const float rp = rato::wave_sum(valid ? (-(p[a] - P.x_final[a]) + dp[a]) : 0.0f);
-      const float rv = rato::wave_sum(valid ? (-(v[a] - P.x_final[3 + a]) + dv[a]) : 0.0f);
+      float lp = 0.0f, lv = 0.0f;
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        lp += vld[i] ? (-(p[a][i] - P.x_final[a]) + dp[a][i]) : 0.0f;
+        lv += vld[i] ? (-(v[a][i] - P.x_final[3 + a]) + dv[a][i]) : 0.0f;
+      }
+      const float rp = rato::wave_sum(lp);
+      const float rv = rato::wave_sum(lv);
       if (lane == 0) {
         red[wave][CPT * 6 + a] = rp;
         red[wave][CPT * 6 + 3 + a] = rv;
@@ -275,8 +402,256 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Row-parallel (adjoint) linearization — the default drone linearize kernel.
+//
+// The forward/column form above needs 6 registers per control column and
+// re-rolls the trajectory once per column group; it spends ~15 wave-
+// instructions per stored dword.  Here a workgroup owns 64 samples (one per
+// lane) and 8 waves:
+//   phase 0  all waves stage the block's noise tile dW[S][3][64] into LDS with
+//            every load in flight at once (a per-step global load would queue
+//            behind the chip-wide store stream for microseconds per step);
+//   phase 1  waves 0,1,2 roll out ONE AXIS each (the axes decouple:
+//            drone_risk.py:122-131) and leave a22_t (the only state-dependent
+//            entry of the step Jacobian) and p_{t+1} in LDS: 20 B per sample-step;
+//   phase 2  all waves pull tasks from an LDS work queue.  Row task t rebuilds
+//            g_j(t), w = -(Q+Q^T) d from p_{t+1} and sweeps the row with the adjoint
+//              mu_{t+1} = e_0^T,  mu_k = mu_{k+1} A_k,  d p_{t+1}/d u_s = mu_{s+1}[1] dt/m
+//            (A_k = [[1, dt], [a21, a22_k]], B = [0, dt/m]^T): 3 packed FMAs + 6
+//            multiplies per 6 stored dwords, ~40 VGPRs, one contiguous descending
+//            1.5 KB-per-step store stream per wave.  The sweep also accumulates the
+//            row's dot product with u, so g_up = -g + (grad g).u is exactly the
+//            reference's expression (drone_risk.py:278).  One extra task runs the
+//            adjoint from t = S for the final-state Jacobian (2 rows x 3 axes),
+//            reduces it over the block's samples and forms the rhs (:271).
+constexpr int ROWS_NW = 8;        // waves per workgroup
+constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+#ifndef RATO_DIAG
+#define RATO_DIAG 0  // diagnostic builds only (scratch/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores
+#endif
+
+// LDS float atomic max through the order-preserving integer trick (deterministic).
+__device__ __forceinline__ void lds_max_float(float* addr, float v) {
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+__host__ __device__ inline size_t rows_lds_floats(int S) {
+  // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | XS[6][64] | ZM[64] | head (+pad)
+  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 6 * ROWS_SAMPLES + ROWS_SAMPLES + 4;
+}
+
+__global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kernel(
+    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
+    const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
+    float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part_du,
+    float* __restrict__ part_rhs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
+  const int S = P.S;
+  const int lane = threadIdx.x & (RATO_WAVE - 1), wave = threadIdx.x / RATO_WAVE;
+  // Before step t of the rollout, PP[t] / AZ[t] hold that step's noise (xi_x, xi_y) / xi_z; the
+  // axis wave that consumes a component overwrites it with its own output (same lane, so program
+  // order is enough).  No __restrict__ on these pointers for that reason.
+  float2_t* A2 = reinterpret_cast<float2_t*>(lds_raw);              // [S][64] (a22x, a22y)
+  float2_t* PP = A2 + (size_t)S * ROWS_SAMPLES;                     // [S][64] p_{t+1} (x, y)
+  float* AZ = reinterpret_cast<float*>(PP + (size_t)S * ROWS_SAMPLES);  // [S][64] a22z
+  float2_t* US = reinterpret_cast<float2_t*>(AZ + (size_t)S * ROWS_SAMPLES);  // [S] (ux, uy)
+  float* UZ = reinterpret_cast<float*>(US + S);                     // [S]
+  float* XS = UZ + S;                                               // [6][64] x_S
+  float* ZM = XS + 6 * ROWS_SAMPLES;                                // [64] running max of g
+  int* head = reinterpret_cast<int*>(ZM + ROWS_SAMPLES);
+
+  const size_t m_raw = (size_t)blockIdx.x * ROWS_SAMPLES + lane;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;  // clamp loads; stores are predicated
+  const float inv_m = 1.0f / mass[m];
+  const float a21 = -P.kp * P.dt * inv_m;
+  const float dtm = P.dt * inv_m;
+  // every wave needs its samples' obstacle matrices (row tasks rebuild g and w = -(Q+Q^T) d)
+  float q00[NOBS], qs[NOBS], q11[NOBS];
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    q00[j] = Qsym[(size_t)(j * 3 + 0) * ld + m];
+    qs[j] = Qsym[(size_t)(j * 3 + 1) * ld + m];
+    q11[j] = Qsym[(size_t)(j * 3 + 2) * ld + m];
+  }
+
+  // ---- phase 0: stage dW[t][a][64 samples], the controls and the queue state
+  {
+    float* PPf = reinterpret_cast<float*>(PP);
+    const int nrows = 3 * S;
+    constexpr int MAXR = 8;  // rows per wave per batch (loads in flight)
+    for (int r0 = wave; r0 < nrows; r0 += ROWS_NW * MAXR) {
+      float tmp[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + i * ROWS_NW;
+        tmp[i] = (r < nrows) ? dW[(size_t)r * ld + m] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + i * ROWS_NW;
+        if (r < nrows) {
+          const int t = r / 3, a = r - 3 * t;
+          if (a < 2) PPf[(t * ROWS_SAMPLES + lane) * 2 + a] = tmp[i];
+          else AZ[t * ROWS_SAMPLES + lane] = tmp[i];
+        }
+      }
+    }
+    for (int i = threadIdx.x; i < S; i += ROWS_NW * RATO_WAVE) {
+      float2_t u2;
+      u2.x = us[i * 3 + 0];
+      u2.y = us[i * 3 + 1];
+      US[i] = u2;
+      UZ[i] = us[i * 3 + 2];
+    }
+    if (threadIdx.x < ROWS_SAMPLES) ZM[threadIdx.x] = -INFINITY;
+    if (threadIdx.x == 0) *head = 0;
+  }
+  __syncthreads();
+
+  // ---- phase 1: waves 0..2 roll out one axis each (pass-1 coefficients into LDS)
+  if (wave < 3 && RATO_DIAG != 2) {
+    const int a = wave;
+    const float cn = sqrtf(P.dt) * P.beta * inv_m;  // sqrt(dt) * (beta/m): drone_risk.py:136,151
+    float p = P.x_init[a], v = P.x_init[3 + a];
+    float* PPf = reinterpret_cast<float*>(PP);
+    for (int t = 0; t < S; ++t) {
+      const int slot = t * ROWS_SAMPLES + lane;
+      const float xi = (a < 2) ? PPf[slot * 2 + a] : AZ[slot];
+      const float u = (a == 0) ? US[t].x : ((a == 1) ? US[t].y : UZ[t]);
+      const float a22 = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v)) * inv_m;
+      const float acc = (u - (P.kp * p + P.kd * v)) * inv_m - P.drag * fabsf(v) * v * inv_m;
+      const float pn = p + P.dt * v;
+      const float vn = v + P.dt * acc + cn * xi;
+      p = pn;
+      v = vn;
+      if (a < 2) {
+        reinterpret_cast<float*>(A2)[slot * 2 + a] = a22;
+        PPf[slot * 2 + a] = p;
+      } else {
+        AZ[slot] = a22;
+      }
+    }
+    XS[a * ROWS_SAMPLES + lane] = p;
+    XS[(3 + a) * ROWS_SAMPLES + lane] = v;
+  }
+  __syncthreads();
+
+  // ---- phase 2: tasks from the LDS queue.  task 0 = final-state Jacobian; task i>0 = row t = S - i.
+  constexpr int RT = ROWS_SAMPLES;  // tile width: each row sweep below is one contiguous descending stream
+  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * NOBS * RT;
+  float* __restrict__ Gt = G + (size_t)blockIdx.x * tile_floats + lane;
+  // One LDS fetch-add per task, issued by lane 0 and broadcast (written without `continue`:
+  // hipcc 7.2 mis-structured the earlier for(;;)/continue form into a loop that re-ran task 0).
+  auto next_task = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(head, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  int task = (RATO_DIAG == 1) ? S + 1 : next_task();
+  while (task <= S) {
+    if (task == 0) {
+      // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s: rows (P, V) of the 3 axes, summed over the block's
+      // samples; the same sweep accumulates (d x_S / d u) . u for the rhs  (drone_risk.py:271)
+      float mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        mP0[a] = 1.0f; mP1[a] = 0.0f; mV0[a] = 0.0f; mV1[a] = 1.0f;
+        dP[a] = dV[a] = 0.0f;
+      }
+      for (int s = S - 1; s >= 0; --s) {
+        const float2_t u2 = US[s];
+        const float uu[3] = {u2.x, u2.y, UZ[s]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float eP = mP1[a] * dtm, eV = mV1[a] * dtm;
+          dP[a] += eP * uu[a];
+          dV[a] += eV * uu[a];
+          const float sp = rato::wave_sum(valid ? eP : 0.0f);
+          const float sv = rato::wave_sum(valid ? eV : 0.0f);
+          if (lane == 0) {
+            part_du[((size_t)blockIdx.x * S + s) * 6 + a] = sp;
+            part_du[((size_t)blockIdx.x * S + s) * 6 + 3 + a] = sv;
+          }
+        }
+        if (s > 0) {  // mu_s = mu_{s+1} A_s
+          const float2_t aa = A2[s * ROWS_SAMPLES + lane];
+          const float az = AZ[s * ROWS_SAMPLES + lane];
+          const float a22[3] = {aa.x, aa.y, az};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float nP0 = mP0[a] + mP1[a] * a21, nP1 = mP0[a] * P.dt + mP1[a] * a22[a];
+            const float nV0 = mV0[a] + mV1[a] * a21, nV1 = mV0[a] * P.dt + mV1[a] * a22[a];
+            mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float xp = XS[a * ROWS_SAMPLES + lane], xv = XS[(3 + a) * ROWS_SAMPLES + lane];
+        const float rp = rato::wave_sum(valid ? (-(xp - P.x_final[a]) + dP[a]) : 0.0f);
+        const float rv = rato::wave_sum(valid ? (-(xv - P.x_final[3 + a]) + dV[a]) : 0.0f);
+        if (lane == 0) {
+          part_rhs[(size_t)blockIdx.x * 6 + a] = rp;
+          part_rhs[(size_t)blockIdx.x * 6 + 3 + a] = rv;
+        }
+      }
+    } else {
+      const int t = S - task;  // S-1 ... 0 (longest rows first)
+      const float2_t pp = PP[t * ROWS_SAMPLES + lane];
+      float gj[NOBS], wx[NOBS], wy[NOBS];  // g, and -(Q+Q^T) d pre-multiplied by dt/m
+      float gmax = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
+        gj[j] = 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
+        wx[j] = -(2.0f * q00[j] * dx + qs[j] * dy) * dtm;
+        wy[j] = -(qs[j] * dx + 2.0f * q11[j] * dy) * dtm;
+        gmax = fmaxf(gmax, gj[j]);
+      }
+      lds_max_float(&ZM[lane], gmax);
+      float m0x = 1.0f, m0y = 1.0f, m1x = 0.0f, m1y = 0.0f;  // mu_{t+1} = e_0^T (x and y axes)
+      float accx = 0.0f, accy = 0.0f;                        // sum_s mu_{s+1}[1] u_s  per axis
+      float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * NOBS * RT);
+      for (int k = t; k >= 1; --k) {
+        const float2_t aa = A2[k * ROWS_SAMPLES + lane];
+        const float2_t u2 = US[k - 1];
+        const float n0x = m0x + m1x * a21, n0y = m0y + m1y * a21;
+        const float n1x = m0x * P.dt + m1x * aa.x, n1y = m0y * P.dt + m1y * aa.y;
+        m0x = n0x; m0y = n0y; m1x = n1x; m1y = n1y;
+        accx += m1x * u2.x;
+        accy += m1y * u2.y;
+        if (valid && (RATO_DIAG != 3 || m1x == 123.456f)) {
+          float* __restrict__ o = Grow + (k - 1) * (2 * NOBS * RT);  // column s = k-1
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) {
+            o[j * RT] = wx[j] * m1x;
+            o[(NOBS + j) * RT] = wy[j] * m1y;
+          }
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j)  // g_up = -g + (grad g) . u   (drone_risk.py:278)
+          g_up[((size_t)j * S + t) * ld + m] = -gj[j] + wx[j] * accx + wy[j] * accy;
+      }
+    }
+    task = next_task();
+  }
+  if (Z) {
+    __syncthreads();
+    if (wave == 0 && valid) Z[m] = ZM[lane] - P.tol;
+  }
+}
+
 bool params_ok(const rato_drone_params* p) {
-  return p && p->M > 0 && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
+  return p && p->M > 0 && p->ld >= p->M && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
 }
 
 }  // namespace
@@ -301,47 +676,84 @@ extern "C" int rato_drone_obstacle_constraints(const rato_drone_params* p, const
   return RATO_OK;
 }
 
-extern "C" int rato_drone_linearize_nblocks(int32_t M) { return M > 0 ? rato::nblocks_for(M) : RATO_EINVAL; }
-
 namespace {
-template <int CPT>
+template <int CPT, int SPL>
 int launch_linearize(const rato_drone_params* p, const float* us, const float* dW, const float* mass,
                      const float* Qsym, float* G, float* g_up, float* Z, float* part_du, float* part_rhs,
                      hipStream_t stream) {
   const int ngroups = (p->S + CPT - 1) / CPT;
-  dim3 grid(rato::nblocks_for(p->M), ngroups), block(RATO_BLOCK);
-  hipLaunchKernelGGL(drone_linearize_kernel<CPT>, grid, block, 0, stream, *p, us, dW, mass, Qsym, G, g_up, Z,
+  dim3 grid((p->M + RATO_BLOCK * SPL - 1) / (RATO_BLOCK * SPL), ngroups), block(RATO_BLOCK);
+  hipLaunchKernelGGL((drone_linearize_kernel<CPT, SPL>), grid, block, 0, stream, *p, us, dW, mass, Qsym, G, g_up, Z,
                      part_du, part_rhs);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
+
+// Resolve cols_per_thread / samples_per_lane (0 = choose).  Tuned on MI355X
+// (profiles/): wide lanes once there are enough samples to fill the chip.
+size_t rows_lds_bytes(int S) { return rows_lds_floats(S) * sizeof(float); }
+constexpr size_t ROWS_LDS_MAX = 160 * 1024;
+
+bool plan(int32_t M, int32_t S, int32_t ld, int32_t* cpt, int32_t* spl) {
+  if (M <= 0 || S <= 0 || ld < M) return false;
+  if (*cpt == 0 && *spl == 0) {  // default: the row-parallel kernel whenever its LDS tables fit
+    if (S >= 2 && rows_lds_bytes(S) <= ROWS_LDS_MAX) *cpt = -1;
+  }
+  if (*cpt == -1) {
+    *spl = 1;
+    return S >= 2 && rows_lds_bytes(S) <= ROWS_LDS_MAX;
+  }
+  if (*spl == 0) *spl = (M >= 65536 && ld % 4 == 0) ? 4 : ((M >= 32768 && ld % 2 == 0) ? 2 : 1);
+  if (*cpt == 0) *cpt = (*spl == 4) ? 4 : ((*spl == 2) ? 8 : (M >= 65536 ? 8 : 4));
+  if (*spl != 1 && *spl != 2 && *spl != 4) return false;
+  if (ld % *spl != 0) return false;
+  const bool ok = (*spl == 1 && (*cpt == 4 || *cpt == 8 || *cpt == 16 || *cpt == 32)) ||
+                  (*spl == 2 && (*cpt == 4 || *cpt == 8)) || (*spl == 4 && (*cpt == 2 || *cpt == 4));
+  return ok;
+}
 }  // namespace
+
+extern "C" int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld, int32_t* cols_per_thread,
+                                         int32_t* samples_per_lane, int32_t* tile) {
+  if (!cols_per_thread || !samples_per_lane || !tile) return RATO_EINVAL;
+  if (!plan(M, S, ld, cols_per_thread, samples_per_lane)) return RATO_EINVAL;
+  *tile = (*cols_per_thread == -1) ? ROWS_SAMPLES : RATO_TILE;
+  if (*cols_per_thread == -1) return (M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
+  return (M + RATO_BLOCK * *samples_per_lane - 1) / (RATO_BLOCK * *samples_per_lane);
+}
 
 extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym, float* G, float* g_up, float* Z,
-                                    float* part_du, float* part_rhs, int32_t cols_per_thread, void* stream) {
+                                    float* part_du, float* part_rhs, int32_t cols_per_thread,
+                                    int32_t samples_per_lane, void* stream) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part_du || !part_rhs) return RATO_EINVAL;
-  int cpt = cols_per_thread;
-  if (cpt == 0) {
-    // largest column group that still yields >= 2 waves per SIMD (1024 SIMDs)
-    const long waves_per_group = (long)rato::nblocks_for(p->M) * (RATO_BLOCK / RATO_WAVE);
-    cpt = 4;
-    const int cands[3] = {32, 16, 8};
-    for (int i = 0; i < 3; ++i) {
-      const int ng = (p->S + cands[i] - 1) / cands[i];
-      if (waves_per_group * ng >= 2048) {
-        cpt = cands[i];
-        break;
-      }
-    }
-  }
+  int32_t cpt = cols_per_thread, spl = samples_per_lane;
+  if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
-  switch (cpt) {
-    case 4: return launch_linearize<4>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st);
-    case 8: return launch_linearize<8>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st);
-    case 16: return launch_linearize<16>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st);
-    case 32: return launch_linearize<32>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st);
-    default: return RATO_EINVAL;
+  if (cpt == -1) {
+    const size_t lds = rows_lds_bytes(p->S);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
+    }
+    dim3 grid((p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES), block(ROWS_NW * RATO_WAVE);
+    hipLaunchKernelGGL(drone_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, mass, Qsym, G, g_up, Z,
+                       part_du, part_rhs);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
   }
+#define RATO_CASE(C, L) \
+  if (cpt == C && spl == L) return launch_linearize<C, L>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st)
+  RATO_CASE(4, 1);
+  RATO_CASE(8, 1);
+  RATO_CASE(16, 1);
+  RATO_CASE(32, 1);
+  RATO_CASE(4, 2);
+  RATO_CASE(8, 2);
+  RATO_CASE(2, 4);
+  RATO_CASE(4, 4);
+#undef RATO_CASE
+  return RATO_EINVAL;
 }

@@ -5,7 +5,7 @@
 
 #include "rato_saa.h"
 
-#define RATO_BLOCK 256           // 4 waves per workgroup
+#define RATO_BLOCK 256           // 4 waves per workgroup (== RATO_TILE of rato_saa.h)
 #define RATO_WAVE 64
 
 // hipGetLastError() is sticky per host thread: clear anything left behind by an
@@ -17,6 +17,8 @@
     hipError_t e__ = hipGetLastError();                  \
     if (e__ != hipSuccess) return RATO_EHIP - (int)e__;  \
   } while (0)
+
+static_assert(RATO_BLOCK == RATO_TILE, "one workgroup writes one Jacobian tile");
 
 namespace rato {
 

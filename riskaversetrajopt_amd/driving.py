@@ -19,8 +19,7 @@ std_matrix_ped_initial_state = np.sqrt(P.variance_ped_initial_state)   # driving
 BETA = 3e-2                                                            # driving.py:94
 
 
-def num_pairs(S):
-    return S * (S - 1) // 2
+from .drone_risk import TILE, num_pairs, num_tiles, untile  # noqa: E402  (same packed layout)
 
 
 def sample_uncertain_parameters(M, method='saa', S=P.S, rng=None):
@@ -181,13 +180,13 @@ class Model:
 
     # ---- linearization (K4) ------------------------------------------------
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True):
-        """-> dict: G [n_pairs][2][M], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
+        """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
         M, S = ws.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}
-        G = o.get("G") if "G" in o else self._empty(max(num_pairs(S), 1), 2, M)
+        G = o.get("G") if "G" in o else self._empty(num_tiles(M), max(num_pairs(S), 1), 2, TILE)
         g_up = o.get("g_up") if "g_up" in o else self._empty(S, M)
         Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
         final_du = o.get("final_du") if "final_du" in o else self._empty(4, n_u * S)
@@ -199,10 +198,15 @@ class Model:
             _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
         return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M}
 
-    def expand_g_obs_du(self, G):
-        """packed G [n_pairs][2][M] (host ndarray) -> dense (M, S, n_u*S)."""
+    def expand_g_obs_du(self, G, M=None):
+        """packed G -> dense host (M, S, n_u*S); small M only.  G is either the tile-blocked
+        device tensor [n_tiles][n_pairs][2][TILE] or an untiled [n_pairs][2][M'] tensor/ndarray."""
         S = self.S
-        M = G.shape[-1]
+        if isinstance(G, torch.Tensor):
+            if G.dim() == 4:
+                G = untile(G, self.M if M is None else M)
+            G = G.double().cpu().numpy()
+        M = G.shape[-1]                                 # (n_pairs, 2, M)
         dense = np.zeros((M, S, n_u * S))
         for t in range(1, S):
             off = t * (t - 1) // 2
@@ -223,14 +227,14 @@ class Model:
                                np.asarray(dWs)[None], self.device)
         r = self.linearize_device(us_mat, inputs=inputs)
         rhs = r["final_rhs"].double().cpu().numpy()
-        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())[0]
+        g_obs_du = self.expand_g_obs_du(r["G"], 1)[0]
         return (r["final_du"].double().cpu().numpy(), rhs, rhs.copy(), g_obs_du,
                 r["g_up"][:, 0].double().cpu().numpy())
 
     def get_all_constraints_coeffs_batched(self, us_mat):
         """vmap over the model's samples (driving.py:305-307), dense; small M only."""
         r = self.linearize_device(us_mat)
-        return (self.expand_g_obs_du(r["G"].double().cpu().numpy()),
+        return (self.expand_g_obs_du(r["G"], r["M"]),
                 r["g_up"].t().double().cpu().numpy())
 
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------

@@ -20,21 +20,49 @@ n_x, n_u, n_obs = P.n_x, P.n_u, P.n_obs
 OSQP_TOL = P.OSQP_TOL
 
 
+TILE = 256      # RATO_TILE of include/rato_saa.h (the row-parallel drone kernel uses 64-wide tiles)
+
+
 def num_pairs(S):
     return S * (S - 1) // 2
 
 
+def num_tiles(M, tile=TILE):
+    return (M + tile - 1) // tile
+
+
+def untile(G, M):
+    """tile-blocked [n_tiles][rows...][TILE] -> [rows...][M] (a view-free copy; small M / tests)."""
+    nd = G.dim()
+    perm = list(range(1, nd - 1)) + [0, nd - 1]
+    rows = G.shape[1:-1]
+    return G.permute(*perm).reshape(*rows, G.shape[0] * G.shape[-1])[..., :M]
+
+
+def pad4(M):
+    """Row stride of the SoA arrays: samples padded to a multiple of 4 so that a lane
+    can move 4 consecutive samples with one 16-byte access."""
+    return (M + 3) // 4 * 4
+
+
 def to_soa_inputs(DWs, masses, obs_Qs, device):
-    """Reference layouts -> kernel layouts (fp32, sample index fastest).
-    DWs (M,S,6) -> dW [S][3][M] (only rows 3..5 are used by sigma, drone_risk.py:136);
-    obs_Qs (M,n_obs,3,3) -> Qsym [n_obs][3][M] = (Q00, Q01+Q10, Q11) of [:2,:2] (:174)."""
+    """Reference layouts -> kernel layouts (fp32, sample index fastest, row stride
+    ld = pad4(M); padding samples are inert: zero noise, unit mass, zero Q).
+    DWs (M,S,6) -> dW [S][3][ld] (only rows 3..5 are used by sigma, drone_risk.py:136);
+    obs_Qs (M,n_obs,3,3) -> Qsym [n_obs][3][ld] = (Q00, Q01+Q10, Q11) of [:2,:2] (:174).
+    Returns (dW, mass, Qsym, M)."""
     DWs = torch.as_tensor(np.asarray(DWs), device=device)
-    dW = DWs[:, :, 3:6].permute(1, 2, 0).contiguous().float()
-    mass = torch.as_tensor(np.asarray(masses), device=device).contiguous().float()
+    M, S = DWs.shape[0], DWs.shape[1]
+    ld = pad4(M)
+    dW = torch.zeros((S, 3, ld), dtype=torch.float32, device=device)
+    dW[:, :, :M] = DWs[:, :, 3:6].permute(1, 2, 0).float()
+    mass = torch.ones(ld, dtype=torch.float32, device=device)
+    mass[:M] = torch.as_tensor(np.asarray(masses), device=device).float()
     Q = torch.as_tensor(np.asarray(obs_Qs), device=device)
-    Qsym = torch.stack([Q[:, :, 0, 0], Q[:, :, 0, 1] + Q[:, :, 1, 0], Q[:, :, 1, 1]], dim=1)  # (M,3,n_obs)
-    Qsym = Qsym.permute(2, 1, 0).contiguous().float()
-    return dW, mass, Qsym
+    Qs = torch.stack([Q[:, :, 0, 0], Q[:, :, 0, 1] + Q[:, :, 1, 0], Q[:, :, 1, 1]], dim=1)  # (M,3,n_obs)
+    Qsym = torch.zeros((n_obs, 3, ld), dtype=torch.float32, device=device)
+    Qsym[:, :, :M] = Qs.permute(2, 1, 0).float()
+    return dW, mass, Qsym, M
 
 
 class Model:
@@ -58,19 +86,19 @@ class Model:
         self._lib = _lib.load()
         if DWs is not None:
             self.DWs, self.masses, self.obs_Qs = DWs, masses, obs_Qs
-            self._dW, self._mass, self._Qsym = to_soa_inputs(DWs, masses, obs_Qs, self.device)
-            self.M = self._mass.numel()
+            self._dW, self._mass, self._Qsym, self.M = to_soa_inputs(DWs, masses, obs_Qs, self.device)
             if self._dW.shape[0] != S:
                 raise ValueError(f"DWs has {self._dW.shape[0]} steps, Model has S={S}")
 
     @classmethod
-    def from_device(cls, S, dW, mass, Qsym, method='saa', alpha=0.1):
-        """Batch already resident in HBM in kernel layout (throughput runs)."""
+    def from_device(cls, S, dW, mass, Qsym, method='saa', alpha=0.1, M=None):
+        """Batch already resident in HBM in kernel layout (throughput runs):
+        dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld]; M <= ld samples are used."""
         self = cls(S, None, None, None, method, alpha, device=dW.device)
         self.DWs = self.masses = self.obs_Qs = None
         self._dW, self._mass, self._Qsym = (_lib.require_f32_device(t, n) for t, n in
                                             ((dW, "dW"), (mass, "mass"), (Qsym, "Qsym")))
-        self.M = mass.numel()
+        self.M = mass.numel() if M is None else M
         return self
 
     # ---- layout helpers (drone_risk.py:95-120) -----------------------------
@@ -86,9 +114,12 @@ class Model:
         return us
 
     # ---- plumbing ----------------------------------------------------------
-    def _params(self, M=None):
+    def _inputs(self, inputs):
+        return inputs if inputs is not None else (self._dW, self._mass, self._Qsym, self.M)
+
+    def _params(self, M, ld):
         p = _lib.DroneParams()
-        p.M, p.S = (self.M if M is None else M), self.S
+        p.M, p.ld, p.S = M, ld, self.S
         p.dt, p.beta, p.drag = self.dt, self.beta, self.drag_coefficient
         p.kp, p.kd = -float(P.feedback_gain[0, 0]), -float(P.feedback_gain[0, 3])
         p.tol = OSQP_TOL
@@ -114,18 +145,19 @@ class Model:
 
     # ---- rollout + constraint values (K1) ----------------------------------
     def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
-        """-> (Z [M], xs [S+1][6][M] or None, g [n_obs][S][M] or None), device tensors."""
-        dW, mass, Qsym = inputs if inputs is not None else (self._dW, self._mass, self._Qsym)
-        M = mass.numel()
+        """-> (Z [M], xs [S+1][6][M] or None, g [n_obs][S][M] or None): device tensors
+        (views of row-stride-ld buffers)."""
+        dW, mass, Qsym, M = self._inputs(inputs)
+        ld = mass.numel()
         us = self._us_device(us_mat)
-        Z = self._empty(M)
-        xs = self._empty(self.S + 1, n_x, M) if want_xs else None
-        g = self._empty(n_obs, self.S, M) if want_g else None
-        p = self._params(M)
+        Z = self._empty(ld)
+        xs = self._empty(self.S + 1, n_x, ld) if want_xs else None
+        g = self._empty(n_obs, self.S, ld) if want_g else None
+        p = self._params(M, ld)
         _lib.check(self._lib.rato_drone_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass),
                                              _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
                                              _lib.current_stream()), "rato_drone_eval")
-        return Z, xs, g
+        return Z[:M], (xs[..., :M] if want_xs else None), (g[..., :M] if want_g else None)
 
     def us_to_state_trajectories(self, us_mat):
         """drone_risk.py:157-162 -> (M, S+1, n_x)."""
@@ -150,45 +182,62 @@ class Model:
         if single:
             xs, obs_Q = xs[None], obs_Q[None]
         M = xs.shape[0]
-        xs_d = torch.as_tensor(xs, device=self.device).permute(1, 2, 0).contiguous().float()
-        _, _, Qsym = to_soa_inputs(np.zeros((M, 1, 6)), np.ones(M), obs_Q, self.device)
-        g = self._empty(n_obs, self.S, M)
-        p = self._params(M)
+        _, _, Qsym, _ = to_soa_inputs(np.zeros((M, 1, 6)), np.ones(M), obs_Q, self.device)
+        ld = Qsym.shape[-1]
+        xs_d = torch.zeros((self.S + 1, n_x, ld), dtype=torch.float32, device=self.device)
+        xs_d[..., :M] = torch.as_tensor(xs, device=self.device).permute(1, 2, 0).float()
+        g = self._empty(n_obs, self.S, ld)
+        p = self._params(M, ld)
         _lib.check(self._lib.rato_drone_obstacle_constraints(C.byref(p), _lib.ptr(xs_d), _lib.ptr(Qsym),
                                                              _lib.ptr(g), _lib.current_stream()),
                    "rato_drone_obstacle_constraints")
-        out = g.permute(2, 0, 1).double().cpu().numpy()
+        out = g[..., :M].permute(2, 0, 1).double().cpu().numpy()
         return out[0] if single else out
 
     # ---- linearization (K2 + K6) -------------------------------------------
-    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True):
+    def linearize_plan(self, M, ld, cols_per_thread=0, samples_per_lane=0):
+        """-> (nblocks, cols_per_thread, samples_per_lane, tile) as the library resolves them."""
+        cpt, spl, tile = C.c_int32(cols_per_thread), C.c_int32(samples_per_lane), C.c_int32(0)
+        nblk = self._lib.rato_drone_linearize_plan(M, self.S, ld, C.byref(cpt), C.byref(spl), C.byref(tile))
+        if nblk < 0:
+            raise _lib.RatoError(f"no linearize variant for cols_per_thread={cols_per_thread}, "
+                                 f"samples_per_lane={samples_per_lane}, ld={ld}")
+        return nblk, cpt.value, spl.value, tile.value
+
+    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
+                         want_Z=True):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
-           G  [n_pairs][2][n_obs][M]  packed causal Jacobian (see rato_saa.h)
-           g_up [n_obs][S][M], Z [M],
+           G  [n_tiles][n_pairs][2][n_obs][TILE]  packed causal Jacobian, tile-blocked (rato_saa.h)
+           g_up [n_obs][S][M], Z [M]  (views of row-stride-ld buffers),
            du_sum [S][6] (float64: sums over samples of dx_S/du_{s,axis}),
            rhs_sum [6]   (float64: sums of -v_final + v_final_du.u)
+        ``out``: a dict returned by an earlier call (same shapes) whose buffers are reused.
         """
-        dW, mass, Qsym = inputs if inputs is not None else (self._dW, self._mass, self._Qsym)
-        M, S = mass.numel(), self.S
+        dW, mass, Qsym, M = self._inputs(inputs)
+        ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
-        nblk = self._lib.rato_drone_linearize_nblocks(M)
+        nblk, cpt, spl, tile = self.linearize_plan(M, ld, cols_per_thread, samples_per_lane)
         o = out if out is not None else {}
-        G = o.get("G") if "G" in o else self._empty(max(num_pairs(S), 1), 2, n_obs, M)
-        g_up = o.get("g_up") if "g_up" in o else self._empty(n_obs, S, M)
-        Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
-        part_du = o.get("part_du") if "part_du" in o else self._empty(nblk, S, 6)
-        part_rhs = o.get("part_rhs") if "part_rhs" in o else self._empty(nblk, 6)
-        p = self._params(M)
+        G = o["G"] if ("G" in o and o["G"].shape[-1] == tile) else \
+            self._empty(num_tiles(M, tile), max(num_pairs(S), 1), 2, n_obs, tile)
+        g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
+        Z = (o["_Z"] if "_Z" in o else self._empty(ld)) if want_Z else None
+        part_du = o["part_du"] if o.get("part_du") is not None and o["part_du"].shape[0] == nblk \
+            else self._empty(nblk, S, 6)
+        part_rhs = o["part_rhs"] if o.get("part_rhs") is not None and o["part_rhs"].shape[0] == nblk \
+            else self._empty(nblk, 6)
+        p = self._params(M, ld)
         _lib.check(self._lib.rato_drone_linearize(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
-            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part_du), _lib.ptr(part_rhs), int(cols_per_thread),
+            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part_du), _lib.ptr(part_rhs), cpt, spl,
             _lib.current_stream()), "rato_drone_linearize")
         du_sum = stats.sum_partials(part_du, out=o.get("du_sum"))
         rhs_sum = stats.sum_partials(part_rhs, out=o.get("rhs_sum"))
-        return {"G": G, "g_up": g_up, "Z": Z, "du_sum": du_sum, "rhs_sum": rhs_sum,
-                "part_du": part_du, "part_rhs": part_rhs, "M": M}
+        return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None), "du_sum": du_sum,
+                "rhs_sum": rhs_sum, "part_du": part_du, "part_rhs": part_rhs, "M": M,
+                "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt, "samples_per_lane": spl}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
@@ -200,10 +249,16 @@ class Model:
             out[3 + a, a::n_u] = d[:, 3 + a]
         return out
 
-    def expand_g_obs_du(self, G):
-        """packed G [n_pairs][2][n_obs][M] (host ndarray) -> dense (M,n_obs,S,n_u*S)."""
+    def expand_g_obs_du(self, G, M=None):
+        """packed G -> dense host (M,n_obs,S,n_u*S); small M only.  G is either the
+        tile-blocked device tensor [n_tiles][n_pairs][2][n_obs][TILE] or an already
+        untiled [n_pairs][2][n_obs][M'] tensor/ndarray."""
         S = self.S
-        M = G.shape[-1]
+        if isinstance(G, torch.Tensor):
+            if G.dim() == 5:
+                G = untile(G, self.M if M is None else M)
+            G = G.double().cpu().numpy()
+        M = G.shape[-1]                                # (n_pairs, 2, n_obs, M)
         dense = np.zeros((M, n_obs, S, n_u * S))
         for t in range(1, S):
             off = t * (t - 1) // 2
@@ -226,7 +281,7 @@ class Model:
         r = self.linearize_device(us_mat, inputs=inputs)
         v_final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0)
         rhs = r["rhs_sum"].cpu().numpy()
-        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())[0]
+        g_obs_du = self.expand_g_obs_du(r["G"], 1)[0]
         g_up = r["g_up"][:, :, 0].double().cpu().numpy()
         return v_final_du, rhs, rhs.copy(), g_obs_du, g_up
 
@@ -234,7 +289,7 @@ class Model:
         """vmap of the above over the model's samples (drone_risk.py:288-290), dense;
         small M only.  -> (g_obs_du (M,n_obs,S,3S), g_up (M,n_obs,S))."""
         r = self.linearize_device(us_mat)
-        g_obs_du = self.expand_g_obs_du(r["G"].double().cpu().numpy())
+        g_obs_du = self.expand_g_obs_du(r["G"], r["M"])
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 

@@ -35,14 +35,17 @@ def sample_uncertain_parameters(method='saa', M=100, S=P.S, dt=P.dt, rng=None):
 
 def sample_uncertain_parameters_device(M, S, dt=P.dt, seed=0, device='cuda:0'):
     """Synthetic batch with the reference's distributions drawn on the device,
-    already in kernel layout: dW [S][3][M], mass [M], Qsym [n_obs][3][M] (fp32)."""
+    already in kernel layout with row stride ld = M rounded up to a multiple of 4:
+    dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld] (fp32; the ld-M padding samples are
+    ordinary draws that the kernels ignore)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    dW = torch.randn((S, 3, M), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(dt))
-    mass = P.mass_nom + P.mass_delta * (2 * torch.rand(M, generator=g, device=device, dtype=torch.float32) - 1)
+    ld = (M + 3) // 4 * 4
+    dW = torch.randn((S, 3, ld), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(dt))
+    mass = P.mass_nom + P.mass_delta * (2 * torch.rand(ld, generator=g, device=device, dtype=torch.float32) - 1)
     r = torch.as_tensor(P.obs_radii, dtype=torch.float32, device=device)[:, None, None] + \
-        P.obs_radii_deltas * (2 * torch.rand((P.n_obs, 3, M), generator=g, device=device, dtype=torch.float32) - 1)
+        P.obs_radii_deltas * (2 * torch.rand((P.n_obs, 3, ld), generator=g, device=device, dtype=torch.float32) - 1)
     q = 1.0 / (r * r)                      # diag entries (x, y, z) per obstacle
     Qsym = torch.stack([q[:, 0], torch.zeros_like(q[:, 0]), q[:, 1]], dim=1).contiguous()
     return dW, mass, Qsym

@@ -39,8 +39,19 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_size_queries(lib):
     assert lib.rato_abi_version() == 1
-    assert lib.rato_drone_linearize_nblocks(1000) == 4
-    assert lib.rato_drone_linearize_nblocks(0) < 0
+    import ctypes as C
+    cpt, spl, tile = C.c_int32(8), C.c_int32(1), C.c_int32(0)
+    assert lib.rato_drone_linearize_plan(1000, 50, 1000, C.byref(cpt), C.byref(spl), C.byref(tile)) == 4
+    assert tile.value == 256
+    cpt, spl = C.c_int32(0), C.c_int32(0)
+    nblk = lib.rato_drone_linearize_plan(100000, 50, 100000, C.byref(cpt), C.byref(spl), C.byref(tile))
+    assert cpt.value == -1 and tile.value == 64 and nblk == (100000 + 63) // 64       # row-parallel default
+    cpt, spl = C.c_int32(0), C.c_int32(0)
+    assert lib.rato_drone_linearize_plan(1000, 500, 1000, C.byref(cpt), C.byref(spl), C.byref(tile)) > 0
+    assert cpt.value > 0 and tile.value == 256                                          # LDS tables too big
+    cpt, spl = C.c_int32(4), C.c_int32(4)
+    assert lib.rato_drone_linearize_plan(1001, 50, 1001, C.byref(cpt), C.byref(spl), C.byref(tile)) < 0   # ld % 4
+    assert lib.rato_drone_linearize_plan(0, 50, 0, C.byref(cpt), C.byref(spl), C.byref(tile)) < 0
     S = 40
     assert lib.rato_car_ego_scratch_floats(S) == (S + 1) * 4 + (S + 1) * 2 + (S + 1) * 2 * 2 * S
     assert lib.rato_risk_stats_workspace_bytes(10000) > 5120 * 4
@@ -49,7 +60,7 @@ def test_abi_version_and_size_queries(lib):
 def test_params_struct_layout_matches_header():
     from riskaversetrajopt_amd import _lib
     # 2 int32 + 6 float + 6 + 6 + 6 floats
-    assert ctypes.sizeof(_lib.DroneParams) == 4 * (2 + 6 + 18)
+    assert ctypes.sizeof(_lib.DroneParams) == 4 * (3 + 6 + 18)
     assert ctypes.sizeof(_lib.CarParams) == 4 * (2 + 5 + 8)
 
 
