@@ -81,19 +81,23 @@ class DroneWork:
         else:
             self.kernel = "drone_eval_kernel"
 
-    def hot_kernel(self):
-        """Launch only the dominant kernel (between the timing events)."""
+    def hot_kernel(self, events=None):
+        """One pass; ``events`` bracket ONLY the dominant kernel's launch."""
         if self.mode == "linearize":
             return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
-                                               out=self.out)
+                                               out=self.out, events=events)
+        if events is not None:
+            events[0].record()
         Z, _, _ = self.model.eval_device(self.us)
+        if events is not None:
+            events[1].record()
         return {"Z": Z, "du_sum": None}
 
     def sums(self, r):
         import torch
         if r["du_sum"] is None:
             return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
-        return torch.cat([r["du_sum"].reshape(-1), r["rhs_sum"].reshape(-1)])
+        return r["sums"]
 
     def algorithmic_bytes(self):
         M, S = self.M, self.S
@@ -139,11 +143,16 @@ class DrivingWork:
         else:
             self.kernel = "car_eval_kernel"
 
-    def hot_kernel(self):
+    def hot_kernel(self, events=None):
+        if events is not None:
+            events[0].record()
         if self.mode == "linearize":
-            return self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
-        Z, _, _ = self.model.eval_device(self.us)
-        return {"Z": Z}
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
+        else:
+            r = {"Z": self.model.eval_device(self.us)[0]}
+        if events is not None:
+            events[1].record()
+        return r
 
     def sums(self, r):
         import torch
@@ -189,10 +198,16 @@ class HopperWork:
         import torch
         self.lam = torch.rand((self.C, self.M), device=device)
 
-    def hot_kernel(self):
+    def hot_kernel(self, events=None):
+        if events is not None:
+            events[0].record()
         if self.mode == "linearize":
-            return self.model.slip_device(self.px, self.forces, lam=self.lam, want_deriv=True)
-        return self.model.slip_device(self.px, self.forces, want_h=False)
+            r = self.model.slip_device(self.px, self.forces, lam=self.lam, want_deriv=True)
+        else:
+            r = self.model.slip_device(self.px, self.forces, want_h=False)
+        if events is not None:
+            events[1].record()
+        return r
 
     def sums(self, r):
         import torch
@@ -261,11 +276,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        r = work.hot_kernel()
-        if i is not None:
-            ev[i][1].record()
+        r = work.hot_kernel(events=ev[i] if i is not None else None)
         sums, Z_all = rdist.exchange(work.sums(r), r["Z"])        # the one collective (no-op at N=1)
         stats.risk_stats_device(Z_all, args.alpha, workspace=ws_bytes, out=stats_out)
         return sums

@@ -97,7 +97,7 @@ int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW
  *   samples_per_lane 2 x cpt {4,8}, samples_per_lane 4 x cpt {2,4}
  * This call resolves 0 / 0 ("let the library choose") to a concrete pair and
  * returns the number of sample blocks the launch will use = rows of
- * part_du / part_rhs.  Returns <0 on bad arguments. */
+ * part.  Returns <0 on bad arguments. */
 int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
                               int32_t* cols_per_thread, int32_t* samples_per_lane,
                               int32_t* tile /* out: TILE of the G layout */);
@@ -111,16 +111,15 @@ int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
  *                                         (the z-control column is identically 0)
  *   g_up     [3 obs][S][M]                -g + grad g . u   (:278)
  *   Z        [M] or NULL                  max_{j,t} g - tol at this iterate
- *   part_du  [nblocks][S][6]              per-block sums of d x_S / d u_{s,axis}:
- *                                         entries (P_x,P_y,P_z,V_x,V_y,V_z)
- *   part_rhs [nblocks][6]                 per-block sums of -v_final + v_final_du.u (:271)
+ *   part     [nblocks][6*S + 6]           per-block sums (nblocks from rato_drone_linearize_plan):
+ *                                         [s*6 + e], e = (P_x,P_y,P_z,V_x,V_y,V_z): d x_S / d u_{s,axis};
+ *                                         [6*S + r]: -v_final + v_final_du.u (:271), r = row of x
  * cols_per_thread / samples_per_lane: see rato_drone_linearize_plan (0 = choose).
  * All [..][M] arrays (dW, mass, Qsym, g_up, Z) use the row stride p->ld.
  */
 int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                          const float* mass, const float* Qsym,
-                         float* G, float* g_up, float* Z,
-                         float* part_du, float* part_rhs,
+                         float* G, float* g_up, float* Z, float* part,
                          int32_t cols_per_thread, int32_t samples_per_lane, void* stream);
 
 /* Model.obstacle_avoidance_constraints on given trajectories (drone_risk.py:198-213).

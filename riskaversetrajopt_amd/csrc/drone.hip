@@ -169,8 +169,7 @@ template <int CPT, int SPL>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
-    float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part_du,
-    float* __restrict__ part_rhs) {
+    float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
   const size_t m_raw = ((size_t)blockIdx.x * RATO_BLOCK + threadIdx.x) * SPL;  // first sample of this lane
@@ -392,13 +391,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
       float acc = 0.0f;
 #pragma unroll
       for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += red[w][tid];
-      part_du[((size_t)blockIdx.x * S + s) * 6 + e] = acc;
+      part[(size_t)blockIdx.x * (6 * S + 6) + s * 6 + e] = acc;
     }
   } else if (lead && tid < CPT * 6 + 6) {
     float acc = 0.0f;
 #pragma unroll
     for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += red[w][tid];
-    part_rhs[(size_t)blockIdx.x * 6 + (tid - CPT * 6)] = acc;
+    part[(size_t)blockIdx.x * (6 * S + 6) + 6 * S + (tid - CPT * 6)] = acc;
   }
 }
 
@@ -448,8 +447,7 @@ __host__ __device__ inline size_t rows_lds_floats(int S) {
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
-    float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part_du,
-    float* __restrict__ part_rhs) {
+    float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
@@ -576,8 +574,8 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
           const float sp = rato::wave_sum(valid ? eP : 0.0f);
           const float sv = rato::wave_sum(valid ? eV : 0.0f);
           if (lane == 0) {
-            part_du[((size_t)blockIdx.x * S + s) * 6 + a] = sp;
-            part_du[((size_t)blockIdx.x * S + s) * 6 + 3 + a] = sv;
+            part[(size_t)blockIdx.x * (6 * S + 6) + s * 6 + a] = sp;
+            part[(size_t)blockIdx.x * (6 * S + 6) + s * 6 + 3 + a] = sv;
           }
         }
         if (s > 0) {  // mu_s = mu_{s+1} A_s
@@ -598,8 +596,8 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
         const float rp = rato::wave_sum(valid ? (-(xp - P.x_final[a]) + dP[a]) : 0.0f);
         const float rv = rato::wave_sum(valid ? (-(xv - P.x_final[3 + a]) + dV[a]) : 0.0f);
         if (lane == 0) {
-          part_rhs[(size_t)blockIdx.x * 6 + a] = rp;
-          part_rhs[(size_t)blockIdx.x * 6 + 3 + a] = rv;
+          part[(size_t)blockIdx.x * (6 * S + 6) + 6 * S + a] = rp;
+          part[(size_t)blockIdx.x * (6 * S + 6) + 6 * S + 3 + a] = rv;
         }
       }
     } else {
@@ -679,12 +677,11 @@ extern "C" int rato_drone_obstacle_constraints(const rato_drone_params* p, const
 namespace {
 template <int CPT, int SPL>
 int launch_linearize(const rato_drone_params* p, const float* us, const float* dW, const float* mass,
-                     const float* Qsym, float* G, float* g_up, float* Z, float* part_du, float* part_rhs,
-                     hipStream_t stream) {
+                     const float* Qsym, float* G, float* g_up, float* Z, float* part, hipStream_t stream) {
   const int ngroups = (p->S + CPT - 1) / CPT;
   dim3 grid((p->M + RATO_BLOCK * SPL - 1) / (RATO_BLOCK * SPL), ngroups), block(RATO_BLOCK);
   hipLaunchKernelGGL((drone_linearize_kernel<CPT, SPL>), grid, block, 0, stream, *p, us, dW, mass, Qsym, G, g_up, Z,
-                     part_du, part_rhs);
+                     part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
@@ -724,10 +721,10 @@ extern "C" int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld, int32
 
 extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym, float* G, float* g_up, float* Z,
-                                    float* part_du, float* part_rhs, int32_t cols_per_thread,
-                                    int32_t samples_per_lane, void* stream) {
+                                    float* part, int32_t cols_per_thread, int32_t samples_per_lane,
+                                    void* stream) {
   RATO_CLEAR_ERROR();
-  if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part_du || !part_rhs) return RATO_EINVAL;
+  if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part) return RATO_EINVAL;
   int32_t cpt = cols_per_thread, spl = samples_per_lane;
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
@@ -739,13 +736,12 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
       if (e != hipSuccess) return RATO_EHIP - (int)e;
     }
     dim3 grid((p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES), block(ROWS_NW * RATO_WAVE);
-    hipLaunchKernelGGL(drone_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, mass, Qsym, G, g_up, Z,
-                       part_du, part_rhs);
+    hipLaunchKernelGGL(drone_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, mass, Qsym, G, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
 #define RATO_CASE(C, L) \
-  if (cpt == C && spl == L) return launch_linearize<C, L>(p, us, dW, mass, Qsym, G, g_up, Z, part_du, part_rhs, st)
+  if (cpt == C && spl == L) return launch_linearize<C, L>(p, us, dW, mass, Qsym, G, g_up, Z, part, st)
   RATO_CASE(4, 1);
   RATO_CASE(8, 1);
   RATO_CASE(16, 1);

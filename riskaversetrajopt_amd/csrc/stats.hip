@@ -12,7 +12,10 @@
 namespace {
 
 // ------------------------------------------------------------ sum partials
-constexpr int SP_COLS = 32, SP_ROWS = 32;  // 1024 threads: 32 columns x 32 row lanes
+// 1024 threads = 16 columns x 64 row lanes.  Row lanes stride over the blocks with 4
+// independent loads in flight (the buffer is a few MB, L2-resident: latency-, not
+// bandwidth-bound), then a fixed-order LDS tree gives a run-to-run identical fp64 sum.
+constexpr int SP_COLS = 16, SP_ROWS = 64;
 
 __global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const float* __restrict__ part, int nblocks,
                                                                        int ncols, double scale,
@@ -20,16 +23,29 @@ __global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const fl
   __shared__ double red[SP_ROWS][SP_COLS + 1];
   const int cx = threadIdx.x % SP_COLS, ry = threadIdx.x / SP_COLS;
   const int c = blockIdx.x * SP_COLS + cx;
-  double acc = 0.0;
-  if (c < ncols)
-    for (int b = ry; b < nblocks; b += SP_ROWS) acc += (double)part[(size_t)b * ncols + c];
-  red[ry][cx] = acc;
-  __syncthreads();
-  if (ry == 0 && c < ncols) {
-    double s = 0.0;
-    for (int r = 0; r < SP_ROWS; ++r) s += red[r][cx];  // fixed order
-    out[c] = s * scale;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c < ncols) {
+    int b = ry;
+    for (; b + 3 * SP_ROWS < nblocks; b += 4 * SP_ROWS) {
+      const float v0 = part[(size_t)b * ncols + c];
+      const float v1 = part[(size_t)(b + SP_ROWS) * ncols + c];
+      const float v2 = part[(size_t)(b + 2 * SP_ROWS) * ncols + c];
+      const float v3 = part[(size_t)(b + 3 * SP_ROWS) * ncols + c];
+      a0 += (double)v0;
+      a1 += (double)v1;
+      a2 += (double)v2;
+      a3 += (double)v3;
+    }
+    for (; b < nblocks; b += SP_ROWS) a0 += (double)part[(size_t)b * ncols + c];
   }
+  red[ry][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+#pragma unroll
+  for (int half = SP_ROWS / 2; half > 0; half >>= 1) {  // fixed-order tree over the row lanes
+    if (ry < half) red[ry][cx] += red[ry + half][cx];
+    __syncthreads();
+  }
+  if (ry == 0 && c < ncols) out[c] = red[0][cx] * scale;
 }
 
 // ------------------------------------------------------------- risk stats
@@ -197,16 +213,23 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_tail(const float* __restrict__ 
   }
 }
 
-__global__ void rs_final(long M, double alpha, unsigned k, int var_is_max, int nblocks,
-                         const Workspace* __restrict__ ws, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsigned k, int var_is_max, int nblocks,
+                                                       const Workspace* __restrict__ ws, double* __restrict__ out) {
+  // one wave: lane i folds blocks i, i+64, ... in order, then a fixed shuffle tree (deterministic)
+  const int lane = threadIdx.x;
   double s = 0, c = 0, m = -INFINITY, tail = 0;
-  for (int b = 0; b < nblocks; ++b) {  // fixed order
+  for (int b = lane; b < nblocks; b += RATO_WAVE) {
     s += ws->blockpart[b][0];
     c += ws->blockpart[b][1];
     m = fmax(m, ws->blockpart[b][2]);
     tail += ws->blockpart[b][3];
   }
+  s = rato::wave_sum(s);
+  c = rato::wave_sum(c);
+  tail = rato::wave_sum(tail);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, RATO_WAVE));
+  if (lane != 0) return;
   const double t = (double)ws->tstar;
   // VaR = sort(Z)[M - floor(alpha M) - 1]; when floor(alpha M) == M the reference's
   // index is -1, which NumPy wraps to the LAST element (drone_main_plot.py:651).
@@ -261,7 +284,7 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
   hipLaunchKernelGGL(rs_pass2, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_pass3, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_tail, grid, block, 0, st, Z, (long)M, k, ws);
-  hipLaunchKernelGGL(rs_final, dim3(1), dim3(64), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
+  hipLaunchKernelGGL(rs_final, dim3(1), dim3(RATO_WAVE), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

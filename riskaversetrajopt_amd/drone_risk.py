@@ -205,7 +205,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True):
+                         want_Z=True, events=None):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -214,6 +214,8 @@ class Model:
            du_sum [S][6] (float64: sums over samples of dx_S/du_{s,axis}),
            rhs_sum [6]   (float64: sums of -v_final + v_final_du.u)
         ``out``: a dict returned by an earlier call (same shapes) whose buffers are reused.
+        ``events``: optional (start, end) torch.cuda.Event pair recorded tightly around the
+        linearize launch on the launch stream (bench.py's roofline timing).
         """
         dW, mass, Qsym, M = self._inputs(inputs)
         ld, S = mass.numel(), self.S
@@ -224,20 +226,22 @@ class Model:
             self._empty(num_tiles(M, tile), max(num_pairs(S), 1), 2, n_obs, tile)
         g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
         Z = (o["_Z"] if "_Z" in o else self._empty(ld)) if want_Z else None
-        part_du = o["part_du"] if o.get("part_du") is not None and o["part_du"].shape[0] == nblk \
-            else self._empty(nblk, S, 6)
-        part_rhs = o["part_rhs"] if o.get("part_rhs") is not None and o["part_rhs"].shape[0] == nblk \
-            else self._empty(nblk, 6)
+        part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) \
+            else self._empty(nblk, 6 * S + 6)
         p = self._params(M, ld)
+        if events is not None:
+            events[0].record()
         _lib.check(self._lib.rato_drone_linearize(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
-            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part_du), _lib.ptr(part_rhs), cpt, spl,
-            _lib.current_stream()), "rato_drone_linearize")
-        du_sum = stats.sum_partials(part_du, out=o.get("du_sum"))
-        rhs_sum = stats.sum_partials(part_rhs, out=o.get("rhs_sum"))
-        return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None), "du_sum": du_sum,
-                "rhs_sum": rhs_sum, "part_du": part_du, "part_rhs": part_rhs, "M": M,
-                "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt, "samples_per_lane": spl}
+            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
+            "rato_drone_linearize")
+        if events is not None:
+            events[1].record()
+        sums = stats.sum_partials(part, out=o.get("sums"))           # [6S+6] fp64, one launch
+        return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None),
+                "du_sum": sums[:6 * S].view(S, 6), "rhs_sum": sums[6 * S:], "sums": sums,
+                "part": part, "M": M, "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt,
+                "samples_per_lane": spl, "tile": tile}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
