@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, stats
+from . import _lib, assemble, qp, stats
 from . import driving_params as P
 
 n_x, n_u = P.n_x, P.n_u
@@ -237,6 +237,64 @@ class Model:
         return (self.expand_g_obs_du(r["G"], r["M"]),
                 r["g_up"].t().double().cpu().numpy())
 
+    # ---- L3: sparse QP assembly (driving.py:243-258, 301-421) --------------
+    SLACK_PENALTY = 1000.0      # driving.py:387-388
+
+    def _assemble(self, us_mat, relax):
+        r = self.linearize_device(us_mat)
+        M = r["M"]
+        G = untile(r["G"], M).double().cpu().numpy()[:, :, None, :]          # (n_pairs, 2, 1, M)
+        g_up = r["g_up"].double().cpu().numpy()[None]                        # (1, S, M)
+        return assemble.saa_constraints(
+            r["final_du"].double().cpu().numpy(), r["final_rhs"].double().cpu().numpy(), G, g_up,
+            n_u=n_u, S=self.S, M=M, alpha=self.alpha, method=self.method, kappa=1.0, baseline_pad=0.0,
+            u_min=self.u_min, u_max=self.u_max, relax=relax)
+
+    def get_objective_coeffs(self):
+        """driving.py:375-397 -> (P csc, q)."""
+        return assemble.objective(n_u, self.S, self.M, self.dt, P.R, self.SLACK_PENALTY)
+
+    def get_constraints_coeffs(self, us_mat, scp_iter):
+        """driving.py:399-421 -> (A csc, l, u).  scp_iter < 1 zeroes rows [n_x:] with n_x = 8 although
+        there are only 4 final rows, so the CVaR sum row and the first three -y_i rows survive
+        (:411-415); the reference's ``ls *= 0`` turns -inf into nan there, which OSQP's projection
+        treats like the l = u = 0 used here."""
+        relax = ('zero', n_x) if scp_iter < 1 else None
+        return self._assemble(us_mat, relax)
+
+    def get_all_constraints_coeffs_all(self, us_mat):
+        """driving.py:301-373 -> dense (constraints_dparams, low, up) without the control bounds; small M only."""
+        if self.M > 2000:
+            raise MemoryError("the dense QP matrix is O(M^2); use get_constraints_coeffs (sparse)")
+        A, l, u = self._assemble(us_mat, None)
+        k = n_u * self.S
+        return A[:-k].toarray(), l[:-k], u[:-k]
+
+    # ---- L4: host QP (driving.py:423-456) ------------------------------------
+    def define_problem(self, us_mat_p, scp_iter=0, verbose=False):
+        self.P, self.q = self.get_objective_coeffs()
+        self.A, self.l, self.u = self.get_constraints_coeffs(us_mat_p, scp_iter)
+        if scp_iter == 0 or scp_iter == 1:          # the sparsity pattern changes: set up again (:429-437)
+            self.osqp_prob = qp.OSQP()
+            self.osqp_prob.setup(self.P, self.q, self.A, self.l, self.u, eps_abs=OSQP_TOL, eps_rel=OSQP_TOL,
+                                 linsys_solver="qdldl", warm_start=True, verbose=verbose, polish=P.OSQP_POLISH)
+        else:
+            self.osqp_prob.update(l=self.l, u=self.u)
+            self.osqp_prob.update(Ax=self.A.data)
+        return True
+
+    def solve(self, verbose=False):
+        S = self.S
+        self.res = self.osqp_prob.solve()
+        if self.res.info.status != 'solved':
+            print("[solve]: Problem infeasible.")
+        us_sol = self.convert_us_vec_to_us_mat(self.res.x[:(n_u * S)])
+        ys, t_risk_sol = self.res.x[(n_u * S):-2], self.res.x[-1]
+        if verbose:
+            print("y_min =", np.min(ys))
+            print("slack_var =", self.res.x[-2])
+        return us_sol, t_risk_sol
+
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------
     def monte_carlo_cost(self, us_mat):
         us = np.asarray(us_mat)
@@ -252,3 +310,9 @@ class Model:
         return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
 
     monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
+
+
+def L2_error_us(us_mat, us_mat_prev):
+    """driving.py:459-464."""
+    error = np.mean(np.linalg.norm(us_mat - us_mat_prev, axis=-1))
+    return error / np.mean(np.linalg.norm(us_mat, axis=-1))

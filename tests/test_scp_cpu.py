@@ -1,0 +1,34 @@
+"""CPU: SCP driver + sparse assembly + host QP end to end on the fp64 oracle (reference-scale M)."""
+import numpy as np
+
+from oracle import drone as od, driving as ocar, stats as ostats
+from riskaversetrajopt_amd import scp
+from tests._oracle_qp import DroneOracleQP, DrivingOracleQP
+
+
+def test_drone_scp_converges_and_is_safe_in_sample():
+    S, M, alpha = 20, 20, 0.2
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(0), 'saa', M=M, S=S)
+    o = od.Model(S, DWs, masses, Q, 'saa', alpha)
+    out = scp.run_drone(DroneOracleQP(o), num_scp_iters_max=12, warmup_iters=1)
+    assert out["us"].shape == (S, 3)
+    assert out["L2_error"][-1] < 1e-2 and out["L2_error"][-1] < out["L2_error"][2]
+    assert np.all(np.abs(out["us"]) <= od.u_max + 1e-6)
+    assert out["define_s"].shape == (12,) and np.all(np.diff(out["cumulative_s"]) > 0)
+    # the final mean state reaches the goal (equality rows) and the in-sample CVaR constraint holds
+    xs = o.us_to_state_trajectories(out["us"])
+    np.testing.assert_allclose(xs[:, -1, :].mean(0), od.x_final, atol=5e-3)
+    _, Z = o.monte_carlo_no_collisions_constraint_verification(out["us"])
+    assert ostats.monte_carlo_avar(Z + od.OSQP_TOL, alpha) < 5e-2
+
+
+def test_driving_scp_runs_and_keeps_distance():
+    S, M, alpha = 20, 12, 0.1
+    o = ocar.Model(*ocar.sample_uncertain_parameters(np.random.RandomState(0), M, 'saa', S), alpha=alpha)
+    out = scp.run_driving(DrivingOracleQP(o), num_scp_iters_max=8)
+    assert out["us"].shape == (S, 2) and np.isfinite(out["us"]).all()
+    assert out["L2_error"][-1] < 5e-2
+    xs = o.us_to_state_trajectories(out["us"])
+    np.testing.assert_allclose(xs[0, -1, :4], ocar.state_ego_goal, atol=1e-2)
+    d = o.separation_distances_at_all_times(xs)
+    assert np.quantile(d.min(axis=1), 0.25) > -0.05
