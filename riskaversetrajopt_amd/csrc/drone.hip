@@ -424,7 +424,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
 //            reference's expression (drone_risk.py:278).  One extra task runs the
 //            adjoint from t = S for the final-state Jacobian (2 rows x 3 axes),
 //            reduces it over the block's samples and forms the rhs (:271).
-constexpr int ROWS_NW = 8;        // waves per workgroup
+#ifndef RATO_ROWS_NW
+#define RATO_ROWS_NW 8
+#endif
+#ifndef RATO_ROWS_MINW
+#define RATO_ROWS_MINW 1
+#endif
+constexpr int ROWS_NW = RATO_ROWS_NW;  // waves per workgroup
 constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -433,19 +439,15 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 #define RATO_DIAG 0  // diagnostic builds only (scratch/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores
 #endif
 
-// LDS float atomic max through the order-preserving integer trick (deterministic).
-__device__ __forceinline__ void lds_max_float(float* addr, float v) {
-  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
-}
-
 __host__ __device__ inline size_t rows_lds_floats(int S) {
-  // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | XS[6][64] | ZM[64] | head (+pad)
-  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 6 * ROWS_SAMPLES + ROWS_SAMPLES + 4;
+  // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | XS[6][64] | head (+pad)
+  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 6 * ROWS_SAMPLES + 4;
 }
 
-__global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kernel(
-    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
+// grid = (tiles, row_split): blockIdx.y > 0 only for the tiles of an incomplete last "round" (and for
+// small batches), whose row tasks are dealt out to row_split workgroups that each rebuild the LDS tables.
+__global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
+    rato_drone_params P, int tile_base, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -461,10 +463,11 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
   float2_t* US = reinterpret_cast<float2_t*>(AZ + (size_t)S * ROWS_SAMPLES);  // [S] (ux, uy)
   float* UZ = reinterpret_cast<float*>(US + S);                     // [S]
   float* XS = UZ + S;                                               // [6][64] x_S
-  float* ZM = XS + 6 * ROWS_SAMPLES;                                // [64] running max of g
-  int* head = reinterpret_cast<int*>(ZM + ROWS_SAMPLES);
+  int* head = reinterpret_cast<int*>(XS + 6 * ROWS_SAMPLES);
 
-  const size_t m_raw = (size_t)blockIdx.x * ROWS_SAMPLES + lane;
+  const int tile = tile_base + blockIdx.x;
+  const int part_id = blockIdx.y, row_split = gridDim.y;
+  const size_t m_raw = (size_t)tile * ROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;  // clamp loads; stores are predicated
   const float inv_m = 1.0f / mass[m];
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
   {
     float* PPf = reinterpret_cast<float*>(PP);
     const int nrows = 3 * S;
-    constexpr int MAXR = 8;  // rows per wave per batch (loads in flight)
+    constexpr int MAXR = 20;  // rows per wave per batch: S = 50 needs 150/8 = 19 -> one batch, all loads in flight
     for (int r0 = wave; r0 < nrows; r0 += ROWS_NW * MAXR) {
       float tmp[MAXR];
 #pragma unroll
@@ -508,7 +511,6 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
       US[i] = u2;
       UZ[i] = us[i * 3 + 2];
     }
-    if (threadIdx.x < ROWS_SAMPLES) ZM[threadIdx.x] = -INFINITY;
     if (threadIdx.x == 0) *head = 0;
   }
   __syncthreads();
@@ -541,79 +543,77 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
   }
   __syncthreads();
 
-  // ---- phase 2: tasks from the LDS queue.  task 0 = final-state Jacobian; task i>0 = row t = S - i.
+  // ---- Z = max_{j,t} g - tol from the p_{t+1} table (one wave of partition 0; cheap)
+  if (Z && part_id == 0 && wave == ROWS_NW - 1) {
+    float zmax = -INFINITY;
+    for (int t = 0; t < S; ++t) {
+      const float2_t pp = PP[t * ROWS_SAMPLES + lane];
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
+        zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
+      }
+    }
+    if (valid) Z[m] = zmax - P.tol;
+  }
+
+  // ---- phase 2: tasks from the LDS queue.
+  // Partition p of row_split owns the tasks congruent to p (mod row_split), longest first.
   constexpr int RT = ROWS_SAMPLES;  // tile width: each row sweep below is one contiguous descending stream
   const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * NOBS * RT;
-  float* __restrict__ Gt = G + (size_t)blockIdx.x * tile_floats + lane;
+  float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
   // One LDS fetch-add per task, issued by lane 0 and broadcast (written without `continue`:
   // hipcc 7.2 mis-structured the earlier for(;;)/continue form into a loop that re-ran task 0).
   auto next_task = [&]() -> int {
     int v = 0;
     if (lane == 0) v = atomicAdd(head, 1);
-    return __builtin_amdgcn_readfirstlane(v);
+    return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
   };
-  int task = (RATO_DIAG == 1) ? S + 1 : next_task();
-  while (task <= S) {
-    if (task == 0) {
-      // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s: rows (P, V) of the 3 axes, summed over the block's
+  // tasks 0..2: final-state Jacobian of axis a = task; tasks 3..S+2: row t = S + 2 - task
+  int task = (RATO_DIAG == 1) ? S + 3 : next_task();
+  while (task <= S + 2) {
+    if (task < 3) {
+      // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s for one axis: rows (P, V), summed over the block's
       // samples; the same sweep accumulates (d x_S / d u) . u for the rhs  (drone_risk.py:271)
-      float mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        mP0[a] = 1.0f; mP1[a] = 0.0f; mV0[a] = 0.0f; mV1[a] = 1.0f;
-        dP[a] = dV[a] = 0.0f;
-      }
-      for (int s = S - 1; s >= 0; --s) {
-        const float2_t u2 = US[s];
-        const float uu[3] = {u2.x, u2.y, UZ[s]};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float eP = mP1[a] * dtm, eV = mV1[a] * dtm;
-          dP[a] += eP * uu[a];
-          dV[a] += eV * uu[a];
-          const float sp = rato::wave_sum(valid ? eP : 0.0f);
-          const float sv = rato::wave_sum(valid ? eV : 0.0f);
-          if (lane == 0) {
-            part[(size_t)blockIdx.x * (6 * S + 6) + s * 6 + a] = sp;
-            part[(size_t)blockIdx.x * (6 * S + 6) + s * 6 + 3 + a] = sv;
-          }
-        }
-        if (s > 0) {  // mu_s = mu_{s+1} A_s
-          const float2_t aa = A2[s * ROWS_SAMPLES + lane];
-          const float az = AZ[s * ROWS_SAMPLES + lane];
-          const float a22[3] = {aa.x, aa.y, az};
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const float nP0 = mP0[a] + mP1[a] * a21, nP1 = mP0[a] * P.dt + mP1[a] * a22[a];
-            const float nV0 = mV0[a] + mV1[a] * a21, nV1 = mV0[a] * P.dt + mV1[a] * a22[a];
-            mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
-          }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float xp = XS[a * ROWS_SAMPLES + lane], xv = XS[(3 + a) * ROWS_SAMPLES + lane];
-        const float rp = rato::wave_sum(valid ? (-(xp - P.x_final[a]) + dP[a]) : 0.0f);
-        const float rv = rato::wave_sum(valid ? (-(xv - P.x_final[3 + a]) + dV[a]) : 0.0f);
+      const int a = task;
+      float mP0 = 1.0f, mP1 = 0.0f, mV0 = 0.0f, mV1 = 1.0f, dP = 0.0f, dV = 0.0f;
+      for (int s2 = S - 1; s2 >= 0; --s2) {
+        const float ua = (a == 0) ? US[s2].x : ((a == 1) ? US[s2].y : UZ[s2]);
+        const float eP = mP1 * dtm, eV = mV1 * dtm;
+        dP += eP * ua;
+        dV += eV * ua;
+        const float sp = rato::wave_sum_dpp(valid ? eP : 0.0f);
+        const float sv = rato::wave_sum_dpp(valid ? eV : 0.0f);
         if (lane == 0) {
-          part[(size_t)blockIdx.x * (6 * S + 6) + 6 * S + a] = rp;
-          part[(size_t)blockIdx.x * (6 * S + 6) + 6 * S + 3 + a] = rv;
+          part[(size_t)tile * (6 * S + 6) + s2 * 6 + a] = sp;
+          part[(size_t)tile * (6 * S + 6) + s2 * 6 + 3 + a] = sv;
         }
+        if (s2 > 0) {  // mu_s = mu_{s+1} A_s
+          const int slot = s2 * ROWS_SAMPLES + lane;
+          const float a22 = (a < 2) ? reinterpret_cast<const float*>(A2)[slot * 2 + a] : AZ[slot];
+          const float nP0 = mP0 + mP1 * a21, nP1 = mP0 * P.dt + mP1 * a22;
+          const float nV0 = mV0 + mV1 * a21, nV1 = mV0 * P.dt + mV1 * a22;
+          mP0 = nP0; mP1 = nP1; mV0 = nV0; mV1 = nV1;
+        }
+      }
+      const float xp = XS[a * ROWS_SAMPLES + lane], xv = XS[(3 + a) * ROWS_SAMPLES + lane];
+      const float rp = rato::wave_sum_dpp(valid ? (-(xp - P.x_final[a]) + dP) : 0.0f);
+      const float rv = rato::wave_sum_dpp(valid ? (-(xv - P.x_final[3 + a]) + dV) : 0.0f);
+      if (lane == 0) {
+        part[(size_t)tile * (6 * S + 6) + 6 * S + a] = rp;
+        part[(size_t)tile * (6 * S + 6) + 6 * S + 3 + a] = rv;
       }
     } else {
-      const int t = S - task;  // S-1 ... 0 (longest rows first)
+      const int t = S + 2 - task;  // S-1 ... 0 (longest rows first)
       const float2_t pp = PP[t * ROWS_SAMPLES + lane];
       float gj[NOBS], wx[NOBS], wy[NOBS];  // g, and -(Q+Q^T) d pre-multiplied by dt/m
-      float gmax = -INFINITY;
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) {
         const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
         gj[j] = 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
         wx[j] = -(2.0f * q00[j] * dx + qs[j] * dy) * dtm;
         wy[j] = -(qs[j] * dx + 2.0f * q11[j] * dy) * dtm;
-        gmax = fmaxf(gmax, gj[j]);
       }
-      lds_max_float(&ZM[lane], gmax);
       float m0x = 1.0f, m0y = 1.0f, m1x = 0.0f, m1y = 0.0f;  // mu_{t+1} = e_0^T (x and y axes)
       float accx = 0.0f, accy = 0.0f;                        // sum_s mu_{s+1}[1] u_s  per axis
       float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * NOBS * RT);
@@ -641,10 +641,6 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE) void drone_linearize_rows_kerne
       }
     }
     task = next_task();
-  }
-  if (Z) {
-    __syncthreads();
-    if (wave == 0 && valid) Z[m] = ZM[lane] - P.tol;
   }
 }
 
@@ -735,8 +731,25 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
     }
-    dim3 grid((p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES), block(ROWS_NW * RATO_WAVE);
-    hipLaunchKernelGGL(drone_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, mass, Qsym, G, g_up, Z, part);
+    // Small batches (fewer tiles than resident workgroup slots) deal each tile's row tasks out to
+    // row_split workgroups so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us).  Splitting only
+    // the tiles of an incomplete last round of a large batch was measured and does not pay
+    // (M = 1e5: 0.627 -> 0.648 ms), so large batches use one workgroup per tile.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int per_cu = (int)(ROWS_LDS_MAX / lds);
+    if (per_cu > 32 / ROWS_NW) per_cu = 32 / ROWS_NW;
+    if (per_cu < 1) per_cu = 1;
+    const int slots = cus * per_cu;
+    const int n_tiles = (p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
+    int split = 1;
+    if (n_tiles < slots) {
+      split = slots / n_tiles;
+      if (split > (p->S + 3) / 4) split = (p->S + 3) / 4;  // keep >= 4 tasks per workgroup
+      if (split < 1) split = 1;
+    }
+    hipLaunchKernelGGL(drone_linearize_rows_kernel, dim3(n_tiles, split), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, 0,
+                       us, dW, mass, Qsym, G, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

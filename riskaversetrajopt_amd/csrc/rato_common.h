@@ -28,6 +28,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Wave-wide sum through DPP (no LDS crossbar round trips: ~10x lower latency than the
+// ds_bpermute chain __shfl_xor compiles to).  The total is valid in EVERY lane (read back
+// from lane 63 with readlane).  Fixed combination order, so results are deterministic.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  int x = __float_as_int(v);
+  // row_shr:1,2,3 then row_shr:4 + row_shr:8 style prefix inside each row of 16 lanes
+  float a = v;
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x111, 0xf, 0xf, true));  // row_shr:1
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x112, 0xf, 0xf, true));  // row_shr:2
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x114, 0xf, 0xf, true));  // row_shr:4
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x118, 0xf, 0xf, true));  // row_shr:8
+  // lane 15 of each row now holds the row total; combine the four rows
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x142, 0xa, 0xf, true));  // row_bcast:15
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x143, 0xc, 0xf, true));  // row_bcast:31
+  (void)x;
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, RATO_WAVE);
