@@ -14,8 +14,8 @@ quoted on: drone_risk, M = 1e5 samples per GPU, S = 50 steps, fp32.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — the dominant kernel's algorithmic HBM bytes / its launch time
                  measured live with HIP events on the launch stream, vs 8 TB/s
-  cpu_baseline — the NumPy fp64 oracle ("port") timed on this box's host, on a
-                 bounded sample of the same workload (rank 0, N=1 only).
+  cpu_baseline — the oracle ("port": C + OpenMP for the drone, NumPy otherwise) timed on
+                 this box's host cores, on a bounded sample of the same workload (rank 0, N=1 only).
 Other workloads (--workload driving|hopper, --M, --S, --mode eval) are for
 sweeps; they print the same line shape.
 """
@@ -108,18 +108,22 @@ class DroneWork:
         return eval_in + M * B * (3 * S + 3 * S * (S - 1)) + nblk * (6 * S + 6) * B   # g_up, G nnz | partials
 
     def cpu_baseline(self, n, alpha):
-        from oracle import drone as od, stats as ostats
+        """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples; dense outputs in the
+        reference's shapes, buffers reused) on the same workload; -> step(nthreads) callable."""
+        from oracle import c_oracle, drone as od, stats as ostats
         rng = np.random.RandomState(0)
         DWs, masses, obs_Qs = od.sample_uncertain_parameters(rng, 'saa', M=n, S=self.S)
-        o = od.Model(self.S, DWs, masses, obs_Qs, 'saa', alpha)
         us = graze_us(self.S, 3)
+        want = ("v_final_du", "val_final", "g_obs_du", "g_up", "Z") if self.mode == "linearize" else ("Z",)
+        out = c_oracle.drone(us, DWs, masses, obs_Qs, od.T / self.S, nthreads=0, want=want)   # first touch
 
-        def step():
+        def step(nthreads):
+            c = c_oracle.drone(us, DWs, masses, obs_Qs, od.T / self.S, nthreads=nthreads, want=want, out=out)
             if self.mode == "linearize":
-                fdu, flo, _, gdu, gup = o.get_all_constraints_coeffs(us)
-                fdu.mean(0), flo.mean(0)
-            _, Z = o.monte_carlo_no_collisions_constraint_verification(us)
+                c["v_final_du"].mean(0), c["val_final"].mean(0)
+            Z = c["Z"]
             return ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha), np.mean(Z <= 1e-6)
+        step.threaded = True
         return step
 
 
@@ -236,7 +240,7 @@ class HopperWork:
 
 
 WORKLOADS = {"drone": DroneWork, "driving": DrivingWork, "hopper": HopperWork}
-CPU_SAMPLES = {"drone": 4000, "driving": 3000, "hopper": 50000}
+CPU_SAMPLES = {"drone": 8000, "driving": 3000, "hopper": 50000}
 
 
 def pmc_traffic(workload, mode, M, S):
@@ -328,19 +332,36 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n = args.cpu_samples or CPU_SAMPLES[args.workload]
             cpu_step = work.cpu_baseline(n, args.alpha)
-            cpu_step()                                     # warm-up
-            reps, t_cpu = 0, 0.0
-            while t_cpu < 10.0 and reps < 5:
-                t1 = time.perf_counter()
-                cpu_step()
-                t_cpu += time.perf_counter() - t1
-                reps += 1
-            cpu_val = n * unit_steps * reps / t_cpu
+            threaded = getattr(cpu_step, "threaded", False)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = min(avail, 64) if threaded else 1
+
+            def timed(fn, budget_s, max_reps):
+                fn()                                       # warm-up
+                reps, t_cpu = 0, 0.0
+                while t_cpu < budget_s and reps < max_reps:
+                    t1 = time.perf_counter()
+                    fn()
+                    t_cpu += time.perf_counter() - t1
+                    reps += 1
+                return n * unit_steps * reps / t_cpu, reps, t_cpu
+
+            if threaded:
+                v1, r1, t1 = timed(lambda: cpu_step(1), 6.0, 40)
+                vp, rp, tp = timed(lambda: cpu_step(cores), 12.0, 200)
+                cpu_val, extra = vp, (f"C oracle (oracle/saa_oracle.c, fp64, dense outputs like the reference, "
+                                      f"OpenMP over samples), M={n}: {cores} threads {vp:.3e} ({rp} reps, {tp:.1f} s); "
+                                      f"1 thread {v1:.3e} ({r1} reps, {t1:.1f} s)")
+            else:
+                cpu_val, reps, t_cpu = timed(cpu_step, 10.0, 5)
+                extra = f"NumPy fp64 oracle, M={n}, {reps} rep(s), {t_cpu:.1f} s"
             line["cpu_baseline"] = {
-                "value": cpu_val, "unit": line["unit"], "cores": 1, "kind": "port",
-                "sample": f"NumPy fp64 oracle (restatement of the reference's path; the reference's JAX/XLA-CPU "
-                          f"path is not installable here), same workload at M={n}, {reps} rep(s), "
-                          f"{t_cpu:.1f} s; host has {os.cpu_count()} cores",
+                "value": cpu_val, "unit": line["unit"], "cores": cores, "kind": "port",
+                "sample": extra + f"; restatement of the reference's path (its JAX/XLA-CPU path is not installable "
+                                  f"here); host reports {os.cpu_count()} cpus",
                 "gpu_over_cpu": value / cpu_val}
         print(json.dumps(line))
     if world > 1:
