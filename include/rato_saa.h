@@ -164,10 +164,15 @@ int rato_car_eval(const rato_car_params* p, const float* us, const float* dW,
                   const float* x0_ped, const float* w_speed, const float* w_rep,
                   float* ego_scratch, float* Z, float* xs, float* g, void* stream);
 
+/* Kernel variants of rato_car_linearize: cols_per_thread = -1 row-parallel adjoint kernel (default;
+ * needs ~20*64*S bytes of LDS <= 160 KB), 4/8/16 forward column kernel.  Resolves 0 to a concrete
+ * value, reports the TILE of the G layout and returns the number of sample blocks (<0: bad arguments). */
+int rato_car_linearize_plan(int32_t M, int32_t S, int32_t* cols_per_thread, int32_t* tile);
+
 /*
  * Replaces vmap(Model.get_all_constraints_coeffs) (driving.py:260-307).
  * outputs:
- *   G        [n_tiles][n_pairs][2 controls][RATO_TILE]   d g_t / d u[s,i] for s<t
+ *   G        [n_tiles][n_pairs][2 controls][TILE]   d g_t / d u[s,i] for s<t
  *   g_up     [S][M]
  *   Z        [M] or NULL
  *   final_du [4][2S]   d x_S[0:4] / d u  (sample independent, so already the mean; :311)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 8 + [C.c_int32, C.c_int32, c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
+    "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rato_car_eval": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 9 + [c_stream]),
     "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),

@@ -266,6 +266,187 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
   if (lead && valid && Z) Z[m] = zmax - P.tol;
 }
 
+// ---------------------------------------------------------------------------
+// Row-parallel (adjoint) linearization for the driving problem — default.
+// Same structure as drone_linearize_rows_kernel: a workgroup owns 64 samples;
+//   phase 0  stage the noise tile, the controls and the (sample-independent) ego tables in LDS;
+//   phase 1  wave 0 rolls the 4-state pedestrian out and leaves K_k = dt w_r (I - n n^T)/r (3 floats)
+//            and the pedestrian position q_{k+1} (2 floats) in LDS: 20 B per sample-step;
+//   phase 2  all waves pull row tasks from an LDS queue and sweep row t with the 8-state adjoint
+//            eta_{t+1} = grad_x g_t = (-n, 0, 0, +n, 0, 0),  eta_k = eta_{k+1} J_k,
+//            d g_t / d u_{s,i} = dt * eta_{s+1}[2 + i]   (u_0 drives v_ego, u_1 drives phi_ego),
+//            accumulating the row's dot product with u for g_up (driving.py:295).
+// The forward/column kernel above re-rolls the pedestrian once per column group and carries
+// 8 registers per control step; it stays as the fallback when the LDS tables do not fit.
+constexpr int CROWS_NW = 8;
+constexpr int CROWS_SAMPLES = 64;
+
+typedef float cfloat2_t __attribute__((ext_vector_type(2)));
+typedef float cfloat4_t __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t car_rows_lds_floats(int S) {
+  // KK float2 + QP float2 + K11 float per (k, lane) | EGOP float2[S+1] | EC float4[S] | US float2[S] | head (+pad)
+  return (size_t)S * CROWS_SAMPLES * 5 + (size_t)(S + 1) * 2 + (size_t)S * 4 + (size_t)S * 2 + 4;
+}
+
+__global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel(
+    rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
+    const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
+    const float* __restrict__ scratch, float* __restrict__ G, float* __restrict__ g_up, float* __restrict__ Z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
+  const size_t M = (size_t)P.M;
+  const int S = P.S;
+  const int lane = threadIdx.x & (RATO_WAVE - 1), wave = threadIdx.x / RATO_WAVE;
+  // (no __restrict__: QP[t] holds step t's noise until the rollout overwrites it with q_{t+1})
+  cfloat4_t* EC = reinterpret_cast<cfloat4_t*>(car_lds_raw);                 // [S] (dt c, dt s, -dt v s, dt v c)
+  cfloat2_t* KK = reinterpret_cast<cfloat2_t*>(EC + S);                      // [S][64] (k00, k01)
+  cfloat2_t* QP = KK + (size_t)S * CROWS_SAMPLES;                            // [S][64] q_{k+1}
+  cfloat2_t* EGOP = QP + (size_t)S * CROWS_SAMPLES;                          // [S+1] ego position
+  cfloat2_t* US = EGOP + (S + 1);                                            // [S]
+  float* K11 = reinterpret_cast<float*>(US + S);                             // [S][64]
+  int* head = reinterpret_cast<int*>(K11 + (size_t)S * CROWS_SAMPLES);
+
+  const size_t m_raw = (size_t)blockIdx.x * CROWS_SAMPLES + lane;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;
+  const float w_s = w_speed[m], w_r = w_rep[m];
+  const float ks = P.dt * w_s;
+  const float* __restrict__ ego = scratch;
+
+  // ---- phase 0: stage noise, controls, ego tables
+  {
+    float* QPf = reinterpret_cast<float*>(QP);
+    const int nrows = 2 * S;
+    constexpr int MAXR = 16;
+    for (int r0 = wave; r0 < nrows; r0 += CROWS_NW * MAXR) {
+      float tmp[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + i * CROWS_NW;
+        tmp[i] = (r < nrows) ? dW[(size_t)r * M + m] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + i * CROWS_NW;
+        if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp[i];
+      }
+    }
+    for (int t = threadIdx.x; t <= S; t += CROWS_NW * RATO_WAVE) {
+      cfloat2_t e;
+      e.x = ego[t * 4 + 0];
+      e.y = ego[t * 4 + 1];
+      EGOP[t] = e;
+      if (t < S) {
+        const float v = ego[t * 4 + 2], ph = ego[t * 4 + 3];
+        float sn, cs;
+        sincosf(ph, &sn, &cs);
+        cfloat4_t c;
+        c.x = P.dt * cs;
+        c.y = P.dt * sn;
+        c.z = -P.dt * v * sn;
+        c.w = P.dt * v * cs;
+        EC[t] = c;
+        cfloat2_t u2;
+        u2.x = us[t * 2 + 0];
+        u2.y = us[t * 2 + 1];
+        US[t] = u2;
+      }
+    }
+    if (threadIdx.x == 0) *head = 0;
+  }
+  __syncthreads();
+
+  // ---- phase 1: wave 0 rolls the pedestrian out (driving.py:145-158,196-203)
+  if (wave == 0) {
+    PedConsts c;
+    c.w_s = w_s;
+    c.w_r = w_r;
+    c.cn = sqrtf(P.dt) * P.beta;
+    float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+    for (int t = 0; t < S; ++t) {
+      const int slot = t * CROWS_SAMPLES + lane;
+      const cfloat2_t xi = QP[slot];
+      const cfloat2_t e = EGOP[t];
+      float n0, n1, rinv;
+      ped_step(P, c, e.x, e.y, xi.x, xi.y, px, py, vx, vy, n0, n1, rinv);
+      const float kr = P.dt * w_r * rinv;  // dt w_r (I - n n^T)/r at state t
+      cfloat2_t kk;
+      kk.x = kr * (1.0f - n0 * n0);
+      kk.y = -kr * n0 * n1;
+      KK[slot] = kk;
+      K11[slot] = kr * (1.0f - n1 * n1);
+      cfloat2_t q;
+      q.x = px;
+      q.y = py;
+      QP[slot] = q;
+    }
+  }
+  __syncthreads();
+
+  // ---- Z = max_t g_t - tol (one wave; cheap)
+  if (Z && wave == CROWS_NW - 1) {
+    float zmax = -INFINITY;
+    for (int t = 0; t < S; ++t) {
+      const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e = EGOP[t + 1];
+      const float dx = e.x - q.x, dy = e.y - q.y;
+      zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
+    }
+    if (valid) Z[m] = zmax - P.tol;
+  }
+
+  // ---- phase 2: row tasks, longest first
+  constexpr int RT = CROWS_SAMPLES;
+  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * RT;
+  float* __restrict__ Gt = G + (size_t)blockIdx.x * tile_floats + lane;
+  auto next_task = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(head, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  int task = next_task();
+  while (task < S) {
+    const int t = S - 1 - task;
+    const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e1 = EGOP[t + 1];
+    const float dx = e1.x - q.x, dy = e1.y - q.y;
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float n0 = dx / r, n1 = dy / r;
+    const float gt = -(r - P.d_min);                       // driving.py:223-230,269
+    float epx = -n0, epy = -n1, ev = 0.0f, eph = 0.0f;     // eta (ego part)
+    float qx = n0, qy = n1, qvx = 0.0f, qvy = 0.0f;        // eta (pedestrian part)
+    float acc = 0.0f;
+    float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * RT);
+    for (int k = t; k >= 1; --k) {
+      const int slot = k * CROWS_SAMPLES + lane;
+      const cfloat2_t kk = KK[slot];
+      const float k11 = K11[slot];
+      const cfloat4_t c = EC[k];
+      const cfloat2_t u2 = US[k - 1];
+      const float f0 = qvx * kk.x + qvy * kk.y, f1 = qvx * kk.y + qvy * k11;   // (eta_qv) K
+      const float nev = ev + epx * c.x + epy * c.y;
+      const float neph = eph + epx * c.z + epy * c.w;
+      const float nqvx = qvx + P.dt * qx;
+      const float nqvy = qvy + P.dt * qy - ks * (qvx + qvy);
+      epx -= f0;
+      epy -= f1;
+      qx += f0;
+      qy += f1;
+      ev = nev;
+      eph = neph;
+      qvx = nqvx;
+      qvy = nqvy;
+      const float o0 = P.dt * ev, o1 = P.dt * eph;         // d g_t / d u_{k-1, 0|1}
+      acc += o0 * u2.x + o1 * u2.y;
+      if (valid) {
+        float* __restrict__ o = Grow + (k - 1) * (2 * RT);
+        o[0] = o0;
+        o[RT] = o1;
+      }
+    }
+    if (valid) g_up[(size_t)t * M + m] = -gt + acc;        // driving.py:295
+    task = next_task();
+  }
+}
+
 bool params_ok(const rato_car_params* p) {
   return p && p->M > 0 && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
 }
@@ -300,6 +481,34 @@ extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const fl
   return RATO_OK;
 }
 
+namespace {
+constexpr size_t CAR_ROWS_LDS_MAX = 160 * 1024;
+size_t car_rows_lds_bytes(int S) { return car_rows_lds_floats(S) * sizeof(float); }
+}  // namespace
+
+extern "C" int rato_car_linearize_plan(int32_t M, int32_t S, int32_t* cols_per_thread, int32_t* tile) {
+  if (M <= 0 || S <= 0 || !cols_per_thread || !tile) return RATO_EINVAL;
+  int c = *cols_per_thread;
+  if (c == 0) c = (S >= 2 && car_rows_lds_bytes(S) <= CAR_ROWS_LDS_MAX) ? -1 : 0;
+  if (c == -1 && !(S >= 2 && car_rows_lds_bytes(S) <= CAR_ROWS_LDS_MAX)) return RATO_EINVAL;
+  if (c == 0) {
+    const long waves_per_group = (long)rato::nblocks_for(M) * (RATO_BLOCK / RATO_WAVE);
+    c = 4;
+    const int cands[2] = {16, 8};
+    for (int i = 0; i < 2; ++i) {
+      const int ng = (S + cands[i] - 1) / cands[i];
+      if (waves_per_group * ng >= 2048) {
+        c = cands[i];
+        break;
+      }
+    }
+  }
+  if (c != -1 && c != 4 && c != 8 && c != 16) return RATO_EINVAL;
+  *cols_per_thread = c;
+  *tile = (c == -1) ? CROWS_SAMPLES : RATO_TILE;
+  return (c == -1) ? (M + CROWS_SAMPLES - 1) / CROWS_SAMPLES : rato::nblocks_for(M);
+}
+
 extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, const float* dW,
                                   const float* x0_ped, const float* w_speed, const float* w_rep,
                                   float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
@@ -309,18 +518,20 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
   hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, final_du, final_rhs);
-  int spt = cols_per_thread;
-  if (spt == 0) {
-    const long waves_per_group = (long)rato::nblocks_for(p->M) * (RATO_BLOCK / RATO_WAVE);
-    spt = 4;
-    const int cands[2] = {16, 8};
-    for (int i = 0; i < 2; ++i) {
-      const int ng = (p->S + cands[i] - 1) / cands[i];
-      if (waves_per_group * ng >= 2048) {
-        spt = cands[i];
-        break;
-      }
+  int32_t spt = cols_per_thread, tile = 0;
+  if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
+  if (spt == -1) {
+    const size_t lds = car_rows_lds_bytes(p->S);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
     }
+    dim3 grid((p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES), block(CROWS_NW * RATO_WAVE);
+    hipLaunchKernelGGL(car_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
+                       ego_scratch, G, g_up, Z);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
   }
   switch (spt) {
     case 4: return launch_car_linearize<4>(p, dW, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, st);

@@ -186,7 +186,12 @@ class Model:
         M, S = ws.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}
-        G = o.get("G") if "G" in o else self._empty(num_tiles(M), max(num_pairs(S), 1), 2, TILE)
+        cpt, tile = C.c_int32(int(cols_per_thread)), C.c_int32(0)
+        if self._lib.rato_car_linearize_plan(M, S, C.byref(cpt), C.byref(tile)) < 0:
+            raise _lib.RatoError(f"no car linearize variant for cols_per_thread={cols_per_thread}, S={S}")
+        cols_per_thread, tile = cpt.value, tile.value
+        G = o["G"] if ("G" in o and o["G"].shape[-1] == tile) else \
+            self._empty(num_tiles(M, tile), max(num_pairs(S), 1), 2, tile)
         g_up = o.get("g_up") if "g_up" in o else self._empty(S, M)
         Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
         final_du = o.get("final_du") if "final_du" in o else self._empty(4, n_u * S)
@@ -196,7 +201,8 @@ class Model:
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
             _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
             _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
-        return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M}
+        return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M,
+                "cols_per_thread": cols_per_thread, "tile": tile}
 
     def expand_g_obs_du(self, G, M=None):
         """packed G -> dense host (M, S, n_u*S); small M only.  G is either the tile-blocked

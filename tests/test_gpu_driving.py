@@ -52,7 +52,8 @@ def test_rollout_and_distances_vs_oracle(S, M):
 
 
 @pytest.mark.parametrize("S,M,spt", [(20, 300, 0), (20, 100, 4), (20, 100, 8), (20, 100, 16), (40, 130, 0),
-                                      (40, 70, 16), (33, 65, 8), (2, 5, 4), (1, 3, 0)])
+                                      (40, 70, 16), (33, 65, 8), (2, 5, 4), (1, 3, 0), (20, 300, -1), (40, 257, -1),
+                                      (33, 65, -1), (2, 5, -1), (120, 9, 0), (130, 5, 0)])
 def test_linearization_vs_oracle(S, M, spt):
     o, d = _models(S, M)
     us = swerve(S)
@@ -68,15 +69,22 @@ def test_linearization_vs_oracle(S, M, spt):
     np.testing.assert_allclose(r["Z"].cpu().numpy(), Z_o, rtol=tol.G_RTOL, atol=tol.G_ATOL)
 
 
-def test_grouping_is_bitwise_consistent_and_deterministic():
+def test_variants_agree_and_are_deterministic():
     from riskaversetrajopt_amd.driving import untile
     M = 200
     _, d = _models(40, M)
     us = swerve(40)
     ref = d.linearize_device(us, cols_per_thread=4)
-    for spt in (8, 16, 4):
+    b = untile(ref["G"], M).cpu().numpy()
+    for spt in (4, 8, 16, -1):
         r = d.linearize_device(us, cols_per_thread=spt)
-        assert bool((untile(r["G"], M) == untile(ref["G"], M)).all()) and bool((r["g_up"] == ref["g_up"]).all())
+        a = untile(r["G"], M).cpu().numpy()
+        assert np.all(np.abs(a - b) <= 1e-5 * np.abs(b).max(axis=(0, 1), keepdims=True) + 1e-12), spt
+        assert np.array_equal(a == 0.0, b == 0.0)
+        np.testing.assert_allclose(r["g_up"].cpu().numpy(), ref["g_up"].cpu().numpy(), rtol=1e-5, atol=5e-5)
+        again = d.linearize_device(us, cols_per_thread=spt)
+        assert bool((untile(again["G"], M) == untile(r["G"], M)).all()), spt
+        assert bool((again["g_up"] == r["g_up"]).all()) and bool((again["Z"] == r["Z"]).all())
 
 
 def test_single_sample_api_and_baseline():
@@ -133,7 +141,7 @@ def test_full_size_C3_properties():
         Gu[t] = (Gp[off:off + t] * u[:t, :, None]).sum(dim=(0, 1))
     assert (r["g_up"] + g - Gu).abs().max().item() < 2e-3
     Z_eval, _, _ = d.eval_device(us)
-    assert bool((Z_eval == r["Z"]).all())
+    assert (Z_eval - r["Z"]).abs().max().item() <= 1e-5
     ok_o, Z_o = o.monte_carlo_separation_constraints_verification(us)
     st = d.monte_carlo_statistics(us, alpha=0.05)
     assert abs(st["frac_satisfied"] - ok_o.mean()) <= np.sum(np.abs(Z_o - 1e-6) < tol.NEAR_THRESHOLD) / M + 1e-12
