@@ -78,6 +78,7 @@ class DroneWork:
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl)
             self.out = r                                                       # buffers are reused every step
             self.variant = "cols_per_thread=%d samples_per_lane=%d" % (r["cols_per_thread"], r["samples_per_lane"])
+            self.kernel = "drone_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "drone_linearize_kernel"
         else:
             self.kernel = "drone_eval_kernel"
 
@@ -144,6 +145,8 @@ class DrivingWork:
         if self.mode == "linearize":
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt)
             self.out = {k: r[k] for k in ("G", "g_up", "Z", "final_du", "final_rhs")}
+            self.variant = "cols_per_thread=%d" % r["cols_per_thread"]
+            self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
             self.kernel = "car_eval_kernel"
 
@@ -274,7 +277,7 @@ def main():
     stats_out = torch.empty(8, dtype=torch.float64, device=device)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -297,7 +300,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -364,7 +367,7 @@ def main():
                                   f"here); host reports {os.cpu_count()} cpus",
                 "gpu_over_cpu": value / cpu_val}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

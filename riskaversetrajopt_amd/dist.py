@@ -27,14 +27,17 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("RATO_FORCE_DIST") == "1"     # exercise the collective path on a single GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -66,7 +69,8 @@ def exchange(sums64, Z32, group=None):
     """The single collective of an evaluation.  ``sums64``: rank-local fp64 sums
     (any shape), ``Z32``: rank-local fp32 Z (M_local,) — equal M_local on all
     ranks.  Returns (total_sums (like sums64), Z_all (world*M_local,))."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and os.environ.get("RATO_FORCE_DIST") != "1"):
         return sums64, Z32
     world = dist.get_world_size(group)
     n_sums, M_local = sums64.numel(), Z32.numel()

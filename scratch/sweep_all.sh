@@ -1,0 +1,10 @@
+#!/bin/bash
+# M-sweep of every kernel: prints one line per (workload, mode, M)
+run() { timeout 120 python bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" 2>/dev/null | python scratch/pline.py "$*"; }
+for M in 10000 100000 1000000; do run --workload drone --mode linearize --M $M; done
+for M in 10000 100000 1000000 10000000; do run --workload drone --mode eval --M $M; done
+for M in 10000 100000 1000000 4000000; do run --workload driving --mode linearize --M $M; done
+for M in 10000 100000 1000000 10000000; do run --workload driving --mode eval --M $M; done
+for M in 50000 1000000; do run --workload hopper --mode linearize --M $M; run --workload hopper --mode eval --M $M; done
+run --workload drone --mode linearize --M 100000 --S 20
+run --workload driving --mode linearize --M 100000 --S 20
