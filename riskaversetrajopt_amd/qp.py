@@ -213,10 +213,15 @@ class OSQP:
                and res.info.status_polish != 1 and tries < 3):
             tries += 1
             f = 10.0 ** (-tries)
-            it0, t_run = res.info.iter, res.info.run_time
+            prev = res
             res = self._solve_once(o["eps_abs"] * f, o["eps_rel"] * f)
-            res.info.iter += it0
-            res.info.run_time += t_run
+            res.info.iter += prev.info.iter
+            res.info.run_time += prev.info.run_time
+            if res.info.status != "solved":      # the tighter pass ran out of iterations: keep the
+                prev.info.iter, prev.info.run_time = res.info.iter, res.info.run_time   # eps-accurate point
+                self.x, self.y = prev.x, prev.y
+                self.z = self.A @ prev.x
+                return prev
         return res
 
     def _solve_once(self, eps_abs, eps_rel):
