@@ -215,6 +215,10 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
 int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale,
                       double* out, void* stream);
 
+/* Failure detection (the reference has none: an infeasible QP only prints, drone_risk.py:458-459):
+ * counts the NaN/Inf entries of a device array into *count (device uint32). */
+int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, void* stream);
+
 /* Workspace bytes needed by rato_risk_stats for M samples. */
 size_t rato_risk_stats_workspace_bytes(int64_t M);
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),

@@ -48,6 +48,18 @@ __global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const fl
   if (ry == 0 && c < ncols) out[c] = red[0][cx] * scale;
 }
 
+// ------------------------------------------------------------ non-finite check
+__global__ __launch_bounds__(RATO_BLOCK) void count_nonfinite_kernel(const float* __restrict__ x, long n,
+                                                                     unsigned* __restrict__ count) {
+  unsigned bad = 0;
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * RATO_BLOCK)
+    bad += !isfinite(x[i]);
+  const unsigned long long m = __ballot(bad != 0);
+  // per-lane counts can exceed 1 with the grid stride; add them exactly
+  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, RATO_WAVE);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, bad);
+}
+
 // ------------------------------------------------------------- risk stats
 constexpr int B1 = 2048, B2 = 2048, B3 = 1024;  // 11 + 11 + 10 key bits
 constexpr int RS_MAX_BLOCKS = 1024;
@@ -251,6 +263,19 @@ extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t nco
   if (!part || !out || nblocks <= 0 || ncols <= 0) return RATO_EINVAL;
   dim3 grid((ncols + SP_COLS - 1) / SP_COLS), block(SP_COLS * SP_ROWS);
   hipLaunchKernelGGL(sum_partials_kernel, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!x || !count || n <= 0) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  long nb = (n + RATO_BLOCK * 8 - 1) / (RATO_BLOCK * 8);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)nb), dim3(RATO_BLOCK), 0, st, x, (long)n, count);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -83,3 +83,17 @@ def run_driving(model, num_scp_iters_max=15, verbose=False):
     define_s, solve_s = np.array(define_s), np.array(solve_s)
     return {"us": us_prev, "t_risk": t_risk, "define_s": define_s, "solve_s": solve_s,
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
+
+
+def save_results(path, *arrays):
+    """The reference's result-file convention: several ``np.save`` calls appended to ONE file
+    (``us`` then ``xs``: drone_risk.py:534-539; nine arrays: drone_main_plot.py:700-710)."""
+    with open(path, 'wb') as f:
+        for a in arrays:
+            np.save(f, np.asarray(a))
+
+
+def load_results(path, n):
+    """Read back ``n`` arrays written by ``save_results`` (sequential ``np.load``, drone_risk.py:704-708)."""
+    with open(path, 'rb') as f:
+        return [np.load(f) for _ in range(n)]

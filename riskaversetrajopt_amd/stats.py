@@ -66,3 +66,13 @@ def sum_partials(part, scale=1.0, out=None):
     _lib.check(lib.rato_sum_partials(_lib.ptr(part), nblocks, ncols, float(scale), _lib.ptr(out),
                                      _lib.current_stream()), "rato_sum_partials")
     return out
+
+
+def count_nonfinite(x):
+    """Number of NaN/Inf entries of a device fp32 tensor (one small kernel + a 4-byte readback)."""
+    lib = _lib.load()
+    _lib.require_f32_device(x, "x")
+    cnt = torch.empty(1, dtype=torch.int32, device=x.device)
+    _lib.check(lib.rato_count_nonfinite(_lib.ptr(x), x.numel(), _lib.ptr(cnt), _lib.current_stream()),
+               "rato_count_nonfinite")
+    return int(cnt.item())

@@ -83,3 +83,15 @@ def test_sum_partials(nblocks, ncols):
     np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-9)
     again = stats.sum_partials(part, scale=0.5).cpu().numpy()
     assert np.array_equal(out, again)
+
+
+def test_count_nonfinite():
+    import torch
+    from riskaversetrajopt_amd import stats
+    x = torch.randn(1000003, device="cuda")
+    assert stats.count_nonfinite(x) == 0
+    x[5] = float("nan")
+    x[77777] = float("inf")
+    x[-1] = -float("inf")
+    assert stats.count_nonfinite(x) == 3
+    assert stats.count_nonfinite(torch.full((70000,), float("nan"), device="cuda")) == 70000

@@ -32,3 +32,15 @@ def test_driving_scp_runs_and_keeps_distance():
     np.testing.assert_allclose(xs[0, -1, :4], ocar.state_ego_goal, atol=1e-2)
     d = o.separation_distances_at_all_times(xs)
     assert np.quantile(d.min(axis=1), 0.25) > -0.05
+
+
+def test_result_files_follow_the_reference_convention(tmp_path):
+    us, xs = np.arange(60.0).reshape(20, 3), np.random.RandomState(0).randn(4, 21, 6)
+    f = tmp_path / "drone_alpha=0.1_repeat=0.npy"
+    scp.save_results(f, us, xs)
+    with open(f, 'rb') as fh:                       # exactly how drone_risk.py:704-708 reads it
+        a = np.load(fh)
+        b = np.load(fh)
+    assert np.array_equal(a, us) and np.array_equal(b, xs)
+    c, d = scp.load_results(f, 2)
+    assert np.array_equal(c, us) and np.array_equal(d, xs)
