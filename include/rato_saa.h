@@ -14,7 +14,9 @@
  *     e.g. torch.Tensor.data_ptr(); nothing is allocated or freed here.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
  *     are asynchronous and stream-ordered; nothing synchronises the device.
- *   - no global state: safe to call concurrently from one host thread per GPU.
+ *   - no global state beyond cached device properties (CU count, LDS attribute): safe to call
+ *     concurrently from one host thread per GPU, and — after one ordinary call per kernel
+ *     variant — inside a hipGraph stream capture (no non-stream runtime call is made).
  *   - return value: 0 ok; RATO_EINVAL bad argument; RATO_EHIP-<hipError_t>
  *     when a launch fails.
  *   - the sample index m is ALWAYS the fastest-varying index (SoA), so every

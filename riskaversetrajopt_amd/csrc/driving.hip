@@ -12,6 +12,8 @@
 //   d g_t / d u_c = -n_{t+1}^T (E_{t+1}[pos, c] - dpp_{t+1})
 // Lane = sample; grid.y = groups of control steps s (both controls of a step
 // share one slot because they share the activity window t > s).
+#include <atomic>
+
 #include "rato_common.h"
 
 namespace {
@@ -522,10 +524,12 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
   if (spt == -1) {
     const size_t lds = car_rows_lds_bytes(p->S);
-    if (lds > 64 * 1024) {
+    static std::atomic<size_t> lds_attr_set{64 * 1024};   // cached: capture-safe after the first call
+    if (lds > lds_attr_set.load()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
+      lds_attr_set.store(lds);
     }
     dim3 grid((p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES), block(CROWS_NW * RATO_WAVE);
     hipLaunchKernelGGL(car_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,

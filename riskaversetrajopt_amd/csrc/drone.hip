@@ -9,6 +9,8 @@
 // the trajectory is known, and each thread re-rolls the (cheap) trajectory while
 // it propagates CPT columns held in registers.  Axes decouple:
 //   A_t = [[1, dt], [-kp dt/m, 1 - dt (kd + 2 c_d |v_t|)/m]],  B = [0, dt/m]^T.
+#include <atomic>
+
 #include "rato_common.h"
 
 namespace {
@@ -726,17 +728,27 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
   hipStream_t st = rato::as_stream(stream);
   if (cpt == -1) {
     const size_t lds = rows_lds_bytes(p->S);
-    if (lds > 64 * 1024) {
+    // Device properties are cached so that a launch inside a hipGraph capture makes no non-stream
+    // runtime call (the first, uncaptured call sets them).
+    static std::atomic<size_t> lds_attr_set{64 * 1024};
+    static std::atomic<int> cu_count{0};
+    if (lds > lds_attr_set.load()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
+      lds_attr_set.store(lds);
     }
     // Small batches (fewer tiles than resident workgroup slots) deal each tile's row tasks out to
     // row_split workgroups so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us).  Splitting only
     // the tiles of an incomplete last round of a large batch was measured and does not pay
     // (M = 1e5: 0.627 -> 0.648 ms), so large batches use one workgroup per tile.
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cus = cu_count.load();
+    if (cus == 0) {
+      int dev = 0;
+      cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      cu_count.store(cus);
+    }
     int per_cu = (int)(ROWS_LDS_MAX / lds);
     if (per_cu > 32 / ROWS_NW) per_cu = 32 / ROWS_NW;
     if (per_cu < 1) per_cu = 1;

@@ -134,6 +134,13 @@ __device__ void flush_hist(unsigned* lds_hist, unsigned* __restrict__ ghist) {
   }
 }
 
+// zeroes the three histograms (a kernel rather than hipMemsetAsync: memset nodes of this size did not
+// replay correctly inside a captured hipGraph on ROCm 7.2)
+__global__ __launch_bounds__(RATO_BLOCK) void rs_zero(Workspace* __restrict__ ws) {
+  unsigned* h = ws->hist1;  // hist1, hist2, hist3 are contiguous
+  for (int i = blockIdx.x * RATO_BLOCK + threadIdx.x; i < B1 + B2 + B3; i += gridDim.x * RATO_BLOCK) h[i] = 0;
+}
+
 __global__ __launch_bounds__(RATO_BLOCK) void rs_pass1(const float* __restrict__ Z, long M, float thr,
                                                        Workspace* __restrict__ ws) {
   __shared__ unsigned h[B1];
@@ -302,9 +309,8 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
   long nb = (M + RATO_BLOCK * 4 - 1) / (RATO_BLOCK * 4);
   if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
   if (nb < 1) nb = 1;
-  hipError_t e = hipMemsetAsync(ws, 0, offsetof(Workspace, blockpart), st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
   dim3 grid((unsigned)nb), block(RATO_BLOCK);
+  hipLaunchKernelGGL(rs_zero, dim3(4), block, 0, st, ws);
   hipLaunchKernelGGL(rs_pass1, grid, block, 0, st, Z, (long)M, thr, ws);
   hipLaunchKernelGGL(rs_pass2, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_pass3, grid, block, 0, st, Z, (long)M, k, ws);

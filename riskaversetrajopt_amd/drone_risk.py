@@ -297,6 +297,26 @@ class Model:
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
+    # ---- hipGraph: one SCP-iteration's device work as a single replayable graph -------------
+    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0):
+        """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
+        only the capture/replay plumbing; the nodes are this library's kernels).  Returns a
+        ``StepGraph``: write the controls into ``.us`` (device tensor, (S, n_u)), call ``.replay()``
+        and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[8], rato_saa.h)."""
+        alpha = self.alpha if alpha is None else alpha
+        us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
+        out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane)
+        ws = torch.empty(self._lib.rato_risk_stats_workspace_bytes(out["M"]), dtype=torch.uint8, device=self.device)
+        st = torch.empty(8, dtype=torch.float64, device=self.device)
+        stats.risk_stats_device(out["Z"], alpha, workspace=ws, out=st)         # warm-up: uncaptured first call
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            res = self.linearize_device(us, cols_per_thread=out["cols_per_thread"],
+                                        samples_per_lane=out["samples_per_lane"], out=out)
+            stats.risk_stats_device(res["Z"], alpha, workspace=ws, out=st)
+        return StepGraph(graph, us, res, st)
+
     # ---- L3: sparse QP assembly (drone_risk.py:221-237, 282-423) -----------
     MULTIPLIER = 0.01           # drone_risk.py:307,353: constraint rows are scaled by 0.01
     SLACK_PENALTY = 10000.0     # :389-390
@@ -384,6 +404,19 @@ class Model:
 
     monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
     monte_carlo_var = staticmethod(stats.monte_carlo_var)
+
+
+class StepGraph:
+    """A captured device step (see Model.capture_step)."""
+
+    def __init__(self, graph, us, out, stats_out):
+        self.graph, self.us, self.out, self.stats = graph, us, out, stats_out
+
+    def replay(self, us_mat=None):
+        if us_mat is not None:
+            self.us.copy_(torch.as_tensor(np.asarray(us_mat), dtype=torch.float32), non_blocking=True)
+        self.graph.replay()
+        return self.out, self.stats
 
 
 def L2_error_us(us_mat, us_mat_prev):

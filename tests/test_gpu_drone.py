@@ -203,3 +203,48 @@ def test_full_size_C2_properties():
             acc[3 + a, a::3] += Phi[:, S, a, :, 1].sum(0)
     np.testing.assert_allclose(d.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M), acc / M,
                                rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)
+
+
+def test_captured_step_graph_matches_eager():
+    import torch
+    from riskaversetrajopt_amd import stats
+    from riskaversetrajopt_amd.drone_risk import untile
+    S, M = 50, 3000
+    _, d = _models(S, M)
+    step = d.capture_step(alpha=0.1)
+    for scale in (1.0, 0.6):
+        us = graze(S) * scale
+        out, st = step.replay(us)
+        torch.cuda.synchronize()
+        eager = d.linearize_device(us)
+        assert bool((untile(out["G"], M) == untile(eager["G"], M)).all())
+        assert bool((out["g_up"] == eager["g_up"]).all()) and bool((out["Z"] == eager["Z"]).all())
+        np.testing.assert_array_equal(out["sums"].cpu().numpy(), eager["sums"].cpu().numpy())
+        ref = stats.risk_stats_device(eager["Z"], 0.1).cpu().numpy()
+        np.testing.assert_array_equal(st.cpu().numpy(), ref)
+
+
+def test_bad_arguments_are_rejected_not_computed():
+    import ctypes as C
+    import torch
+    from riskaversetrajopt_amd import _lib, drone_risk
+    _, d = _models(20, 8)
+    with pytest.raises(ValueError):
+        d.eval_device(np.zeros((19, 3)))                        # wrong horizon
+    with pytest.raises(_lib.RatoError):
+        d.linearize_device(graze(20), cols_per_thread=5)        # no such kernel variant
+    with pytest.raises(_lib.RatoError):
+        drone_risk.Model.from_device(20, torch.zeros((20, 3, 8), dtype=torch.float64, device="cuda"),
+                                     torch.ones(8, device="cuda"), torch.zeros((3, 3, 8), device="cuda"))
+    lib = _lib.load()
+    p = d._params(0, 8)                                         # M = 0: empty batch is an error, not a no-op
+    z = torch.zeros(8, device="cuda")
+    rc = lib.rato_drone_eval(C.byref(p), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, None,
+                             _lib.current_stream())
+    assert rc == -1
+    p = d._params(8, 4)                                         # ld < M
+    assert lib.rato_drone_eval(C.byref(p), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None,
+                               None, _lib.current_stream()) == -1
+    p = d._params(8, 8)
+    assert lib.rato_drone_eval(C.byref(p), None, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, None,
+                               _lib.current_stream()) == -1     # null input pointer
