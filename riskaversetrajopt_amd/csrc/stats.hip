@@ -85,10 +85,11 @@ __device__ __forceinline__ float value_of(unsigned k) {
 
 // Whole block: find the bin containing ascending rank k in hist[0..NB) and the
 // rank remaining inside that bin.  Result is returned to every thread.
-template <int NB>
+template <int NB, int NT = RATO_BLOCK>
 __device__ void find_bin(const unsigned* __restrict__ hist, unsigned k, unsigned& bin, unsigned& krem) {
-  constexpr int PER = NB / RATO_BLOCK;
-  __shared__ unsigned wsum[RATO_BLOCK / RATO_WAVE];
+  constexpr int PER = NB / NT;
+  static_assert(PER >= 1 && PER * NT == NB, "bins must divide evenly over the threads");
+  __shared__ unsigned wsum[NT / RATO_WAVE];
   __shared__ unsigned res[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned local[PER], tot = 0;
@@ -262,6 +263,84 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
   out[7] = (double)k;
 }
 
+// ---- single-workgroup form for small M (<= RS_SINGLE_MAX): the whole selection in ONE launch (Z is a few tens of
+// KB and L2-resident; five ~5 us launches become one ~10 us launch).  Same arithmetic, fixed reduction order.
+constexpr int RS1_T = 1024;
+constexpr long RS_SINGLE_MAX = 1 << 14;  // measured: at M = 1e5 one workgroup (LDS atomic contention) is slower than 5 launches
+
+__device__ __forceinline__ double block_sum_1024(double v, double* red) {
+  v = rato::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int w = 0; w < RS1_T / RATO_WAVE; ++w) s += red[w];   // fixed order, every thread computes the same
+  return s;
+}
+
+__global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, long M, double alpha, unsigned k,
+                                                   int var_is_max, float thr, double* __restrict__ out) {
+  __shared__ unsigned h[B1];
+  __shared__ double red[RS1_T / RATO_WAVE];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  double sum = 0.0, cnt = 0.0;
+  float mx = -INFINITY;
+  for (long i = tid; i < M; i += RS1_T) {
+    const float z = Z[i];
+    atomicAdd(&h[key_of(z) >> 21], 1u);
+    sum += (double)z;
+    cnt += (z <= thr) ? 1.0 : 0.0;
+    mx = fmaxf(mx, z);
+  }
+  __syncthreads();
+  unsigned b1, k1, b2, k2, b3, k3;
+  find_bin<B1, RS1_T>(h, k, b1, k1);
+  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  for (long i = tid; i < M; i += RS1_T) {
+    const unsigned key = key_of(Z[i]);
+    if ((key >> 21) == b1) atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u);
+  }
+  __syncthreads();
+  find_bin<B2, RS1_T>(h, k1, b2, k2);
+  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  const unsigned prefix = (b1 << 11) | b2;
+  for (long i = tid; i < M; i += RS1_T) {
+    const unsigned key = key_of(Z[i]);
+    if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
+  }
+  __syncthreads();
+  find_bin<B3, RS1_T>(h, k2, b3, k3);
+  const float t = value_of((b1 << 21) | (b2 << 10) | b3);
+  double tail = 0.0;
+  for (long i = tid; i < M; i += RS1_T) {
+    const float z = Z[i];
+    tail += (z > t) ? ((double)z - (double)t) : 0.0;
+  }
+  const double S = block_sum_1024(sum, red);
+  const double C = block_sum_1024(cnt, red);
+  const double T = block_sum_1024(tail, red);
+  mx = rato::wave_max(mx);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = (double)mx;
+  __syncthreads();
+  if (tid == 0) {
+    double m = -INFINITY;
+    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) m = fmax(m, red[w]);
+    out[0] = var_is_max ? m : (double)t;
+    out[1] = (double)t + (T / (double)M) / alpha;
+    out[2] = C / (double)M;
+    out[3] = S / (double)M;
+    out[4] = m;
+    out[5] = C;
+    out[6] = T;
+    out[7] = (double)k;
+  }
+}
+
 }  // namespace
 
 extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale, double* out,
@@ -306,6 +385,11 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
   const unsigned k = (unsigned)kk;
   Workspace* ws = static_cast<Workspace*>(workspace);
   hipStream_t st = rato::as_stream(stream);
+  if (M <= RS_SINGLE_MAX) {
+    hipLaunchKernelGGL(rs_single, dim3(1), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
+  }
   long nb = (M + RATO_BLOCK * 4 - 1) / (RATO_BLOCK * 4);
   if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
   if (nb < 1) nb = 1;
