@@ -209,6 +209,23 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
                      float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
                      void* stream);
 
+/* --------------------------------------------------------------- assembly */
+
+/*
+ * Device side of the sparse QP assembly (replaces the dense packing loop of
+ * drone_risk.py:339-364 / driving.py:344-363 and the dense->csr scan of :419).
+ * Emits the linearized-constraint block of the CSC value array in the
+ * reference's order: for s = 0..S-2, for g = 0..n_g-1 (u-column s*n_u + g), for
+ * sample i, for row-group r (obstacle), for t = s+1..S-1:
+ *     out[...] = scale * d row(r,t) / d u[s,g]
+ * i.e. column (s,g) occupies M*R*(S-1-s) consecutive values.  G is the packed
+ * tile-blocked Jacobian of the linearize calls (tile = its TILE, n_g = 2,
+ * R = 3 drone / 1 driving).  scale = the reference's MULTIPLIER (0.01 drone, 1
+ * driving), times 1e-7 while scp_iter < 2 (drone_risk.py:413-415).
+ */
+int rato_emit_csc_values(const float* G, int32_t tile, int32_t n_g, int32_t R, int32_t S, int64_t M,
+                         float scale, float* out, void* stream);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,

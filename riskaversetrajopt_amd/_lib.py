@@ -38,6 +38,8 @@ SIGNATURES = {
     "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
+    "rato_emit_csc_values": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
+                                       c_float_p, c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -145,3 +145,68 @@ def objective(n_u, S, M, dt, R, slack_penalty):
     P = P.tocsc()
     P.eliminate_zeros()
     return P, q
+
+
+class FastAssembler:
+    """Per-iteration assembly with a cached sparsity pattern and the device-emitted value block.
+
+    The pattern of A is iteration invariant (the reference relies on it: ``update(Ax=A.data)``,
+    drone_risk.py:451), so it is taken once from a host-assembled matrix; afterwards an iteration only
+    moves the nnz(G) values that ``rato_emit_csc_values`` already wrote in CSC order, the few
+    final-constraint entries and the bounds.  Entries that are structurally present but happen to be
+    exactly 0.0 in a later iterate stay as explicit zeros (the reference would drop them; OSQP does not
+    care).  If the first matrix lacks a structural entry (an exact zero was dropped) the fast path is
+    declined and the caller keeps using the host assembler.
+    """
+
+    def __init__(self, A0, l0, u0, *, n_c, n_u, n_g, R, S, M, saa):
+        A0 = A0.tocsc()
+        A0.sort_indices()
+        self.shape = A0.shape
+        self.indptr, self.indices = A0.indptr.copy(), A0.indices.copy()
+        self.base = A0.data.copy()                       # constants (CVaR rows, identity); rest overwritten
+        self.l0, self.u0 = l0.copy(), u0.copy()
+        self.n_c, self.S, self.M, self.R, self.n_u, self.n_g = n_c, S, M, R, n_u, n_g
+        R_s = R * S
+        n_head = (1 + M) if saa else 0
+        self.obs0 = n_c + n_head
+        self.obs1 = self.obs0 + M * R_s
+        self.ok = True
+        # obstacle block: data positions in emission order (column (s,g) -> [i][r][t>s])
+        pos = []
+        for s in range(S - 1):
+            for g in range(n_g):
+                c = s * n_u + g
+                lo, hi = self.indptr[c], self.indptr[c + 1]
+                rows = self.indices[lo:hi]
+                a, b = lo + np.searchsorted(rows, self.obs0), lo + np.searchsorted(rows, self.obs1)
+                if b - a != M * R * (S - 1 - s):
+                    self.ok = False
+                    return
+                pos.append(np.arange(a, b, dtype=np.int64))
+        self.G_pos = np.concatenate(pos) if pos else np.zeros(0, np.int64)
+        # final-constraint entries
+        self.fin_pos = np.nonzero(self.indices < n_c)[0]
+        self.fin_row = self.indices[self.fin_pos]
+        self.fin_col = np.searchsorted(self.indptr, self.fin_pos, side='right') - 1
+
+    def assemble(self, G_vals, final_du, final_rhs, g_up_irt, *, kappa, baseline_pad, relax):
+        """G_vals: device-emitted values (already multiplied by kappa * relax factor), host ndarray;
+        g_up_irt: (M, R, S) host array.  -> (A csc, l, u)."""
+        data = self.base.copy()
+        l, u = self.l0.copy(), self.u0.copy()
+        data[self.G_pos] = G_vals
+        data[self.fin_pos] = np.asarray(final_du, dtype=np.float64)[self.fin_row, self.fin_col]
+        l[:self.n_c] = final_rhs
+        u[:self.n_c] = final_rhs
+        u[self.obs0:self.obs1] = kappa * np.asarray(g_up_irt, dtype=np.float64).reshape(-1) - baseline_pad
+        if relax is not None:                      # ('scale', first_row, factor, lo, hi): drone_risk.py:413-417
+            first, factor = relax[1], relax[2]
+            n_As = self.shape[0] - self.n_u * self.S
+            sel = (self.indices >= first) & (self.indices < n_As)
+            sel[self.G_pos] = False                # the emitted block already carries the factor
+            data[sel] *= factor
+            l[first:n_As] = relax[3]
+            u[first:n_As] = relax[4]
+        A = sp.csc_matrix((data, self.indices, self.indptr), shape=self.shape)
+        return A, l, u

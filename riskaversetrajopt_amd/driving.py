@@ -265,8 +265,28 @@ class Model:
         there are only 4 final rows, so the CVaR sum row and the first three -y_i rows survive
         (:411-415); the reference's ``ls *= 0`` turns -inf into nan there, which OSQP's projection
         treats like the l = u = 0 used here."""
-        relax = ('zero', n_x) if scp_iter < 1 else None
-        return self._assemble(us_mat, relax)
+        if scp_iter < 1:                            # pattern differs (zeroed rows are dropped): host path
+            return self._assemble(us_mat, ('zero', n_x))
+        fast = getattr(self, "_fast", None)
+        if fast is None:
+            A0, l0, u0 = self._assemble(us_mat, None)
+            fast = assemble.FastAssembler(A0, l0, u0, n_c=4, n_u=n_u, n_g=2, R=1, S=self.S, M=self.M,
+                                          saa=self.method == 'saa')
+            self._fast = fast
+        if not fast.ok or self.S < 2:
+            return self._assemble(us_mat, None)
+        r = self.linearize_device(us_mat)
+        M, S = r["M"], self.S
+        vals = self._empty(M * S * (S - 1))
+        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), r["tile"], 2, 1, S, M, 1.0, _lib.ptr(vals),
+                                                  _lib.current_stream()), "rato_emit_csc_values")
+        g_up = r["g_up"].t().contiguous().double().cpu().numpy()[:, None, :]          # (M, 1, S)
+        return fast.assemble(vals.cpu().numpy(), r["final_du"].double().cpu().numpy(),
+                             r["final_rhs"].double().cpu().numpy(), g_up, kappa=1.0, baseline_pad=0.0, relax=None)
+
+    def get_constraints_coeffs_host(self, us_mat, scp_iter):
+        """Host (NumPy) assembly from the untiled Jacobian — the checker for the fast path."""
+        return self._assemble(us_mat, ('zero', n_x) if scp_iter < 1 else None)
 
     def get_all_constraints_coeffs_all(self, us_mat):
         """driving.py:301-373 -> dense (constraints_dparams, low, up) without the control bounds; small M only."""

@@ -341,12 +341,39 @@ class Model:
         """drone_risk.py:376-399 -> (P csc, q)."""
         return assemble.objective(n_u, self.S, self.M, self.dt, P.R, self.SLACK_PENALTY)
 
+    def get_constraints_coeffs_host(self, us_mat, scp_iter):
+        """Host (NumPy) assembly from the untiled Jacobian — the checker for the fast path."""
+        relax = ('scale', n_x, 1e-7, -0.1, 0.1) if scp_iter < 2 else None
+        return self._assemble(us_mat, relax)
+
     def get_constraints_coeffs(self, us_mat, scp_iter):
         """drone_risk.py:401-423 -> (A csc, l, u) with the reference's row/column order and
         dropped-zero pattern.  scp_iter < 2 relaxes every row after the n_x final rows
-        (A *= 1e-7, l = -0.1, u = 0.1, :413-417)."""
+        (A *= 1e-7, l = -0.1, u = 0.1, :413-417).
+
+        After the first call the sparsity pattern is cached and an iteration only moves the value block
+        that the device wrote in CSC order (rato_emit_csc_values)."""
         relax = ('scale', n_x, 1e-7, -0.1, 0.1) if scp_iter < 2 else None
-        return self._assemble(us_mat, relax)
+        fast = getattr(self, "_fast", None)
+        if fast is None:
+            A0, l0, u0 = self._assemble(us_mat, None)
+            saa = self.method == 'saa'
+            fast = assemble.FastAssembler(A0, l0, u0, n_c=n_x, n_u=n_u, n_g=2, R=n_obs, S=self.S, M=self.M, saa=saa)
+            self._fast = fast
+        if not fast.ok or self.S < 2:
+            return self._assemble(us_mat, relax)
+        r = self.linearize_device(us_mat)
+        M, S = r["M"], self.S
+        factor = relax[2] if relax is not None else 1.0
+        vals = self._empty(M * n_obs * S * (S - 1))
+        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), r["tile"], 2, n_obs, S, M,
+                                                  float(self.MULTIPLIER * factor), _lib.ptr(vals),
+                                                  _lib.current_stream()), "rato_emit_csc_values")
+        final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
+        final_rhs = r["rhs_sum"].cpu().numpy() / M
+        g_up = r["g_up"].permute(2, 0, 1).contiguous().double().cpu().numpy()       # (M, n_obs, S)
+        return fast.assemble(vals.cpu().numpy(), final_du, final_rhs, g_up, kappa=self.MULTIPLIER,
+                             baseline_pad=(1e-3 if self.method == 'baseline' else 0.0), relax=relax)
 
     def get_all_constraints_coeffs_all(self, us_mat):
         """drone_risk.py:282-374 -> dense (constraints_dparams, low, up) WITHOUT the control bounds;

@@ -163,12 +163,15 @@ class OSQP:
         if Px is not None:
             raise NotImplementedError("update(Px=...) is not used by the reference")
         if refactor or q is not None:
-            # values changed: recompute the scaling like a fresh setup (keeps the iterates for warm start)
-            x, y, z = self.x, self.y, self.z
-            self._scale()
+            # like osqp's update_A / update_lin_cost: keep the equilibration (D, E, c) computed at setup,
+            # re-apply it to the new values and refactorise; the iterates are kept for the warm start
+            self.As = sp.csc_matrix(sp.diags(self.E) @ self.A @ sp.diags(self.D))
+            self.qs = self.c * self.D * self.q
+            self.ls, self.us = self.l * self.E, self.u * self.E
+            self.ls[self.l <= -OSQP_INFTY] = -OSQP_INFTY
+            self.us[self.u >= OSQP_INFTY] = OSQP_INFTY
             self._make_rho_vec()
             self._factorize()
-            self.x, self.y, self.z = x, y, z
         else:
             self.ls, self.us = self.l * self.E, self.u * self.E
             self.ls[self.l <= -OSQP_INFTY] = -OSQP_INFTY

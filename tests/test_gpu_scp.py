@@ -96,3 +96,28 @@ def test_driving_scp_iterates_match_oracle_path():
     out = scp.run_driving(d, num_scp_iters_max=10)
     np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=2e-3)
     assert np.all(np.isfinite(out["define_s"])) and out["cumulative_s"][-1] > 0
+
+
+@pytest.mark.parametrize("method", ["saa", "baseline"])
+def test_device_emitted_csc_values_match_host_assembly(method):
+    """rato_emit_csc_values + cached pattern == host assembly (same pattern; values to fp32 rounding)."""
+    S, M = 20, 130
+    _, d = _drone(M, S, method=method)
+    for scp_iter, scale in ((0, 1.0), (2, 1.0), (5, 0.7)):
+        us = graze(S) * scale
+        A, l, u = d.get_constraints_coeffs(us, scp_iter)
+        Ah, lh, uh = d.get_constraints_coeffs_host(us, scp_iter)
+        assert np.array_equal(A.indptr, Ah.indptr) and np.array_equal(A.indices, Ah.indices)
+        np.testing.assert_allclose(A.data, Ah.data, rtol=3e-7, atol=1e-30)
+        np.testing.assert_allclose(l, lh, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(u, uh, rtol=3e-7, atol=1e-12)
+    assert d._fast.ok
+    _, c = _car(70, 20, method=method)
+    t = np.arange(20)[:, None]
+    us = np.hstack([0.4 * np.cos(0.4 * t) - 0.2, 0.05 * np.sin(0.35 * t) + 0.01])
+    for scp_iter in (0, 1, 3):
+        A, l, u = c.get_constraints_coeffs(us, scp_iter)
+        Ah, lh, uh = c.get_constraints_coeffs_host(us, scp_iter)
+        assert np.array_equal(A.indptr, Ah.indptr) and np.array_equal(A.indices, Ah.indices)
+        np.testing.assert_allclose(A.data, Ah.data, rtol=3e-7, atol=1e-30)
+        np.testing.assert_allclose(u, uh, rtol=3e-7, atol=1e-12)
