@@ -277,7 +277,7 @@ def main():
     M, S = work.M, work.S
     unit_steps = getattr(work, "C", S)        # hopper: the unit is a sample-contact
     ws_bytes = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(M * world), dtype=torch.uint8, device=device)
-    stats_out = torch.empty(8, dtype=torch.float64, device=device)
+    stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=device)
 
     def barrier():
         if dist.is_initialized():

@@ -226,6 +226,34 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
 int rato_emit_csc_values(const float* G, int32_t tile, int32_t n_g, int32_t R, int32_t S, int64_t M,
                          float scale, float* out, void* stream);
 
+/* ------------------------------------------- linearized CVaR constraint oracle */
+
+/*
+ * Eliminating the auxiliary y_i of the reference's QP (drone_risk.py:327-368:
+ * y_i >= -slack, y_i >= (G_i u - g_up_i)_r - t for every row r) leaves the single
+ * convex constraint  alpha*M*CVaR_alpha(m(u)) - (M*(1-alpha) - 1)*slack <= 0  with
+ *     m_i(u) = max_r [ (G_i u)_r - g_up_{i,r} ].
+ * These two calls are the device oracle a cutting-plane solve needs per cut
+ * (value: rato_risk_stats on m; subgradient: tail-weighted sum of arg-max rows).
+ *
+ * rato_saa_rowmax: one streaming read of the packed Jacobian G (layout of the
+ * linearize calls; tile = its TILE; R = 3 drone / 1 driving; rows of sample i
+ * indexed r*S + t):  m_out[i], arg_out[i] = max / arg-max (smallest row index on ties).
+ *   g_up [R][S][ld], us [S][n_u] (only controls 0 and 1 enter the rows).
+ */
+int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
+                    const float* g_up, const float* us, int32_t n_u,
+                    float* m_out, int32_t* arg_out, void* stream);
+
+/*
+ * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =
+ * sum over the block's samples of w_i * G_i[arg_i, (s,g)], with w_i = 1 if
+ * m_vals[i] > tstar, lambda if == tstar, 0 otherwise.  Reduce with rato_sum_partials.
+ */
+int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M,
+                       const float* m_vals, const int32_t* arg, float tstar, float lambda,
+                       float* part, void* stream);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,
@@ -247,8 +275,9 @@ size_t rato_risk_stats_workspace_bytes(int64_t M);
  * and AVaR/CVaR (drone_risk.py:663-695; the OSQP LP there is replaced by exact
  * selection of the Rockafellar-Uryasev minimiser followed by the closed form :694).
  *   Z [M]; thr = 1e-6 (the B_satisfied threshold)
- *   out: double[8] = { VaR, CVaR, fraction(Z<=thr), mean(Z), max(Z),
- *                      count(Z<=thr), sum(max(Z-VaR,0)), k (selected ascending rank) }
+ *   out: double[10] = { VaR, CVaR, fraction(Z<=thr), mean(Z), max(Z),
+ *                       count(Z<=thr), sum(max(Z-t,0)), k (selected ascending rank),
+ *                       #{Z > t}, #{Z == t} }   (t = the Rockafellar-Uryasev minimiser = VaR)
  */
 int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
                     void* workspace, size_t workspace_bytes, double* out, void* stream);

@@ -40,6 +40,10 @@ SIGNATURES = {
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
     "rato_emit_csc_values": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
                                        c_float_p, c_stream]),
+    "rato_saa_rowmax": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_float_p,
+                                  c_float_p, C.c_int32, c_float_p, c_float_p, c_stream]),
+    "rato_saa_tail_rows": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_float_p, c_float_p,
+                                     C.c_float, C.c_float, c_float_p, c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -1,0 +1,189 @@
+// Device oracle of the linearized CVaR constraint (gfx950) — what a cutting-plane solve of the SCP
+// subproblem needs per cut, computed where the packed Jacobian already lives (HBM):
+//
+//   m_i(u) = max_r [ (G_i u)_r - g_up_{i,r} ]       rato_saa_rowmax        (one streaming READ of G)
+//   sum_i mu_i G_i[r*_i, :]                          rato_saa_tail_rows     (reads only the arg-max rows)
+//
+// Eliminating the auxiliary y_i of the reference's QP (drone_risk.py:327-368: y_i >= -slack,
+// y_i >= (G_i u - g_up_i)_r - t) leaves  alpha M CVaR_alpha(m(u)) - (M(1-alpha) - 1) slack <= 0  in the
+// variables (u, slack) only; its value comes from rato_risk_stats on m and its subgradient is the
+// tail-weighted sum of arg-max rows.  Both kernels use the tile-blocked packed layout of rato_saa.h.
+#include "rato_common.h"
+
+namespace {
+
+constexpr int RM_NW = 8;        // waves per workgroup (64 samples)
+constexpr int RM_MAXR = 4;      // row groups (obstacles): drone 3, driving 1
+
+typedef float rfloat2_t __attribute__((ext_vector_type(2)));
+
+// grid = ceil(M/64) workgroups; rows t are pulled from an LDS queue, longest first.
+template <int R>
+__global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* __restrict__ G, int tileW, int S,
+                                                                   long M, long ld, const float* __restrict__ g_up,
+                                                                   const float* __restrict__ us, int n_u,
+                                                                   float* __restrict__ m_out,
+                                                                   int* __restrict__ arg_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rm_lds[];
+  rfloat2_t* US = reinterpret_cast<rfloat2_t*>(rm_lds);              // [S] (u_{s,0}, u_{s,1})
+  float* BV = reinterpret_cast<float*>(US + S);                      // [RM_NW][64] best value per wave
+  int* BI = reinterpret_cast<int*>(BV + RM_NW * 64);                 // [RM_NW][64] best row index
+  int* head = BI + RM_NW * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < S; i += RM_NW * RATO_WAVE) {
+    rfloat2_t u2;
+    u2.x = us[i * n_u + 0];
+    u2.y = us[i * n_u + 1];
+    US[i] = u2;
+  }
+  if (threadIdx.x == 0) *head = 0;
+  __syncthreads();
+  const long i0 = (long)blockIdx.x * 64;
+  const long m_raw = i0 + lane;
+  const bool valid = m_raw < M;
+  const long m = valid ? m_raw : M - 1;
+  const size_t n_pairs = (size_t)S * (S - 1) / 2;
+  const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * (n_pairs * 2 * R * tileW) + (i0 % tileW) + lane;
+  float best = -INFINITY;
+  int best_idx = 0;
+  auto next_task = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(head, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  int task = next_task();
+  while (task < S) {
+    const int t = S - 1 - task;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    const float* __restrict__ row = Gt + (size_t)rato::pair_row_offset(t) * (2 * R * tileW);
+#pragma unroll 4
+    for (int s2 = 0; s2 < t; ++s2) {
+      const rfloat2_t u2 = US[s2];
+      const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float g0 = valid ? o[r * tileW] : 0.0f;
+        const float g1 = valid ? o[(R + r) * tileW] : 0.0f;
+        acc[r] += g0 * u2.x + g1 * u2.y;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float v = acc[r] - g_up[((size_t)r * S + t) * ld + m];
+      if (v > best) {           // strict: ties keep the row found first (deterministic given the row)
+        best = v;
+        best_idx = r * S + t;
+      } else if (v == best && (r * S + t) < best_idx) {
+        best_idx = r * S + t;   // and the smallest row index among equal values, whichever wave saw it
+      }
+    }
+    task = next_task();
+  }
+  BV[wave * 64 + lane] = best;
+  BI[wave * 64 + lane] = best_idx;
+  __syncthreads();
+  if (wave == 0) {
+    float b = BV[lane];
+    int bi = BI[lane];
+    for (int w = 1; w < RM_NW; ++w) {
+      const float v = BV[w * 64 + lane];
+      const int vi = BI[w * 64 + lane];
+      if (v > b || (v == b && vi < bi)) {
+        b = v;
+        bi = vi;
+      }
+    }
+    if (valid) {
+      m_out[m] = b;
+      arg_out[m] = bi;
+    }
+  }
+}
+
+// grid = ceil(M/256) workgroups of 256 lanes (one sample each).  part[blk][s*2 + g] = sum over the block's
+// samples of weight_i * G_i[arg_i, (s,g)], weight = 1 for m_i > tstar, lambda for m_i == tstar, else 0.
+template <int R>
+__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __restrict__ G, int tileW, int S, long M,
+                                                               const float* __restrict__ mvals,
+                                                               const int* __restrict__ arg, float tstar,
+                                                               float lambda, float* __restrict__ part) {
+  extern __shared__ float tr_lds[];   // [4 waves][2*(S-1)]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = m < M;
+  float w = 0.0f;
+  int t = 0, r = 0;
+  if (valid) {
+    const float mv = mvals[m];
+    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+    const int a = arg[m];
+    r = a / S;
+    t = a - r * S;
+  }
+  const size_t n_pairs = (size_t)S * (S - 1) / 2;
+  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * R * tileW) + (m % tileW);
+  const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * R * tileW);
+  const int nw = 2 * (S - 1);
+  for (int s2 = 0; s2 < S - 1; ++s2) {
+    float g0 = 0.0f, g1 = 0.0f;
+    if (w != 0.0f && s2 < t) {
+      const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
+      g0 = w * o[r * tileW];
+      g1 = w * o[(R + r) * tileW];
+    }
+    const float s0 = rato::wave_sum_dpp(g0);
+    const float s1 = rato::wave_sum_dpp(g1);
+    if (lane == 0) {
+      tr_lds[wave * nw + s2 * 2 + 0] = s0;
+      tr_lds[wave * nw + s2 * 2 + 1] = s1;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nw; i += RATO_BLOCK) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += tr_lds[wv * nw + i];
+    part[(size_t)blockIdx.x * nw + i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
+                               const float* g_up, const float* us, int32_t n_u, float* m_out, int32_t* arg_out,
+                               void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!G || !g_up || !us || !m_out || !arg_out || M <= 0 || S < 1 || ld < M || n_u < 2 || (tile != 64 && tile != 256) ||
+      (R != 1 && R != 3))
+    return RATO_EINVAL;
+  const size_t lds = (size_t)S * 8 + RM_NW * 64 * 8 + 16;
+  if (lds > 64 * 1024) return RATO_EINVAL;
+  dim3 grid((unsigned)((M + 63) / 64)), block(RM_NW * RATO_WAVE);
+  hipStream_t st = rato::as_stream(stream);
+  if (R == 3)
+    hipLaunchKernelGGL(rowmax_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, (long)ld, g_up, us, n_u, m_out,
+                       arg_out);
+  else
+    hipLaunchKernelGGL(rowmax_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, (long)ld, g_up, us, n_u, m_out,
+                       arg_out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, const float* m_vals,
+                                  const int32_t* arg, float tstar, float lambda, float* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!G || !m_vals || !arg || !part || M <= 0 || S < 2 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
+    return RATO_EINVAL;
+  const size_t lds = (size_t)(RATO_BLOCK / 64) * 2 * (S - 1) * sizeof(float);
+  dim3 grid((unsigned)rato::nblocks_for((int32_t)M)), block(RATO_BLOCK);
+  hipStream_t st = rato::as_stream(stream);
+  if (R == 3)
+    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda, part);
+  else
+    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda, part);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}

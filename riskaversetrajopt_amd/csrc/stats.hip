@@ -68,7 +68,7 @@ struct Workspace {
   unsigned hist1[B1];
   unsigned hist2[B2];
   unsigned hist3[B3];
-  double blockpart[RS_MAX_BLOCKS][4];  // sum Z, count(Z<=thr), max Z, tail sum
+  double blockpart[RS_MAX_BLOCKS][6];  // sum Z, count(Z<=thr), max Z, tail sum, count(Z>t), count(Z==t)
   float tstar;
   unsigned nblocks;
 };
@@ -211,24 +211,38 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_pass3(const float* __restrict__
 
 __global__ __launch_bounds__(RATO_BLOCK) void rs_tail(const float* __restrict__ Z, long M, unsigned k,
                                                       Workspace* __restrict__ ws) {
-  __shared__ double red[RATO_BLOCK / RATO_WAVE];
+  __shared__ double red[3][RATO_BLOCK / RATO_WAVE];
   unsigned b1, k1, b2, k2, b3, k3;
   find_bin<B1>(ws->hist1, k, b1, k1);
   find_bin<B2>(ws->hist2, k1, b2, k2);
   find_bin<B3>(ws->hist3, k2, b3, k3);
   const float t = value_of((b1 << 21) | (b2 << 10) | b3);
-  double tail = 0.0;
+  double tail = 0.0, ngt = 0.0, neq = 0.0;
   for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < M; i += (long)gridDim.x * RATO_BLOCK) {
     const float z = Z[i];
     tail += (z > t) ? ((double)z - (double)t) : 0.0;
+    ngt += (z > t) ? 1.0 : 0.0;
+    neq += (z == t) ? 1.0 : 0.0;
   }
   tail = rato::wave_sum(tail);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tail;
+  ngt = rato::wave_sum(ngt);
+  neq = rato::wave_sum(neq);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = tail;
+    red[1][threadIdx.x >> 6] = ngt;
+    red[2][threadIdx.x >> 6] = neq;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0;
-    for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) s += red[w];
+    double s = 0, g = 0, e = 0;
+    for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) {
+      s += red[0][w];
+      g += red[1][w];
+      e += red[2][w];
+    }
     ws->blockpart[blockIdx.x][3] = s;
+    ws->blockpart[blockIdx.x][4] = g;
+    ws->blockpart[blockIdx.x][5] = e;
     if (blockIdx.x == 0) ws->tstar = t;
   }
 }
@@ -237,16 +251,20 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
                                                        const Workspace* __restrict__ ws, double* __restrict__ out) {
   // one wave: lane i folds blocks i, i+64, ... in order, then a fixed shuffle tree (deterministic)
   const int lane = threadIdx.x;
-  double s = 0, c = 0, m = -INFINITY, tail = 0;
+  double s = 0, c = 0, m = -INFINITY, tail = 0, ngt = 0, neq = 0;
   for (int b = lane; b < nblocks; b += RATO_WAVE) {
     s += ws->blockpart[b][0];
     c += ws->blockpart[b][1];
     m = fmax(m, ws->blockpart[b][2]);
     tail += ws->blockpart[b][3];
+    ngt += ws->blockpart[b][4];
+    neq += ws->blockpart[b][5];
   }
   s = rato::wave_sum(s);
   c = rato::wave_sum(c);
   tail = rato::wave_sum(tail);
+  ngt = rato::wave_sum(ngt);
+  neq = rato::wave_sum(neq);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, RATO_WAVE));
   if (lane != 0) return;
@@ -261,6 +279,8 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
   out[5] = c;
   out[6] = tail;
   out[7] = (double)k;
+  out[8] = ngt;                                // #{Z > t}
+  out[9] = neq;                                // #{Z == t}
 }
 
 // ---- single-workgroup form for small M (<= RS_SINGLE_MAX): the whole selection in ONE launch (Z is a few tens of
@@ -315,14 +335,18 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
   __syncthreads();
   find_bin<B3, RS1_T>(h, k2, b3, k3);
   const float t = value_of((b1 << 21) | (b2 << 10) | b3);
-  double tail = 0.0;
+  double tail = 0.0, ngt = 0.0, neq = 0.0;
   for (long i = tid; i < M; i += RS1_T) {
     const float z = Z[i];
     tail += (z > t) ? ((double)z - (double)t) : 0.0;
+    ngt += (z > t) ? 1.0 : 0.0;
+    neq += (z == t) ? 1.0 : 0.0;
   }
   const double S = block_sum_1024(sum, red);
   const double C = block_sum_1024(cnt, red);
   const double T = block_sum_1024(tail, red);
+  const double NG = block_sum_1024(ngt, red);
+  const double NE = block_sum_1024(neq, red);
   mx = rato::wave_max(mx);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = (double)mx;
@@ -338,6 +362,8 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
     out[5] = C;
     out[6] = T;
     out[7] = (double)k;
+    out[8] = NG;
+    out[9] = NE;
   }
 }
 

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, assemble, qp, stats
+from . import _lib, assemble, cvar_cuts, qp, stats
 from . import drone_params as P
 
 n_x, n_u, n_obs = P.n_x, P.n_u, P.n_obs
@@ -302,12 +302,12 @@ class Model:
         """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
         only the capture/replay plumbing; the nodes are this library's kernels).  Returns a
         ``StepGraph``: write the controls into ``.us`` (device tensor, (S, n_u)), call ``.replay()``
-        and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[8], rato_saa.h)."""
+        and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[10], rato_saa.h)."""
         alpha = self.alpha if alpha is None else alpha
         us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
         out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane)
         ws = torch.empty(self._lib.rato_risk_stats_workspace_bytes(out["M"]), dtype=torch.uint8, device=self.device)
-        st = torch.empty(8, dtype=torch.float64, device=self.device)
+        st = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
         stats.risk_stats_device(out["Z"], alpha, workspace=ws, out=st)         # warm-up: uncaptured first call
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -412,6 +412,29 @@ class Model:
             print("y_min =", np.min(ys))
             print("slack_var =", self.res.x[-2])
         return us_sol, t_risk_sol
+
+    # ---- L4 at large M: reduced (u, slack) problem with device CVaR cuts ----------------------
+    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False):
+        """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
+        y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
+        planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
+        Same optimum as define/update_problem + solve; -> (us_sol (S,n_u), t_risk, info)."""
+        if self.method != 'saa':
+            raise NotImplementedError("the reduced solve covers the 'saa' method")
+        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None))
+        self._lin_buffers = r
+        M, S = r["M"], self.S
+        cs = getattr(self, "_cut_solver", None)
+        if cs is None:
+            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=r["_g_up"].shape[-1],
+                                         R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
+                                         slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max)
+            self._cut_solver = cs
+        final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
+        final_rhs = r["rhs_sum"].cpu().numpy() / M
+        info = cs.solve(r["G"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2), tol=tol,
+                        verbose=verbose)
+        return info["us"], info["t_risk"], info
 
     # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------
     def monte_carlo_cost(self, us_mat):

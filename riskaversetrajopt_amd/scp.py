@@ -55,6 +55,34 @@ def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False):
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
 
 
+def run_drone_reduced(model, num_scp_iters_max=60, verbose=False):
+    """The drone SCP loop (drone_risk.py:519-532) with every subproblem solved through
+    ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
+    "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop."""
+    us_prev = model.initial_guess_us_mat()
+    define_s, solve_s, err, cuts, oracle_s = [], [], [], [], []
+    t_risk = None
+    for scp_iter in range(num_scp_iters_max):
+        _sync()
+        t0 = time.perf_counter()
+        us, t_risk, info = model.solve_reduced(us_prev, scp_iter)
+        _sync()
+        dt_total = time.perf_counter() - t0
+        solve_s.append(info["oracle_s"] + info["master_s"])
+        define_s.append(dt_total - solve_s[-1])
+        oracle_s.append(info["oracle_s"])
+        cuts.append(info["cuts"])
+        err.append(L2_error_us(us, us_prev))
+        us_prev = us
+        if verbose:
+            print(f"scp {scp_iter:3d}  define {define_s[-1]:.4f}s  solve {solve_s[-1]:.4f}s "
+                  f"({info['cuts']} cuts, oracle {info['oracle_s']:.4f}s)  L2 {err[-1]:.3e}")
+    define_s, solve_s = np.array(define_s), np.array(solve_s)
+    return {"us": us_prev, "t_risk": t_risk, "define_s": define_s, "solve_s": solve_s,
+            "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err), "cuts": np.array(cuts),
+            "oracle_s": np.array(oracle_s)}
+
+
 def run_driving(model, num_scp_iters_max=15, verbose=False):
     """driving.py:474-513: two warm-up solves (scp_iter 0 and 1), restart, then a fixed number of
     define_problem/solve iterations (define re-sets the solver up at iterations 0 and 1)."""

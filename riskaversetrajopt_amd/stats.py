@@ -10,7 +10,9 @@ from . import _lib
 
 SATISFIED_THRESHOLD = 1e-6   # ``B_satisfied = max_constraint <= 1e-6`` (drone_risk.py:661)
 
-_STAT_NAMES = ("var", "cvar", "frac_satisfied", "mean", "max", "count_satisfied", "tail_sum", "rank")
+_STAT_NAMES = ("var", "cvar", "frac_satisfied", "mean", "max", "count_satisfied", "tail_sum", "rank",
+               "count_above_var", "count_at_var")
+N_STATS = len(_STAT_NAMES)
 
 
 def _as_device_f32(Z, device=None):
@@ -22,7 +24,7 @@ def _as_device_f32(Z, device=None):
 
 
 def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None):
-    """Z: device tensor (M,) fp32 -> device tensor double[8] (see rato_saa.h).
+    """Z: device tensor (M,) fp32 -> device tensor double[10] (see rato_saa.h).
     Asynchronous on the current stream."""
     lib = _lib.load()
     Z = _as_device_f32(Z)
@@ -31,7 +33,7 @@ def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=Non
     if workspace is None:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=Z.device)
     if out is None:
-        out = torch.empty(8, dtype=torch.float64, device=Z.device)
+        out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
     _lib.check(lib.rato_risk_stats(_lib.ptr(Z), M, float(alpha), float(thr), _lib.ptr(workspace),
                                    workspace.numel(), _lib.ptr(out), _lib.current_stream()),
                "rato_risk_stats")

@@ -121,3 +121,61 @@ def test_device_emitted_csc_values_match_host_assembly(method):
         assert np.array_equal(A.indptr, Ah.indptr) and np.array_equal(A.indices, Ah.indices)
         np.testing.assert_allclose(A.data, Ah.data, rtol=3e-7, atol=1e-30)
         np.testing.assert_allclose(u, uh, rtol=3e-7, atol=1e-12)
+
+
+def test_reduced_cutting_plane_solve_equals_full_qp():
+    """Eliminating y_i / t and solving in (u, slack) by CVaR cuts gives the optimum of the reference's QP."""
+    S, M = 20, 40
+    _, d = _drone(M, S, alpha=0.2)
+    us_prev = graze(S) * 0.5
+    from riskaversetrajopt_amd import scp
+    # (a) at an arbitrary iterate: the reduced solution lifts to a FEASIBLE point of the reference's full QP
+    #     (y_i = max(-slack, m_i - t), t = VaR + slack) with the same objective -> it is the full QP's optimum,
+    #     because the master only ever holds valid cuts (outer approximation).
+    A, l, u = d.get_constraints_coeffs(us_prev, 2)
+    Pm, q = d.get_objective_coeffs()
+    us_red, t_red, info = d.solve_reduced(us_prev, 2)
+    assert info["cuts"] >= 1 and info["status"] == 'solved'
+    nU = 3 * S
+    rows = (A[7 + M:7 + M + M * 3 * S, :nU] @ us_red.reshape(-1) - u[7 + M:7 + M + M * 3 * S]) / 0.01   # (G_i u - g_up_i)_r
+    m_i = rows.reshape(M, 3 * S).max(axis=1)
+    y = np.maximum(-info["slack"], m_i - t_red)
+    z = np.concatenate([us_red.reshape(-1), y, [info["slack"], t_red]])
+    Az = A @ z
+    # tolerance: the device oracle evaluates m_i in fp32 (|m| reaches ~1e2), and the CVaR sum row adds M of them
+    tol_rows = np.full(A.shape[0], 2e-5)
+    tol_rows[6] = 1e-5 * M * max(1.0, np.abs(m_i).max())
+    assert np.all(Az <= u + tol_rows) and np.all(Az >= l - tol_rows), (np.max(Az - u), np.max(l - Az))
+    # (b) along the SCP path (where the full QP is well conditioned) both solves give the same iterate
+    start = scp.run_drone(d, num_scp_iters_max=4, warmup_iters=0)["us"]
+    d.update_problem(start, 4)
+    us_full, t_full = d.solve(verbose=False)
+    assert d.res.info.status == 'solved'
+    us_red2, t_red2, info2 = d.solve_reduced(start, 4)
+    np.testing.assert_allclose(us_red2, us_full, rtol=0, atol=5e-5)
+    assert abs(t_red2 - t_full) < 2e-4 and abs(info2["slack"] - d.res.x[-2]) < 1e-5
+    # scp_iter < 2: every CVaR row is relaxed away (drone_risk.py:413-417; y, t are then free and the full QP
+    # is degenerate), what remains is the minimum-effort control meeting the final constraints
+    us_red0, _, info0 = d.solve_reduced(us_prev, 0)
+    F, f = A[:6, :3 * S].toarray(), l[:6]
+    Pu = Pm[:3 * S, :3 * S].toarray()
+    K = np.block([[Pu, F.T], [F, np.zeros((6, 6))]])
+    sol = np.linalg.solve(K, np.concatenate([np.zeros(3 * S), f]))
+    assert info0["cuts"] == 0 and np.all(np.abs(sol[:3 * S]) < 10)
+    np.testing.assert_allclose(us_red0.reshape(-1), sol[:3 * S], rtol=0, atol=1e-6)
+
+
+def test_reduced_scp_matches_full_scp_and_scales():
+    from riskaversetrajopt_amd import scp
+    S, M = 20, 30
+    o, d = _drone(M, S, alpha=0.2)
+    full = scp.run_drone(d, num_scp_iters_max=15, warmup_iters=0)
+    _, d2 = _drone(M, S, alpha=0.2)
+    red = scp.run_drone_reduced(d2, num_scp_iters_max=15)
+    np.testing.assert_allclose(red["us"], full["us"], rtol=0, atol=2e-4)
+    # a batch no host QP could take (3e6 rows): the reduced path still converges
+    _, big = _drone(20000, S, alpha=0.1, seed=3)
+    out = scp.run_drone_reduced(big, num_scp_iters_max=8)
+    assert np.isfinite(out["us"]).all() and out["L2_error"][-1] < 0.05
+    st = big.monte_carlo_statistics(out["us"], alpha=0.1)
+    assert st["cvar"] < 0.1          # in-sample CVaR of the (nonlinear) constraint is near/below 0
