@@ -82,15 +82,17 @@ class CvarCutSolver:
         # box on u, slack >= 0  as  A_in z <= b_in
         box_A = np.vstack([np.eye(n)[:nU], -np.eye(n)[:nU], -np.eye(n)[nU:]])
         box_b = np.concatenate([np.full(nU, self.u_max), np.full(nU, -self.u_min), [0.0]])
-        cut_A, cut_b = [], []
         info = {"oracle_s": 0.0, "master_s": 0.0}
         phi = tstar = np.nan
         status = "solved"
+        n_cuts = 0
+        t0 = time.perf_counter()
+        master = dense_qp.Master(Pd, self.q, F, f)      # equality elimination + whitening once per SCP iteration
+        master.add_rows(box_A, box_b)
+        info["master_s"] += time.perf_counter() - t0
         for it in range(max_cuts + 1):
             t0 = time.perf_counter()
-            A_in = np.vstack([box_A] + cut_A) if cut_A else box_A
-            b_in = np.concatenate([box_b, cut_b]) if cut_b else box_b
-            z, _ = dense_qp.solve(Pd, self.q, F, f, A_in, b_in)
+            z, _ = master.solve()
             info["master_s"] += time.perf_counter() - t0
             u_vec, s = z[:nU], z[nU]
             if not with_cvar:
@@ -107,8 +109,8 @@ class CvarCutSolver:
                 status = "maximum cuts reached"
                 break
             # phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= g_k.u_k - phi_k
-            cut_A.append(np.concatenate([g, [-self.c_s]])[None, :])
-            cut_b.append(float(g @ u_vec - phi))
+            master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [float(g @ u_vec - phi)])
+            n_cuts += 1
         info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=float(tstar + s),
-                    cuts=len(cut_b), phi=float(phi), status=status)
+                    cuts=n_cuts, phi=float(phi), status=status)
         return info

@@ -55,3 +55,53 @@ def solve(P, q, A_eq, b_eq, A_in, b_in):
         lam = (y / (-r[-1])) / sc
     w = sla.solve_triangular(L.T, v - Linv_c, lower=False)
     return x0 + N @ w, lam
+
+
+class Master:
+    """The same solve with the equality elimination and the Cholesky whitening done ONCE, and inequality rows
+    appended incrementally (a cutting-plane loop adds one row per iteration)."""
+
+    def __init__(self, P, q, A_eq, b_eq):
+        P = np.asarray(P, dtype=np.float64)
+        q = np.asarray(q, dtype=np.float64)
+        n = q.shape[0]
+        if A_eq is not None and len(A_eq):
+            A_eq = np.asarray(A_eq, dtype=np.float64)
+            self.x0 = np.linalg.lstsq(A_eq, np.asarray(b_eq, dtype=np.float64), rcond=None)[0]
+            self.N = sla.null_space(A_eq)
+        else:
+            self.x0, self.N = np.zeros(n), np.eye(n)
+        H = self.N.T @ P @ self.N
+        c = self.N.T @ (P @ self.x0 + q)
+        self.L = np.linalg.cholesky(H)
+        self.Linv_c = sla.solve_triangular(self.L, c, lower=True)
+        self.NLinvT = sla.solve_triangular(self.L, self.N.T, lower=True).T      # N L^-T  (n x k)
+        self.G = np.zeros((0, self.N.shape[1]))
+        self.h = np.zeros(0)
+        self.sc = np.zeros(0)
+
+    def add_rows(self, A_in, b_in):
+        A_in = np.atleast_2d(np.asarray(A_in, dtype=np.float64))
+        b_in = np.atleast_1d(np.asarray(b_in, dtype=np.float64))
+        E = A_in @ self.NLinvT
+        f = b_in - A_in @ self.x0 + E @ self.Linv_c
+        sc = np.maximum(np.linalg.norm(E, axis=1), 1e-300)
+        self.G = np.vstack([self.G, -(E / sc[:, None])])
+        self.h = np.concatenate([self.h, -(f / sc)])
+        self.sc = np.concatenate([self.sc, sc])
+
+    def solve(self):
+        if self.G.shape[0] == 0:
+            v = np.zeros(self.N.shape[1])
+            lam = np.zeros(0)
+        else:
+            A_n = np.vstack([self.G.T, self.h[None, :]])
+            b_n = np.zeros(A_n.shape[0])
+            b_n[-1] = 1.0
+            y, _ = nnls(A_n, b_n, maxiter=20 * A_n.shape[1])
+            r = A_n @ y - b_n
+            if abs(r[-1]) < 1e-14:
+                raise InfeasibleError("master QP infeasible")
+            v = -r[:-1] / r[-1]
+            lam = (y / (-r[-1])) / self.sc
+        return self.x0 + self.NLinvT @ (v - self.Linv_c), lam

@@ -37,3 +37,25 @@ def test_matches_slsqp_and_satisfies_kkt(seed):
 def test_infeasible_master_is_reported():
     with pytest.raises(dense_qp.InfeasibleError):
         dense_qp.solve(np.eye(2), np.zeros(2), None, None, np.array([[1.0, 0.0], [-1.0, 0.0]]), np.array([-1.0, -1.0]))
+
+
+def test_incremental_master_equals_one_shot():
+    rng = np.random.RandomState(9)
+    n = 15
+    L = rng.randn(n, n)
+    P = L @ L.T + np.eye(n)
+    q = rng.randn(n)
+    A_eq = rng.randn(2, n)
+    xf = rng.randn(n)
+    b_eq = A_eq @ xf
+    A1, A2 = rng.randn(10, n), rng.randn(5, n)
+    b1, b2 = A1 @ xf + rng.rand(10), A2 @ xf + rng.rand(5)
+    m = dense_qp.Master(P, q, A_eq, b_eq)
+    m.add_rows(A1, b1)
+    x1, _ = m.solve()
+    np.testing.assert_allclose(x1, dense_qp.solve(P, q, A_eq, b_eq, A1, b1)[0], atol=1e-9)
+    m.add_rows(A2, b2)
+    x2, lam = m.solve()
+    np.testing.assert_allclose(x2, dense_qp.solve(P, q, A_eq, b_eq, np.vstack([A1, A2]), np.concatenate([b1, b2]))[0],
+                               atol=1e-9)
+    assert lam.shape == (15,) and np.all(lam >= 0)
