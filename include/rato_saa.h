@@ -249,10 +249,13 @@ int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t 
  * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =
  * sum over the block's samples of w_i * G_i[arg_i, (s,g)], with w_i = 1 if
  * m_vals[i] > tstar, lambda if == tstar, 0 otherwise.  Reduce with rato_sum_partials.
+ * If stats_dev != NULL (the device double[10] written by rato_risk_stats on m_vals), tstar and
+ * lambda = clamp((alphaM - #{m > t}) / #{m == t}, 0, 1) are taken from it on the device instead
+ * of from the arguments (no host round trip between the two calls).
  */
 int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M,
                        const float* m_vals, const int32_t* arg, float tstar, float lambda,
-                       float* part, void* stream);
+                       const double* stats_dev, double alphaM, float* part, void* stream);
 
 /* ------------------------------------------------------------- statistics */
 

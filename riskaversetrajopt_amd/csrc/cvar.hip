@@ -108,8 +108,15 @@ template <int R>
 __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __restrict__ G, int tileW, int S, long M,
                                                                const float* __restrict__ mvals,
                                                                const int* __restrict__ arg, float tstar,
-                                                               float lambda, float* __restrict__ part) {
+                                                               float lambda, const double* __restrict__ stats_dev,
+                                                               double alphaM, float* __restrict__ part) {
   extern __shared__ float tr_lds[];   // [4 waves][2*(S-1)]
+  if (stats_dev) {  // threshold and tie weight straight from rato_risk_stats' device output (no host round trip)
+    tstar = (float)stats_dev[0];
+    const double n_gt = stats_dev[8], n_eq = stats_dev[9];
+    double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
+    lambda = (float)fmin(fmax(l, 0.0), 1.0);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const bool valid = m < M;
@@ -173,7 +180,8 @@ extern "C" int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t 
 }
 
 extern "C" int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, const float* m_vals,
-                                  const int32_t* arg, float tstar, float lambda, float* part, void* stream) {
+                                  const int32_t* arg, float tstar, float lambda, const double* stats_dev,
+                                  double alphaM, float* part, void* stream) {
   RATO_CLEAR_ERROR();
   if (!G || !m_vals || !arg || !part || M <= 0 || S < 2 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
     return RATO_EINVAL;
@@ -181,9 +189,11 @@ extern "C" int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32
   dim3 grid((unsigned)rato::nblocks_for((int32_t)M)), block(RATO_BLOCK);
   hipStream_t st = rato::as_stream(stream);
   if (R == 3)
-    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda, part);
+    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda,
+                       stats_dev, alphaM, part);
   else
-    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda, part);
+    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda,
+                       stats_dev, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
