@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, assemble, qp, stats
+from . import _lib, assemble, cvar_cuts, qp, stats
 from . import driving_params as P
 
 n_x, n_u = P.n_x, P.n_u
@@ -320,6 +320,25 @@ class Model:
             print("y_min =", np.min(ys))
             print("slack_var =", self.res.x[-2])
         return us_sol, t_risk_sol
+
+    # ---- L4 at large M: reduced (u, slack) problem with device CVaR cuts ----------------------
+    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-7, verbose=False):
+        """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
+        scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint."""
+        if self.method != 'saa':
+            raise NotImplementedError("the reduced solve covers the 'saa' method")
+        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None))
+        self._lin_buffers = r
+        M, S = r["M"], self.S
+        cs = getattr(self, "_cut_solver", None)
+        if cs is None:
+            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=M, R=1, alpha=self.alpha,
+                                         dt=self.dt, Rcost=P.R, slack_penalty=self.SLACK_PENALTY,
+                                         u_min=self.u_min, u_max=self.u_max)
+            self._cut_solver = cs
+        info = cs.solve(r["G"], r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
+                        r["final_rhs"].double().cpu().numpy(), with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
+        return info["us"], info["t_risk"], info
 
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------
     def monte_carlo_cost(self, us_mat):

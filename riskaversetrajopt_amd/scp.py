@@ -56,7 +56,7 @@ def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False):
 
 
 def run_drone_reduced(model, num_scp_iters_max=60, verbose=False):
-    """The drone SCP loop (drone_risk.py:519-532) with every subproblem solved through
+    """The SCP loop (drone_risk.py:519-532; also used for driving, driving.py:486-513) with every subproblem solved through
     ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
     "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop."""
     us_prev = model.initial_guess_us_mat()
@@ -125,3 +125,8 @@ def load_results(path, n):
     """Read back ``n`` arrays written by ``save_results`` (sequential ``np.load``, drone_risk.py:704-708)."""
     with open(path, 'rb') as f:
         return [np.load(f) for _ in range(n)]
+
+
+def run_driving_reduced(model, num_scp_iters_max=15, verbose=False):
+    """driving.py:486-513 with ``Model.solve_reduced`` subproblems (same loop as run_drone_reduced)."""
+    return run_drone_reduced(model, num_scp_iters_max=num_scp_iters_max, verbose=verbose)

@@ -179,3 +179,19 @@ def test_reduced_scp_matches_full_scp_and_scales():
     assert np.isfinite(out["us"]).all() and out["L2_error"][-1] < 0.05
     st = big.monte_carlo_statistics(out["us"], alpha=0.1)
     assert st["cvar"] < 0.1          # in-sample CVaR of the (nonlinear) constraint is near/below 0
+
+
+def test_driving_reduced_scp_matches_full_scp():
+    from riskaversetrajopt_amd import scp
+    S, M = 20, 16
+    _, d = _car(M, S, alpha=0.1)
+    full = scp.run_driving(d, num_scp_iters_max=10)
+    _, d2 = _car(M, S, alpha=0.1)
+    red = scp.run_driving_reduced(d2, num_scp_iters_max=10)
+    np.testing.assert_allclose(red["us"], full["us"], rtol=0, atol=2e-3)
+    assert red["cuts"][0] == 0 and red["cuts"][1:].max() >= 1
+    _, big = _car(30000, S, alpha=0.05, seed=2)
+    out = scp.run_driving_reduced(big, num_scp_iters_max=6)
+    assert np.isfinite(out["us"]).all()
+    st = big.monte_carlo_statistics(out["us"], alpha=0.05)
+    assert st["cvar"] < 0.2
