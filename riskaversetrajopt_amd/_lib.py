@@ -57,7 +57,7 @@ class RatoError(RuntimeError):
 
 
 def lib_path():
-    # RATO_SAA_LIB: alternate build of the same ABI (diagnostic builds under scratch/)
+    # RATO_SAA_LIB: alternate build of the same ABI (diagnostic builds under tools/)
     return os.environ.get("RATO_SAA_LIB") or _build.LIB_PATH
 
 

@@ -438,7 +438,7 @@ constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 #ifndef RATO_DIAG
-#define RATO_DIAG 0  // diagnostic builds only (scratch/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores
+#define RATO_DIAG 0  // diagnostic builds only (tools/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores
 #endif
 
 __host__ __device__ inline size_t rows_lds_floats(int S) {

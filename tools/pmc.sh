@@ -6,4 +6,4 @@ while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1
-python3 $GRAFT_REPO_ROOT/scratch/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/$out
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/$out
