@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--cols-per-thread", type=int, default=0, help="0 auto; -1 row-parallel kernel (drone)")
     ap.add_argument("--samples-per-lane", type=int, default=0)
+    ap.add_argument("--packed-products", action="store_true",
+                    help="drone linearize: write the Jacobian as products (3S(S-1) numbers per sample, SURVEY 8d) "
+                         "instead of the default factored form W[j,t,a] * Phi[t,s,a] (S(S-1) + 6S numbers)")
     ap.add_argument("--graph", action="store_true",
                     help="drone linearize, N=1: replay the step as ONE captured hipGraph (kernel time then comes "
                          "from an eager pre-pass with HIP events, since events cannot bracket a node inside a graph)")
@@ -73,14 +76,18 @@ class DroneWork:
         self.M = args.M or 100000
         self.mode = args.mode
         self.cpt, self.spl = args.cols_per_thread, args.samples_per_lane
+        self.fact = False if args.packed_products else None                   # None: the kernel's default
         dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
         self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M)
         self.us = self.model._us_device(graze_us(self.S, 3))
         self.out = None
         if self.mode == "linearize":
-            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl)
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
+                                            factored=self.fact)
             self.out = r                                                       # buffers are reused every step
-            self.variant = "cols_per_thread=%d samples_per_lane=%d" % (r["cols_per_thread"], r["samples_per_lane"])
+            self.fact = r["factored"]
+            self.variant = "cols_per_thread=%d samples_per_lane=%d jacobian=%s" % (
+                r["cols_per_thread"], r["samples_per_lane"], "factored(W,Phi)" if self.fact else "products")
             self.kernel = "drone_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "drone_linearize_kernel"
         else:
             self.kernel = "drone_eval_kernel"
@@ -89,7 +96,7 @@ class DroneWork:
         """One pass; ``events`` bracket ONLY the dominant kernel's launch."""
         if self.mode == "linearize":
             return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
-                                               out=self.out, events=events)
+                                               out=self.out, events=events, factored=self.fact)
         if events is not None:
             events[0].record()
         Z, _, _ = self.model.eval_device(self.us)
@@ -109,7 +116,10 @@ class DroneWork:
         if self.mode == "eval":
             return eval_in
         nblk = (M + 255) // 256
-        return eval_in + M * B * (3 * S + 3 * S * (S - 1)) + nblk * (6 * S + 6) * B   # g_up, G nnz | partials
+        # Jacobian as written: products (3S(S-1) numbers per sample) or its two factors
+        # Phi[t,s,a] (S(S-1)) and W[j,t,a] (6S) -- the bytes the launch really has to move
+        jac = (S * (S - 1) + 6 * S) if self.fact else 3 * S * (S - 1)
+        return eval_in + M * B * (3 * S + jac) + nblk * (6 * S + 6) * B       # g_up, Jacobian | partials
 
     def cpu_baseline(self, n, alpha):
         """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples; dense outputs in the
@@ -249,12 +259,14 @@ WORKLOADS = {"drone": DroneWork, "driving": DrivingWork, "hopper": HopperWork}
 CPU_SAMPLES = {"drone": 8000, "driving": 3000, "hopper": 50000}
 
 
-def pmc_traffic(workload, mode, M, S):
-    """HBM bytes per launch from the committed PMC profile, if one matches."""
+def pmc_traffic(workload, mode, M, S, jacobian=None):
+    """HBM bytes per launch from the committed PMC profile, if one matches (``jacobian``: the drone linearize
+    output representation the profile was taken with)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         for rec in json.load(open(path)):
-            if (rec["workload"], rec["mode"], rec["M"], rec["S"]) == (workload, mode, M, S):
+            if (rec["workload"], rec["mode"], rec["M"], rec["S"]) == (workload, mode, M, S) \
+                    and rec.get("jacobian") == jacobian:
                 return rec["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -327,6 +339,9 @@ def main():
     if rank == 0:
         value = world * M * unit_steps * args.steps / elapsed
         alg = work.algorithmic_bytes()
+        jacobian = None
+        if args.workload == "drone" and args.mode == "linearize":
+            jacobian = "factored" if work.fact else "products"
         achieved = alg / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "SAA constraint-eval throughput",
@@ -346,7 +361,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "frac_of_measured_copy_6290": achieved / 6290.0,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
-                         "traffic": pmc_traffic(args.workload, args.mode, M, S)},
+                         "traffic": pmc_traffic(args.workload, args.mode, M, S, jacobian)},
             "stats": {"VaR": final_stats[0], "CVaR": final_stats[1], "frac_satisfied": final_stats[2]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -108,9 +108,14 @@ int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
  * Replaces vmap(Model.get_all_constraints_coeffs) (drone_risk.py:239-290) and
  * the per-block stage of the sample mean (:294-296).
  * outputs:
- *   G        [n_tiles][n_pairs][2 axes][3 obs][TILE]
+ *   G        W == NULL: [n_tiles][n_pairs][2 axes][3 obs][TILE]
  *                                         d g[j,t] / d u[s,axis] for s<t
  *                                         (the z-control column is identically 0)
+ *            W != NULL (factored, row-parallel kernel only):
+ *                       [n_tiles][n_pairs][2 axes][TILE]   Phi[t,s,axis] = d p_axis(t+1) / d u[s,axis]
+ *   W        NULL, or  [3 obs][S][2 axes][ld]              W[j,t,axis] = d g[j,t] / d p_axis(t+1),
+ *            so that d g[j,t]/d u[s,axis] = W[j,t,axis] * Phi[t,s,axis]: the three obstacles share
+ *            Phi, i.e. the same Jacobian in S(S-1) + 6S instead of 3S(S-1) numbers per sample.
  *   g_up     [3 obs][S][M]                -g + grad g . u   (:278)
  *   Z        [M] or NULL                  max_{j,t} g - tol at this iterate
  *   part     [nblocks][6*S + 6]           per-block sums (nblocks from rato_drone_linearize_plan):
@@ -121,7 +126,7 @@ int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
  */
 int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                          const float* mass, const float* Qsym,
-                         float* G, float* g_up, float* Z, float* part,
+                         float* G, float* W, float* g_up, float* Z, float* part,
                          int32_t cols_per_thread, int32_t samples_per_lane, void* stream);
 
 /* Model.obstacle_avoidance_constraints on given trajectories (drone_risk.py:198-213).
@@ -223,8 +228,9 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
  * R = 3 drone / 1 driving).  scale = the reference's MULTIPLIER (0.01 drone, 1
  * driving), times 1e-7 while scp_iter < 2 (drone_risk.py:413-415).
  */
-int rato_emit_csc_values(const float* G, int32_t tile, int32_t n_g, int32_t R, int32_t S, int64_t M,
-                         float scale, float* out, void* stream);
+int rato_emit_csc_values(const float* G, const float* W /* NULL, or the factor of a factored G */,
+                         int64_t ld /* row stride of W */, int32_t tile, int32_t n_g, int32_t R, int32_t S,
+                         int64_t M, float scale, float* out, void* stream);
 
 /* ------------------------------------------- linearized CVaR constraint oracle */
 
@@ -241,7 +247,8 @@ int rato_emit_csc_values(const float* G, int32_t tile, int32_t n_g, int32_t R, i
  * indexed r*S + t):  m_out[i], arg_out[i] = max / arg-max (smallest row index on ties).
  *   g_up [R][S][ld], us [S][n_u] (only controls 0 and 1 enter the rows).
  */
-int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
+int rato_saa_rowmax(const float* G, const float* W /* NULL, or the factor of a factored G (R = 3) */,
+                    int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
                     const float* g_up, const float* us, int32_t n_u,
                     float* m_out, int32_t* arg_out, void* stream);
 
@@ -253,7 +260,8 @@ int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t 
  * lambda = clamp((alphaM - #{m > t}) / #{m == t}, 0, 1) are taken from it on the device instead
  * of from the arguments (no host round trip between the two calls).
  */
-int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M,
+int rato_saa_tail_rows(const float* G, const float* W /* NULL or factor */, int64_t ld /* stride of W */,
+                       int32_t tile, int32_t R, int32_t S, int64_t M,
                        const float* m_vals, const int32_t* arg, float tstar, float lambda,
                        const double* stats_dev, double alphaM, float* part, void* stream);
 

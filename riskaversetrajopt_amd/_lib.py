@@ -30,7 +30,7 @@ SIGNATURES = {
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 8 + [C.c_int32, C.c_int32, c_stream]),
+    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [C.c_int32, C.c_int32, c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -38,12 +38,13 @@ SIGNATURES = {
     "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
-    "rato_emit_csc_values": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
-                                       c_float_p, c_stream]),
-    "rato_saa_rowmax": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_float_p,
-                                  c_float_p, C.c_int32, c_float_p, c_float_p, c_stream]),
-    "rato_saa_tail_rows": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, c_float_p, c_float_p,
-                                     C.c_float, C.c_float, c_float_p, C.c_double, c_float_p, c_stream]),
+    "rato_emit_csc_values": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int64, C.c_float, c_float_p, c_stream]),
+    "rato_saa_rowmax": (C.c_int, [c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                  c_float_p, c_float_p, C.c_int32, c_float_p, c_float_p, c_stream]),
+    "rato_saa_tail_rows": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                     c_float_p, c_float_p, C.c_float, C.c_float, c_float_p, C.c_double, c_float_p,
+                                     c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),

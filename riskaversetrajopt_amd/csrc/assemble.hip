@@ -11,8 +11,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __restrict__ G, int tileW, int n_g, int R,
-                                                              int S, long M, float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __restrict__ G,
+                                                              const float* __restrict__ W, long ld, int tileW, int n_g,
+                                                              int R, int S, long M, float scale,
+                                                              float* __restrict__ out) {
   extern __shared__ float lds[];
   const int s = blockIdx.y;                 // control step of this column pair
   const int nt = S - 1 - s;                 // rows t = s+1 .. S-1
@@ -21,7 +23,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __res
   const int nvalid = (int)((M - i0) < 64 ? (M - i0) : 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
-  const size_t tile_floats = n_pairs * n_g * R * tileW;
+  const bool fact = (W != nullptr);         // factored Jacobian: entry = W[r,t,g] * Phi[t,s,g]
+  const int RR = fact ? 1 : R;
+  const size_t tile_floats = n_pairs * n_g * RR * tileW;
   const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * tile_floats + (i0 % tileW) + lane;
   const long before = (long)s * (S - 1) - (long)s * (s - 1) / 2;      // sum_{s'<s} (S-1-s')
   for (int g = 0; g < n_g; ++g) {
@@ -29,7 +33,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __res
       const int r = row / nt, dtt = row - r * nt;                      // output index inside a sample: r*nt + (t-s-1)
       const int t = s + 1 + dtt;
       const size_t pair = (size_t)rato::pair_row_offset(t) + s;
-      const float v = (lane < nvalid) ? Gt[((pair * n_g + g) * R + r) * tileW] : 0.0f;
+      float v = 0.0f;
+      if (lane < nvalid) {
+        v = Gt[((pair * n_g + g) * RR + (fact ? 0 : r)) * tileW];
+        if (fact) v *= W[(((size_t)r * S + t) * n_g + g) * ld + i0 + lane];
+      }
       lds[lane * (L + 1) + row] = v * scale;
     }
     __syncthreads();
@@ -45,15 +53,15 @@ __global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int rato_emit_csc_values(const float* G, int32_t tile, int32_t n_g, int32_t R, int32_t S, int64_t M,
-                                    float scale, float* out, void* stream) {
+extern "C" int rato_emit_csc_values(const float* G, const float* W, int64_t ld, int32_t tile, int32_t n_g, int32_t R,
+                                    int32_t S, int64_t M, float scale, float* out, void* stream) {
   RATO_CLEAR_ERROR();
   if (!G || !out || M <= 0 || S < 2 || n_g <= 0 || R <= 0 || (tile != 64 && tile != 256)) return RATO_EINVAL;
   const size_t lds = (size_t)64 * ((size_t)R * (S - 1) + 1) * sizeof(float);
   if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 85 (drone) / 255 (car)
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)(S - 1)), block(RATO_BLOCK);
-  hipLaunchKernelGGL(emit_csc_kernel, grid, block, lds, rato::as_stream(stream), G, tile, n_g, R, S, (long)M, scale,
-                     out);
+  hipLaunchKernelGGL(emit_csc_kernel, grid, block, lds, rato::as_stream(stream), G, W, (long)ld, tile, n_g, R, S,
+                     (long)M, scale, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -18,8 +18,9 @@ constexpr int RM_MAXR = 4;      // row groups (obstacles): drone 3, driving 1
 typedef float rfloat2_t __attribute__((ext_vector_type(2)));
 
 // grid = ceil(M/64) workgroups; rows t are pulled from an LDS queue, longest first.
-template <int R>
-__global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* __restrict__ G, int tileW, int S,
+template <int R, bool FACT>
+__global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* __restrict__ G,
+                                                                   const float* __restrict__ W, int tileW, int S,
                                                                    long M, long ld, const float* __restrict__ g_up,
                                                                    const float* __restrict__ us, int n_u,
                                                                    float* __restrict__ m_out,
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
   const bool valid = m_raw < M;
   const long m = valid ? m_raw : M - 1;
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
-  const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * (n_pairs * 2 * R * tileW) + (i0 % tileW) + lane;
+  constexpr int RR = FACT ? 1 : R;   // row groups stored per (pair, control): factored keeps only Phi
+  const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * (n_pairs * 2 * RR * tileW) + (i0 % tileW) + lane;
   float best = -INFINITY;
   int best_idx = 0;
   auto next_task = [&]() -> int {
@@ -57,16 +59,30 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-    const float* __restrict__ row = Gt + (size_t)rato::pair_row_offset(t) * (2 * R * tileW);
-#pragma unroll 4
-    for (int s2 = 0; s2 < t; ++s2) {
-      const rfloat2_t u2 = US[s2];
-      const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
+    const float* __restrict__ row = Gt + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
+    if (FACT) {
+      float ax = 0.0f, ay = 0.0f;   // (Phi u) per axis, shared by the row groups
+#pragma unroll 8
+      for (int s2 = 0; s2 < t; ++s2) {
+        const rfloat2_t u2 = US[s2];
+        const float* __restrict__ o = row + (size_t)s2 * (2 * tileW);
+        ax += (valid ? o[0] : 0.0f) * u2.x;
+        ay += (valid ? o[tileW] : 0.0f) * u2.y;
+      }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float g0 = valid ? o[r * tileW] : 0.0f;
-        const float g1 = valid ? o[(R + r) * tileW] : 0.0f;
-        acc[r] += g0 * u2.x + g1 * u2.y;
+      for (int r = 0; r < R; ++r)
+        acc[r] = W[(((size_t)r * S + t) * 2 + 0) * ld + m] * ax + W[(((size_t)r * S + t) * 2 + 1) * ld + m] * ay;
+    } else {
+#pragma unroll 4
+      for (int s2 = 0; s2 < t; ++s2) {
+        const rfloat2_t u2 = US[s2];
+        const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float g0 = valid ? o[r * tileW] : 0.0f;
+          const float g1 = valid ? o[(R + r) * tileW] : 0.0f;
+          acc[r] += g0 * u2.x + g1 * u2.y;
+        }
       }
     }
 #pragma unroll
@@ -105,8 +121,9 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
 // grid = ceil(M/256) workgroups of 256 lanes (one sample each).  part[blk][s*2 + g] = sum over the block's
 // samples of weight_i * G_i[arg_i, (s,g)], weight = 1 for m_i > tstar, lambda for m_i == tstar, else 0.
 template <int R>
-__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __restrict__ G, int tileW, int S, long M,
-                                                               const float* __restrict__ mvals,
+__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __restrict__ G,
+                                                               const float* __restrict__ W, long ld, int tileW, int S,
+                                                               long M, const float* __restrict__ mvals,
                                                                const int* __restrict__ arg, float tstar,
                                                                float lambda, const double* __restrict__ stats_dev,
                                                                double alphaM, float* __restrict__ part) {
@@ -130,15 +147,23 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
     t = a - r * S;
   }
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
-  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * R * tileW) + (m % tileW);
-  const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * R * tileW);
+  const bool fact = (W != nullptr);
+  const int RR = fact ? 1 : R;
+  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * RR * tileW) + (m % tileW);
+  const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
+  float w0 = w, w1 = w;
+  if (fact && w != 0.0f) {   // factored: entry = W[r,t,a] * Phi[t,s,a]
+    w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m];
+    w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m];
+  }
+  const int rsel = fact ? 0 : r;
   const int nw = 2 * (S - 1);
   for (int s2 = 0; s2 < S - 1; ++s2) {
     float g0 = 0.0f, g1 = 0.0f;
     if (w != 0.0f && s2 < t) {
-      const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
-      g0 = w * o[r * tileW];
-      g1 = w * o[(R + r) * tileW];
+      const float* __restrict__ o = row + (size_t)s2 * (2 * RR * tileW);
+      g0 = w0 * o[rsel * tileW];
+      g1 = w1 * o[(RR + rsel) * tileW];
     }
     const float s0 = rato::wave_sum_dpp(g0);
     const float s1 = rato::wave_sum_dpp(g1);
@@ -158,9 +183,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
-                               const float* g_up, const float* us, int32_t n_u, float* m_out, int32_t* arg_out,
-                               void* stream) {
+extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int32_t R, int32_t S, int64_t M,
+                               int64_t ld, const float* g_up, const float* us, int32_t n_u, float* m_out,
+                               int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
   if (!G || !g_up || !us || !m_out || !arg_out || M <= 0 || S < 1 || ld < M || n_u < 2 || (tile != 64 && tile != 256) ||
       (R != 1 && R != 3))
@@ -169,19 +194,24 @@ extern "C" int rato_saa_rowmax(const float* G, int32_t tile, int32_t R, int32_t 
   if (lds > 64 * 1024) return RATO_EINVAL;
   dim3 grid((unsigned)((M + 63) / 64)), block(RM_NW * RATO_WAVE);
   hipStream_t st = rato::as_stream(stream);
-  if (R == 3)
-    hipLaunchKernelGGL(rowmax_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, (long)ld, g_up, us, n_u, m_out,
-                       arg_out);
+  if (R == 3 && W)
+    hipLaunchKernelGGL((rowmax_kernel<3, true>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us, n_u,
+                       m_out, arg_out);
+  else if (R == 3)
+    hipLaunchKernelGGL((rowmax_kernel<3, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us,
+                       n_u, m_out, arg_out);
+  else if (!W)
+    hipLaunchKernelGGL((rowmax_kernel<1, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us,
+                       n_u, m_out, arg_out);
   else
-    hipLaunchKernelGGL(rowmax_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, (long)ld, g_up, us, n_u, m_out,
-                       arg_out);
+    return RATO_EINVAL;
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
 
-extern "C" int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32_t S, int64_t M, const float* m_vals,
-                                  const int32_t* arg, float tstar, float lambda, const double* stats_dev,
-                                  double alphaM, float* part, void* stream) {
+extern "C" int rato_saa_tail_rows(const float* G, const float* W, int64_t ld, int32_t tile, int32_t R, int32_t S,
+                                  int64_t M, const float* m_vals, const int32_t* arg, float tstar, float lambda,
+                                  const double* stats_dev, double alphaM, float* part, void* stream) {
   RATO_CLEAR_ERROR();
   if (!G || !m_vals || !arg || !part || M <= 0 || S < 2 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
     return RATO_EINVAL;
@@ -189,10 +219,10 @@ extern "C" int rato_saa_tail_rows(const float* G, int32_t tile, int32_t R, int32
   dim3 grid((unsigned)rato::nblocks_for((int32_t)M)), block(RATO_BLOCK);
   hipStream_t st = rato::as_stream(stream);
   if (R == 3)
-    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda,
+    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, m_vals, arg, tstar, lambda,
                        stats_dev, alphaM, part);
   else
-    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, tile, S, (long)M, m_vals, arg, tstar, lambda,
+    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, m_vals, arg, tstar, lambda,
                        stats_dev, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;

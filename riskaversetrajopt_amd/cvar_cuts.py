@@ -54,18 +54,19 @@ class CvarCutSolver:
         self.us_dev = e(S, n_u)
 
     # ---- device oracle -----------------------------------------------------
-    def evaluate(self, G, tile, g_up_raw, u_vec):
+    def evaluate(self, G, W, tile, g_up_raw, u_vec):
         """-> (phi = CVaR_alpha(m(u)), t* = VaR, g (nU,) subgradient of phi).  One upload of u, four stream-
         ordered calls, ONE read-back (statistics + subgradient sums)."""
         S, M, n_u = self.S, self.M, self.n_u
         self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
         self.us_dev.copy_(self.u_host, non_blocking=True)
-        _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), tile, self.R, S, M, self.ld, _lib.ptr(g_up_raw),
+        _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld, _lib.ptr(g_up_raw),
                                             _lib.ptr(self.us_dev), n_u, _lib.ptr(self.m), _lib.ptr(self.arg),
                                             _lib.current_stream()), "rato_saa_rowmax")
         stats.risk_stats_device(self.m, self.alpha, workspace=self.ws, out=self.res[:stats.N_STATS])
         if S > 1:
-            _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), tile, self.R, S, M, _lib.ptr(self.m),
+            _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
+                                                   _lib.ptr(self.m),
                                                    _lib.ptr(self.arg), 0.0, 0.0, _lib.ptr(self.res),
                                                    float(self.alpha * M), _lib.ptr(self.part),
                                                    _lib.current_stream()), "rato_saa_tail_rows")
@@ -92,7 +93,7 @@ class CvarCutSolver:
         with threadpool_limits(limits=4):
             return self._solve(*args, **kwargs)
 
-    def _solve(self, G, tile, g_up_raw, final_du, final_rhs, *, with_cvar=True, tol=1e-7, max_cuts=400,
+    def _solve(self, G, W, tile, g_up_raw, final_du, final_rhs, *, with_cvar=True, tol=1e-7, max_cuts=400,
                verbose=False):
         nU, n = self.nU, self.nU + 1
         F = np.hstack([np.asarray(final_du, dtype=np.float64), np.zeros((np.shape(final_du)[0], 1))])
@@ -127,7 +128,7 @@ class CvarCutSolver:
             if not with_cvar:
                 break
             t0 = time.perf_counter()
-            phi, tstar, g = self.evaluate(G, tile, g_up_raw, u_vec)
+            phi, tstar, g = self.evaluate(G, W, tile, g_up_raw, u_vec)
             info["oracle_s"] += time.perf_counter() - t0
             viol = phi - self.c_s * s
             if verbose:

@@ -278,8 +278,8 @@ class Model:
         r = self.linearize_device(us_mat)
         M, S = r["M"], self.S
         vals = self._empty(M * S * (S - 1))
-        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), r["tile"], 2, 1, S, M, 1.0, _lib.ptr(vals),
-                                                  _lib.current_stream()), "rato_emit_csc_values")
+        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), None, 0, r["tile"], 2, 1, S, M, 1.0,
+                                                  _lib.ptr(vals), _lib.current_stream()), "rato_emit_csc_values")
         g_up = r["g_up"].t().contiguous().double().cpu().numpy()[:, None, :]          # (M, 1, S)
         return fast.assemble(vals.cpu().numpy(), r["final_du"].double().cpu().numpy(),
                              r["final_rhs"].double().cpu().numpy(), g_up, kappa=1.0, baseline_pad=0.0, relax=None)
@@ -336,7 +336,7 @@ class Model:
                                          dt=self.dt, Rcost=P.R, slack_penalty=self.SLACK_PENALTY,
                                          u_min=self.u_min, u_max=self.u_max)
             self._cut_solver = cs
-        info = cs.solve(r["G"], r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
+        info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
                         r["final_rhs"].double().cpu().numpy(), with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
 

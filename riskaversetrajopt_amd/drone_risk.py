@@ -205,11 +205,14 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None):
+                         want_Z=True, events=None, factored=None):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
-           G  [n_tiles][n_pairs][2][n_obs][TILE]  packed causal Jacobian, tile-blocked (rato_saa.h)
+           G  [n_tiles][n_pairs][2][n_obs][TILE]  packed causal Jacobian, tile-blocked (rato_saa.h), or — when
+              ``factored`` (default with the row-parallel kernel) — Phi [n_tiles][n_pairs][2][TILE] together
+              with W [n_obs][S][2][M]:  d g[j,t]/d u[s,a] = W[j,t,a] * Phi[t,s,a]  (2.67x fewer bytes at S=50;
+              ``packed_jacobian(result)`` materialises the products)
            g_up [n_obs][S][M], Z [M]  (views of row-stride-ld buffers),
            du_sum [S][6] (float64: sums over samples of dx_S/du_{s,axis}),
            rhs_sum [6]   (float64: sums of -v_final + v_final_du.u)
@@ -221,9 +224,17 @@ class Model:
         ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
         nblk, cpt, spl, tile = self.linearize_plan(M, ld, cols_per_thread, samples_per_lane)
+        if factored is None:
+            factored = (cpt == -1)
+        if factored and cpt != -1:
+            raise _lib.RatoError("the factored output exists for the row-parallel kernel (cols_per_thread=-1) only")
         o = out if out is not None else {}
-        G = o["G"] if ("G" in o and o["G"].shape[-1] == tile) else \
-            self._empty(num_tiles(M, tile), max(num_pairs(S), 1), 2, n_obs, tile)
+        g_shape = (num_tiles(M, tile), max(num_pairs(S), 1), 2, tile) if factored else \
+            (num_tiles(M, tile), max(num_pairs(S), 1), 2, n_obs, tile)
+        G = o["G"] if ("G" in o and tuple(o["G"].shape) == g_shape) else self._empty(*g_shape)
+        Wf = None
+        if factored:
+            Wf = o["_W"] if (o.get("_W") is not None and o["_W"].shape[-1] == ld) else self._empty(n_obs, S, 2, ld)
         g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
         Z = (o["_Z"] if "_Z" in o else self._empty(ld)) if want_Z else None
         part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) \
@@ -232,7 +243,7 @@ class Model:
         if events is not None:
             events[0].record()
         _lib.check(self._lib.rato_drone_linearize(
-            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
+            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G), _lib.ptr(Wf),
             _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
             "rato_drone_linearize")
         if events is not None:
@@ -241,7 +252,8 @@ class Model:
         return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None),
                 "du_sum": sums[:6 * S].view(S, 6), "rhs_sum": sums[6 * S:], "sums": sums,
                 "part": part, "M": M, "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt,
-                "samples_per_lane": spl, "tile": tile}
+                "samples_per_lane": spl, "tile": tile, "factored": bool(factored),
+                "W": (Wf[..., :M] if factored else None), "_W": Wf}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
@@ -253,11 +265,25 @@ class Model:
             out[3 + a, a::n_u] = d[:, 3 + a]
         return out
 
+    def packed_jacobian(self, r):
+        """linearize_device result -> untiled packed Jacobian [n_pairs][2][n_obs][M] (device tensor), whichever
+        representation the kernel wrote (for the factored one the products W * Phi are formed here)."""
+        M, S = r["M"], self.S
+        if not r.get("factored"):
+            return untile(r["G"], M)
+        Phi = untile(r["G"], M)                                   # (n_pairs, 2, M)
+        t_of = torch.as_tensor(np.concatenate([np.full(t, t) for t in range(1, S)]) if S > 1 else np.zeros(0),
+                               dtype=torch.long, device=Phi.device)
+        Wt = r["W"].permute(1, 2, 0, 3)[t_of]                      # (n_pairs, 2, n_obs, M): W[j,t,a] at the pair's t
+        return Phi[:, :, None, :] * Wt
+
     def expand_g_obs_du(self, G, M=None):
         """packed G -> dense host (M,n_obs,S,n_u*S); small M only.  G is either the
-        tile-blocked device tensor [n_tiles][n_pairs][2][n_obs][TILE] or an already
-        untiled [n_pairs][2][n_obs][M'] tensor/ndarray."""
+        tile-blocked device tensor [n_tiles][n_pairs][2][n_obs][TILE], an already untiled
+        [n_pairs][2][n_obs][M'] tensor/ndarray, or a whole linearize_device result dict."""
         S = self.S
+        if isinstance(G, dict):                        # a linearize_device result (either representation)
+            G = self.packed_jacobian(G)
         if isinstance(G, torch.Tensor):
             if G.dim() == 5:
                 G = untile(G, self.M if M is None else M)
@@ -285,7 +311,7 @@ class Model:
         r = self.linearize_device(us_mat, inputs=inputs)
         v_final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0)
         rhs = r["rhs_sum"].cpu().numpy()
-        g_obs_du = self.expand_g_obs_du(r["G"], 1)[0]
+        g_obs_du = self.expand_g_obs_du(r)[0]
         g_up = r["g_up"][:, :, 0].double().cpu().numpy()
         return v_final_du, rhs, rhs.copy(), g_obs_du, g_up
 
@@ -293,7 +319,7 @@ class Model:
         """vmap of the above over the model's samples (drone_risk.py:288-290), dense;
         small M only.  -> (g_obs_du (M,n_obs,S,3S), g_up (M,n_obs,S))."""
         r = self.linearize_device(us_mat)
-        g_obs_du = self.expand_g_obs_du(r["G"], r["M"])
+        g_obs_du = self.expand_g_obs_du(r)
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
@@ -326,7 +352,7 @@ class Model:
         M = r["M"]
         final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
         final_rhs = r["rhs_sum"].cpu().numpy() / M
-        G = untile(r["G"], M).double().cpu().numpy()                 # (n_pairs, 2, n_obs, M)
+        G = self.packed_jacobian(r).double().cpu().numpy()           # (n_pairs, 2, n_obs, M)
         g_up = r["g_up"].double().cpu().numpy()                      # (n_obs, S, M)
         return final_du, final_rhs, G, g_up, M
 
@@ -366,8 +392,9 @@ class Model:
         M, S = r["M"], self.S
         factor = relax[2] if relax is not None else 1.0
         vals = self._empty(M * n_obs * S * (S - 1))
-        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), r["tile"], 2, n_obs, S, M,
-                                                  float(self.MULTIPLIER * factor), _lib.ptr(vals),
+        ldw = r["_W"].shape[-1] if r["factored"] else 0
+        _lib.check(self._lib.rato_emit_csc_values(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), ldw, r["tile"], 2, n_obs,
+                                                  S, M, float(self.MULTIPLIER * factor), _lib.ptr(vals),
                                                   _lib.current_stream()), "rato_emit_csc_values")
         final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
         final_rhs = r["rhs_sum"].cpu().numpy() / M
@@ -432,8 +459,8 @@ class Model:
             self._cut_solver = cs
         final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
         final_rhs = r["rhs_sum"].cpu().numpy() / M
-        info = cs.solve(r["G"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2), tol=tol,
-                        verbose=verbose)
+        info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2),
+                        tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
 
     # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------

@@ -73,7 +73,7 @@ def test_linearization_vs_oracle(S, M, cpt, spl):
     us = graze(S)
     fdu_o, flo_o, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
     r = d.linearize_device(us, cols_per_thread=cpt, samples_per_lane=spl)
-    gdu = d.expand_g_obs_du(r["G"], M)
+    gdu = d.expand_g_obs_du(r)
     tol.assert_jac_close(gdu, gdu_o, what="g_obs_du")
     # exact structural zeros survive the packing
     assert np.all(gdu[gdu_o == 0.0] == 0.0)
@@ -85,6 +85,27 @@ def test_linearization_vs_oracle(S, M, cpt, spl):
     np.testing.assert_allclose(r["rhs_sum"].cpu().numpy() / M, flo_o.mean(0), rtol=tol.MEAN_RTOL, atol=2e-5)
 
 
+@pytest.mark.parametrize("S,M", [(20, 300), (50, 130), (2, 5), (125, 3)])
+def test_products_output_of_rows_kernel_vs_oracle(S, M):
+    """the row-parallel kernel writing the products (un-factored) Jacobian; the default is factored"""
+    o, d = _models(S, M)
+    us = graze(S)
+    _, _, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)
+    r = d.linearize_device(us, cols_per_thread=-1, factored=False)
+    assert not r["factored"] and r["W"] is None
+    gdu = d.expand_g_obs_du(r)
+    tol.assert_jac_close(gdu, gdu_o, what="g_obs_du")
+    assert np.all(gdu[gdu_o == 0.0] == 0.0)
+    np.testing.assert_allclose(r["g_up"].permute(2, 0, 1).cpu().numpy(), gup_o, rtol=5e-5, atol=2e-4)
+    f = d.linearize_device(us, cols_per_thread=-1, factored=True)
+    assert f["factored"]
+    # same factors, different association of dt/m ((w dt/m) mu  vs  w (mu dt/m)): equal to a few fp32 ulp
+    a, b = d.packed_jacobian(f).cpu().numpy(), d.packed_jacobian(r).cpu().numpy()
+    assert np.all(np.abs(a - b) <= 4e-7 * np.abs(b)) and np.array_equal(a == 0.0, b == 0.0)
+    with pytest.raises(Exception):
+        d.linearize_device(us, cols_per_thread=4, factored=True)       # column kernels only write products
+
+
 def test_variants_agree_and_are_deterministic():
     """Every kernel variant computes the same linearization up to fp32 rounding, and each one is
     bitwise reproducible run to run (fixed reduction order; the LDS work queue only decides WHICH
@@ -94,17 +115,21 @@ def test_variants_agree_and_are_deterministic():
     _, d = _models(50, M)
     us = graze(50)
     ref = d.linearize_device(us, cols_per_thread=4, samples_per_lane=1)
-    b = untile(ref["G"], M).cpu().numpy()
-    for cpt, spl in VARIANTS:
-        r = d.linearize_device(us, cols_per_thread=cpt, samples_per_lane=spl)
-        a = untile(r["G"], M).cpu().numpy()
+    assert not ref["factored"]
+    b = d.packed_jacobian(ref).cpu().numpy()
+    for cpt, spl, fact in [(c, l, False) for c, l in VARIANTS] + [(-1, 1, True)]:
+        r = d.linearize_device(us, cols_per_thread=cpt, samples_per_lane=spl, factored=fact)
+        assert r["factored"] == fact and (r["W"] is not None) == fact
+        a = d.packed_jacobian(r).cpu().numpy()
         assert np.all(np.abs(a - b) <= 2e-6 * np.abs(b).max(axis=(0, 1, 2), keepdims=True) + 1e-12), (cpt, spl)
         assert np.array_equal(a == 0.0, b == 0.0)
         np.testing.assert_allclose(r["g_up"].cpu().numpy(), ref["g_up"].cpu().numpy(), rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(r["du_sum"].cpu().numpy(), ref["du_sum"].cpu().numpy(), rtol=1e-5)
         np.testing.assert_allclose(r["rhs_sum"].cpu().numpy(), ref["rhs_sum"].cpu().numpy(), rtol=1e-5, atol=1e-3)
-        again = d.linearize_device(us, cols_per_thread=cpt, samples_per_lane=spl)
+        again = d.linearize_device(us, cols_per_thread=cpt, samples_per_lane=spl, factored=fact)
         assert bool((untile(again["G"], M) == untile(r["G"], M)).all()), (cpt, spl)
+        if fact:
+            assert bool((again["W"] == r["W"]).all())
         assert bool((again["g_up"] == r["g_up"]).all()) and bool((again["Z"] == r["Z"]).all())
         np.testing.assert_array_equal(again["du_sum"].cpu().numpy(), r["du_sum"].cpu().numpy())
         np.testing.assert_array_equal(again["rhs_sum"].cpu().numpy(), r["rhs_sum"].cpu().numpy())
@@ -166,7 +191,8 @@ def test_full_size_C2_properties():
     us = graze(S)
     r = d.linearize_device(us)
     from riskaversetrajopt_amd.drone_risk import untile
-    G_dev = untile(r["G"], M)                                       # (n_pairs,2,3,M)
+    assert r["factored"]                                            # default representation: (W, Phi)
+    G_dev = d.packed_jacobian(r)                                    # (n_pairs,2,3,M)
     # linearity of the linearization: g_up + g == G.u (row sums through the packed layout)
     _, _, g = d.eval_device(us, want_g=True)
     u = torch.as_tensor(us, dtype=torch.float32, device=G_dev.device)
@@ -217,7 +243,7 @@ def test_captured_step_graph_matches_eager():
         out, st = step.replay(us)
         torch.cuda.synchronize()
         eager = d.linearize_device(us)
-        assert bool((untile(out["G"], M) == untile(eager["G"], M)).all())
+        assert bool((untile(out["G"], M) == untile(eager["G"], M)).all()) and bool((out["W"] == eager["W"]).all())
         assert bool((out["g_up"] == eager["g_up"]).all()) and bool((out["Z"] == eager["Z"]).all())
         np.testing.assert_array_equal(out["sums"].cpu().numpy(), eager["sums"].cpu().numpy())
         ref = stats.risk_stats_device(eager["Z"], 0.1).cpu().numpy()
