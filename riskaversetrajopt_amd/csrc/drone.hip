@@ -415,8 +415,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
 //            behind the chip-wide store stream for microseconds per step);
 //   phase 1  waves 0,1,2 roll out ONE AXIS each (the axes decouple:
 //            drone_risk.py:122-131) and leave a22_t (the only state-dependent
-//            entry of the step Jacobian) and p_{t+1} in LDS: 20 B per sample-step;
-//   phase 2  all waves pull tasks from an LDS work queue.  Row task t rebuilds
+//            entry of the step Jacobian) and p_{t+1} in LDS: 20 B per sample-step,
+//            publishing their progress in LDS after every step; each then runs the
+//            final-state adjoint of its own axis and joins phase 2;
+//   phase 2  (overlapped with phase 1: row t only needs steps 0..t, rows are
+//            taken shortest first and wait on the published progress)
+//            all waves pull tasks from an LDS work queue.  Row task t rebuilds
 //            g_j(t), w = -(Q+Q^T) d from p_{t+1} and sweeps the row with the adjoint
 //              mu_{t+1} = e_0^T,  mu_k = mu_{k+1} A_k,  d p_{t+1}/d u_s = mu_{s+1}[1] dt/m
 //            (A_k = [[1, dt], [a21, a22_k]], B = [0, dt/m]^T): 3 packed FMAs + 6
@@ -438,8 +442,8 @@ constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 #ifndef RATO_DIAG
-#define RATO_DIAG 0  // diagnostic builds only (tools/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores
-#endif
+#define RATO_DIAG 0  // diagnostic builds only (tools/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores,
+#endif               // 4 = timeline: part[tile][0..7] <- wall_clock64 at block start / after phase 0 / after phase 1 / end
 
 __host__ __device__ inline size_t rows_lds_floats(int S) {
   // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | XS[6][64] | head (+pad)
@@ -460,7 +464,8 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
-  const int lane = threadIdx.x & (RATO_WAVE - 1), wave = threadIdx.x / RATO_WAVE;
+  const int lane = threadIdx.x & (RATO_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RATO_WAVE);  // scalar: wave-level branches stay scalar
   // Before step t of the rollout, PP[t] / AZ[t] hold that step's noise (xi_x, xi_y) / xi_z; the
   // axis wave that consumes a component overwrites it with its own output (same lane, so program
   // order is enough).  No __restrict__ on these pointers for that reason.
@@ -474,6 +479,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 
   const int tile = tile_base + blockIdx.x;
   const int part_id = blockIdx.y, row_split = gridDim.y;
+#if RATO_DIAG == 4
+  unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
+#endif
   const size_t m_raw = (size_t)tile * ROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;  // clamp loads; stores are predicated
@@ -518,72 +526,71 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
       US[i] = u2;
       UZ[i] = us[i * 3 + 2];
     }
-    if (threadIdx.x == 0) *head = 0;
+    if (threadIdx.x == 0) {
+      head[0] = 0;
+      head[1] = head[2] = (RATO_DIAG == 2) ? S : 0;   // rollout progress of the x and y axes
+    }
   }
   __syncthreads();
+#if RATO_DIAG == 4
+  tl1 = wall_clock64();
+#endif
 
-  // ---- phase 1: waves 0..2 roll out one axis each (pass-1 coefficients into LDS)
-  if (wave < 3 && RATO_DIAG != 2) {
-    const int a = wave;
-    const float cn = sqrtf(P.dt) * P.beta * inv_m;  // sqrt(dt) * (beta/m): drone_risk.py:136,151
-    float p = P.x_init[a], v = P.x_init[3 + a];
-    float* PPf = reinterpret_cast<float*>(PP);
-    for (int t = 0; t < S; ++t) {
-      const int slot = t * ROWS_SAMPLES + lane;
-      const float xi = (a < 2) ? PPf[slot * 2 + a] : AZ[slot];
-      const float u = (a == 0) ? US[t].x : ((a == 1) ? US[t].y : UZ[t]);
-      const float a22 = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v)) * inv_m;
-      const float acc = (u - (P.kp * p + P.kd * v)) * inv_m - P.drag * fabsf(v) * v * inv_m;
-      const float pn = p + P.dt * v;
-      const float vn = v + P.dt * acc + cn * xi;
-      p = pn;
-      v = vn;
-      if (a < 2) {
-        reinterpret_cast<float*>(A2)[slot * 2 + a] = a22;
-        PPf[slot * 2 + a] = p;
-      } else {
-        AZ[slot] = a22;
-      }
-    }
-    XS[a * ROWS_SAMPLES + lane] = p;
-    XS[(3 + a) * ROWS_SAMPLES + lane] = v;
-  }
-  __syncthreads();
-
-  // ---- Z = max_{j,t} g - tol from the p_{t+1} table (one wave of partition 0; cheap)
-  if (Z && part_id == 0 && wave == ROWS_NW - 1) {
-    float zmax = -INFINITY;
-    for (int t = 0; t < S; ++t) {
-      const float2_t pp = PP[t * ROWS_SAMPLES + lane];
-#pragma unroll
-      for (int j = 0; j < NOBS; ++j) {
-        const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
-        zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
-      }
-    }
-    if (valid) Z[m] = zmax - P.tol;
-  }
-
-  // ---- phase 2: tasks from the LDS queue.
-  // Partition p of row_split owns the tasks congruent to p (mod row_split), longest first.
+  // ---- phase 1 (waves 0..2) overlapped with phase 2 (the other waves, then everybody).
+  // Wave a < 3 rolls out axis a, publishing its progress after every step (x and y: prog[a] = steps done),
+  // then runs the final-state adjoint of its own axis and joins the row queue.  Row task t only needs
+  // steps 0..t, so the row waves start sweeping (shortest rows first) while the rollout is still running:
+  // a workgroup starts storing ~1 step after its noise tile has landed instead of after S sequential steps.
+  typedef __attribute__((address_space(3))) volatile int lds_vint;   // keeps the polls / publishes ds_ instructions
+  lds_vint* prog = (lds_vint*)(head + 1);
   constexpr int RT = ROWS_SAMPLES;  // tile width: each row sweep below is one contiguous descending stream
   constexpr int RPP = FACT ? 2 : 2 * NOBS;  // tile rows per (t, s) pair
   const size_t tile_floats = (size_t)rato::pair_row_offset(S) * RPP * RT;
   float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
-  // One LDS fetch-add per task, issued by lane 0 and broadcast (written without `continue`:
-  // hipcc 7.2 mis-structured the earlier for(;;)/continue form into a loop that re-ran task 0).
-  auto next_task = [&]() -> int {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(head, 1);
-    return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
-  };
-  // tasks 0..2: final-state Jacobian of axis a = task; tasks 3..S+2: row t = S + 2 - task
-  int task = (RATO_DIAG == 1) ? S + 3 : next_task();
-  while (task <= S + 2) {
-    if (task < 3) {
-      // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s for one axis: rows (P, V), summed over the block's
-      // samples; the same sweep accumulates (d x_S / d u) . u for the rhs  (drone_risk.py:271)
-      const int a = task;
+
+  if (wave < 3) {
+    const int a = wave;
+    // all three axis waves run the same instruction stream: table offsets (in floats from the LDS base) and
+    // strides instead of per-axis branches.  x/y: noise in PP[t].{x,y}, a22 -> A2[t].{x,y}, p -> PP[t].{x,y};
+    // z: noise in AZ[t], a22 -> AZ[t].
+    float* L = reinterpret_cast<float*>(lds_raw);
+    const int offA2 = 0, offPP = 2 * S * ROWS_SAMPLES, offAZ = 4 * S * ROWS_SAMPLES, offUS = 5 * S * ROWS_SAMPLES,
+              offUZ = offUS + 2 * S;
+    const int st = (a < 2) ? 2 : 1;                                   // floats per (t, lane) slot
+    const int o_noise = ((a < 2) ? offPP + a : offAZ) + lane * st;
+    const int o_a22 = ((a < 2) ? offA2 + a : offAZ) + lane * st;
+    const int o_u = (a < 2) ? offUS + a : offUZ;
+    float* A2f = reinterpret_cast<float*>(A2);
+    float p = P.x_init[a], v = P.x_init[3 + a];
+    if (RATO_DIAG != 2) {
+      const float cn = sqrtf(P.dt) * P.beta * inv_m;  // sqrt(dt) * (beta/m): drone_risk.py:136,151
+      float xi = L[o_noise], u = L[o_u];
+      for (int t = 0; t < S; ++t) {
+        // next step's inputs are fetched BEFORE this step's table stores (same arrays, other slots)
+        const int tn = (t + 1 < S) ? t + 1 : t;
+        const float xi_n = L[o_noise + tn * ROWS_SAMPLES * st], u_n = L[o_u + tn * st];
+        const float a22 = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v)) * inv_m;
+        const float acc = (u - (P.kp * p + P.kd * v)) * inv_m - P.drag * fabsf(v) * v * inv_m;
+        const float pn = p + P.dt * v;
+        const float vn = v + P.dt * acc + cn * xi;
+        p = pn;
+        v = vn;
+        L[o_a22 + t * ROWS_SAMPLES * st] = a22;
+        if (a < 2) {
+          L[o_noise + t * ROWS_SAMPLES * st] = p;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) prog[a] = t + 1;
+        }
+        xi = xi_n;
+        u = u_n;
+      }
+    }
+#if RATO_DIAG == 4
+    tl2 = wall_clock64();
+#endif
+    // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s for this wave's axis: rows (P, V), summed over the block's
+    // samples; the same sweep accumulates (d x_S / d u) . u for the rhs  (drone_risk.py:271)
+    if (RATO_DIAG != 1 && (a % row_split) == part_id) {
       float mP0 = 1.0f, mP1 = 0.0f, mV0 = 0.0f, mV1 = 1.0f, dP = 0.0f, dV = 0.0f;
       for (int s2 = S - 1; s2 >= 0; --s2) {
         const float ua = (a == 0) ? US[s2].x : ((a == 1) ? US[s2].y : UZ[s2]);
@@ -598,21 +605,58 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
         }
         if (s2 > 0) {  // mu_s = mu_{s+1} A_s
           const int slot = s2 * ROWS_SAMPLES + lane;
-          const float a22 = (a < 2) ? reinterpret_cast<const float*>(A2)[slot * 2 + a] : AZ[slot];
+          const float a22 = (a < 2) ? A2f[slot * 2 + a] : AZ[slot];
           const float nP0 = mP0 + mP1 * a21, nP1 = mP0 * P.dt + mP1 * a22;
           const float nV0 = mV0 + mV1 * a21, nV1 = mV0 * P.dt + mV1 * a22;
           mP0 = nP0; mP1 = nP1; mV0 = nV0; mV1 = nV1;
         }
       }
-      const float xp = XS[a * ROWS_SAMPLES + lane], xv = XS[(3 + a) * ROWS_SAMPLES + lane];
-      const float rp = rato::wave_sum_dpp(valid ? (-(xp - P.x_final[a]) + dP) : 0.0f);
-      const float rv = rato::wave_sum_dpp(valid ? (-(xv - P.x_final[3 + a]) + dV) : 0.0f);
+      const float rp = rato::wave_sum_dpp(valid ? (-(p - P.x_final[a]) + dP) : 0.0f);
+      const float rv = rato::wave_sum_dpp(valid ? (-(v - P.x_final[3 + a]) + dV) : 0.0f);
       if (lane == 0) {
         part[(size_t)tile * (6 * S + 6) + 6 * S + a] = rp;
         part[(size_t)tile * (6 * S + 6) + 6 * S + 3 + a] = rv;
       }
+    }
+  }
+
+  // ---- phase 2: tasks from the LDS queue, in ascending row order.
+  // Partition p of row_split owns the tasks congruent to p (mod row_split).  Task T < S is row t = T;
+  // task T = S is Z = max_{j,t} g - tol from the p_{t+1} table.
+  // One LDS fetch-add per task, issued by lane 0 and broadcast (written without `continue`:
+  // hipcc 7.2 mis-structured the earlier for(;;)/continue form into a loop that re-ran task 0).
+  auto next_task = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(head, 1);
+    return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
+  };
+  auto wait_steps = [&](int need) {  // both horizontal axes rolled out through step need-1
+    while (true) {
+      const int p0 = prog[0], p1 = prog[1];
+      if ((p0 < p1 ? p0 : p1) >= need) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  int task = (RATO_DIAG == 1) ? S + 1 : next_task();
+  while (task <= S) {
+    if (task == S) {
+      wait_steps(S);
+      if (Z) {
+        float zmax = -INFINITY;
+        for (int t = 0; t < S; ++t) {
+          const float2_t pp = PP[t * ROWS_SAMPLES + lane];
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) {
+            const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
+            zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
+          }
+        }
+        if (valid) Z[m] = zmax - P.tol;
+      }
     } else {
-      const int t = S + 2 - task;  // S-1 ... 0 (longest rows first)
+      const int t = task;
+      wait_steps(t + 1);
       const float2_t pp = PP[t * ROWS_SAMPLES + lane];
       float gj[NOBS], wx[NOBS], wy[NOBS];  // g, and -(Q+Q^T) d pre-multiplied by dt/m
 #pragma unroll
@@ -663,6 +707,13 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     }
     task = next_task();
   }
+#if RATO_DIAG == 4
+  __syncthreads();   // all of the block's row tasks issued (stores may still be in flight)
+  if (threadIdx.x == 0) {
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(part + (size_t)tile * (6 * S + 6));
+    tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
+  }
+#endif
 }
 
 bool params_ok(const rato_drone_params* p) {
