@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="drone linearize, N=1: replay the step as ONE captured hipGraph (kernel time then comes "
                          "from an eager pre-pass with HIP events, since events cannot bracket a node inside a graph)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the exchange + risk statistics of step i on a side stream while the hot kernel of step "
+                         "i+1 runs (two output slots).  Off by default: measured on one GPU it gains nothing (the step "
+                         "is the dominant kernel + 7 us of partial sums + launch gaps; DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0)
     return ap.parse_args()
@@ -84,19 +88,22 @@ class DroneWork:
         if self.mode == "linearize":
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
                                             factored=self.fact)
-            self.out = r                                                       # buffers are reused every step
             self.fact = r["factored"]
+            # two output slots, reused alternately: the statistics of step i (side stream) read Z / sums of slot
+            # i%2 while step i+1 writes the other slot
+            self.outs = [r, self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
+                                                        factored=self.fact)]
             self.variant = "cols_per_thread=%d samples_per_lane=%d jacobian=%s" % (
                 r["cols_per_thread"], r["samples_per_lane"], "factored(W,Phi)" if self.fact else "products")
             self.kernel = "drone_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "drone_linearize_kernel"
         else:
             self.kernel = "drone_eval_kernel"
 
-    def hot_kernel(self, events=None):
+    def hot_kernel(self, events=None, slot=0):
         """One pass; ``events`` bracket ONLY the dominant kernel's launch."""
         if self.mode == "linearize":
             return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
-                                               out=self.out, events=events, factored=self.fact)
+                                               out=self.outs[slot], events=events, factored=self.fact)
         if events is not None:
             events[0].record()
         Z, _, _ = self.model.eval_device(self.us)
@@ -157,17 +164,19 @@ class DrivingWork:
         self.out = None
         if self.mode == "linearize":
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt)
-            self.out = {k: r[k] for k in ("G", "g_up", "Z", "final_du", "final_rhs")}
+            keys = ("G", "g_up", "Z", "final_du", "final_rhs")
+            r2 = self.model.linearize_device(self.us, cols_per_thread=self.cpt)
+            self.outs = [{k: r[k] for k in keys}, {k: r2[k] for k in keys}]
             self.variant = "cols_per_thread=%d" % r["cols_per_thread"]
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
             self.kernel = "car_eval_kernel"
 
-    def hot_kernel(self, events=None):
+    def hot_kernel(self, events=None, slot=0):
         if events is not None:
             events[0].record()
         if self.mode == "linearize":
-            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.out)
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.outs[slot])
         else:
             r = {"Z": self.model.eval_device(self.us)[0]}
         if events is not None:
@@ -218,7 +227,7 @@ class HopperWork:
         import torch
         self.lam = torch.rand((self.C, self.M), device=device)
 
-    def hot_kernel(self, events=None):
+    def hot_kernel(self, events=None, slot=0):
         if events is not None:
             events[0].record()
         if self.mode == "linearize":
@@ -289,7 +298,8 @@ def main():
     M, S = work.M, work.S
     unit_steps = getattr(work, "C", S)        # hopper: the unit is a sample-contact
     ws_bytes = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(M * world), dtype=torch.uint8, device=device)
-    stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=device)
+    stats_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
+    wss = [ws_bytes, torch.empty_like(ws_bytes)]
 
     def barrier():
         if dist.is_initialized():
@@ -297,13 +307,38 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    use_graph = args.graph and args.workload == "drone" and args.mode == "linearize" and world == 1
+    pipelined = args.overlap and not use_graph
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if pipelined else main_stream
+    ev_lin = [torch.cuda.Event() for _ in range(2)]       # hot kernel of the slot finished
+    ev_free = [torch.cuda.Event() for _ in range(2)]      # statistics of the slot finished (its buffers are free)
+    counter = [0]
+
     def step(i=None):
-        r = work.hot_kernel(events=ev[i] if i is not None else None)
-        sums, Z_all = rdist.exchange(work.sums(r), r["Z"])        # the one collective (no-op at N=1)
-        stats.risk_stats_device(Z_all, args.alpha, workspace=ws_bytes, out=stats_out)
+        """One pass of the hot path.  Pipelined (default): [exchange + VaR/CVaR of step n] on the side stream
+        overlap [linearize of step n+1] on the main stream; every step still does all of its work inside
+        the timed region (both streams are drained before the clock stops)."""
+        slot = counter[0] & 1
+        counter[0] += 1
+        if pipelined:
+            main_stream.wait_event(ev_free[slot])
+        r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot)
+        if pipelined:
+            ev_lin[slot].record(main_stream)
+        with torch.cuda.stream(side):
+            if pipelined:
+                side.wait_event(ev_lin[slot])
+            sums = work.sums(r)
+            if pipelined:
+                for t in (sums, r["Z"]):
+                    t.record_stream(side)
+            sums, Z_all = rdist.exchange(sums, r["Z"])        # the one collective (no-op at N=1)
+            stats.risk_stats_device(Z_all, args.alpha, workspace=wss[slot], out=stats_out[slot])
+            if pipelined:
+                ev_free[slot].record(side)
         return sums
 
-    use_graph = args.graph and args.workload == "drone" and args.mode == "linearize" and world == 1
     for _ in range(args.warmup):
         step()
     if use_graph:
@@ -334,7 +369,7 @@ def main():
         elapsed = float(t.item())
 
     kern_ms = kern_ms_eager if use_graph else float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    final_stats = (sg.stats if use_graph else stats_out).cpu().numpy()
+    final_stats = (sg.stats if use_graph else stats_out[(counter[0] - 1) & 1]).cpu().numpy()
 
     if rank == 0:
         value = world * M * unit_steps * args.steps / elapsed
@@ -355,7 +390,9 @@ def main():
                                    f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}",
                        "M_per_gpu": M, "S": S, "M_total": world * M,
                        "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step",
-                       "launch": "hipGraph replay of the whole step" if use_graph else "eager stream launches"},
+                       "launch": "hipGraph replay of the whole step" if use_graph else (
+                           "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
+                           if pipelined else "eager, one stream, no overlap between steps")},
             "roofline": {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
