@@ -116,6 +116,10 @@ int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
  *   W        NULL, or  [3 obs][S][2 axes][ld]              W[j,t,axis] = d g[j,t] / d p_axis(t+1),
  *            so that d g[j,t]/d u[s,axis] = W[j,t,axis] * Phi[t,s,axis]: the three obstacles share
  *            Phi, i.e. the same Jacobian in S(S-1) + 6S instead of 3S(S-1) numbers per sample.
+ *   A22      NULL, or  [S][2 axes][ld]  (row-parallel kernel only)  the state-dependent entry of the step
+ *            Jacobian A_t = d x_{t+1} / d x_t = [[1, dt], [-kp dt/m, A22[t]]] per horizontal axis: with W and
+ *            g_up this is the whole linearization in 11 S numbers per sample, enough to evaluate G.u for
+ *            ANY u by an O(S) recursion (rato_drone_rowmax_implicit) instead of an O(S^2) read of Phi.
  *   g_up     [3 obs][S][M]                -g + grad g . u   (:278)
  *   Z        [M] or NULL                  max_{j,t} g - tol at this iterate
  *   part     [nblocks][6*S + 6]           per-block sums (nblocks from rato_drone_linearize_plan):
@@ -126,7 +130,7 @@ int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld,
  */
 int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                          const float* mass, const float* Qsym,
-                         float* G, float* W, float* g_up, float* Z, float* part,
+                         float* G, float* W, float* A22, float* g_up, float* Z, float* part,
                          int32_t cols_per_thread, int32_t samples_per_lane, void* stream);
 
 /* Model.obstacle_avoidance_constraints on given trajectories (drone_risk.py:198-213).
@@ -251,6 +255,17 @@ int rato_saa_rowmax(const float* G, const float* W /* NULL, or the factor of a f
                     int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
                     const float* g_up, const float* us, int32_t n_u,
                     float* m_out, int32_t* arg_out, void* stream);
+
+/*
+ * The same m_out / arg_out for the drone WITHOUT reading the Jacobian: (G_i u)_{j,t} =
+ * sum_a W[j,t,a] dp_a(t+1), where dp is the response of the linearized dynamics
+ * d x_{k+1} = A_k d x_k + B u_k (d x_0 = 0, B = [0, dt/m]^T, A_k from A22: see rato_drone_linearize).
+ * One pass over A22, W, g_up (11 S floats per sample instead of S(S-1) + 9 S); values agree with
+ * rato_saa_rowmax to fp32 rounding.   us [S][3] (n_u = 3); p supplies M, ld, S, dt, kp.
+ */
+int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
+                               const float* W, const float* g_up, const float* us,
+                               float* m_out, int32_t* arg_out, void* stream);
 
 /*
  * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =

@@ -30,7 +30,8 @@ SIGNATURES = {
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [C.c_int32, C.c_int32, c_stream]),
+    "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 10 + [C.c_int32, C.c_int32, c_stream]),
+    "rato_drone_rowmax_implicit": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

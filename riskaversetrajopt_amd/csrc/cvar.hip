@@ -158,18 +158,31 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
   }
   const int rsel = fact ? 0 : r;
   const int nw = 2 * (S - 1);
-  for (int s2 = 0; s2 < S - 1; ++s2) {
-    float g0 = 0.0f, g1 = 0.0f;
-    if (w != 0.0f && s2 < t) {
-      const float* __restrict__ o = row + (size_t)s2 * (2 * RR * tileW);
-      g0 = w0 * o[rsel * tileW];
-      g1 = w1 * o[(RR + rsel) * tileW];
+  constexpr int SB = 8;   // columns per batch: 16 gathers in flight, then 16 wave reductions
+  for (int sb = 0; sb < S - 1; sb += SB) {
+    float g0[SB], g1[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int s2 = sb + i;
+      g0[i] = 0.0f;
+      g1[i] = 0.0f;
+      if (w != 0.0f && s2 < t) {
+        const float* __restrict__ o = row + (size_t)s2 * (2 * RR * tileW);
+        g0[i] = o[rsel * tileW];
+        g1[i] = o[(RR + rsel) * tileW];
+      }
     }
-    const float s0 = rato::wave_sum_dpp(g0);
-    const float s1 = rato::wave_sum_dpp(g1);
-    if (lane == 0) {
-      tr_lds[wave * nw + s2 * 2 + 0] = s0;
-      tr_lds[wave * nw + s2 * 2 + 1] = s1;
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int s2 = sb + i;
+      if (s2 < S - 1) {
+        const float s0 = rato::wave_sum_dpp(w0 * g0[i]);
+        const float s1 = rato::wave_sum_dpp(w1 * g1[i]);
+        if (lane == 0) {
+          tr_lds[wave * nw + s2 * 2 + 0] = s0;
+          tr_lds[wave * nw + s2 * 2 + 1] = s1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -181,7 +194,78 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
   }
 }
 
+// Jacobian-free form of rowmax for the drone: one lane per sample, one pass over the step-Jacobian table
+// A22 [S][2][ld], W [3][S][2][ld] and g_up [3][S][ld] (11 S floats per sample).  (G_i u)_{j,t} =
+// W[j,t,x] dp_x(t+1) + W[j,t,y] dp_y(t+1) with d x_{k+1} = A_k d x_k + B u_k, d x_0 = 0 — the forward form of
+// the adjoint sweep that produced Phi (drone.hip), so the values agree with rowmax_kernel<3, true> to rounding.
+__global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
+    rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22,
+    const float* __restrict__ W, const float* __restrict__ g_up, const float* __restrict__ us,
+    float* __restrict__ m_out, int* __restrict__ arg_out) {
+  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  if (m >= P.M) return;
+  const size_t ld = (size_t)P.ld;
+  const int S = P.S;
+  const float inv_m = 1.0f / mass[m];
+  const float a21 = -P.kp * P.dt * inv_m, dtm = P.dt * inv_m;
+  float px = 0.0f, vx = 0.0f, py = 0.0f, vy = 0.0f;   // d x_t (t = 0)
+  float best = -INFINITY;
+  int best_idx = 0;
+  constexpr int TB = 8;   // steps per batch: the 11 loads of a step do not depend on the recursion, so a batch
+                          // issues 88 loads back to back and only then runs its 8 dependent steps
+  for (int t0 = 0; t0 < S; t0 += TB) {
+    float a2[TB][2], wv[TB][3][2], gu[TB][3];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = (t0 + i < S) ? t0 + i : S - 1;
+      a2[i][0] = A22[((size_t)t * 2 + 0) * ld + m];
+      a2[i][1] = A22[((size_t)t * 2 + 1) * ld + m];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        wv[i][j][0] = W[(((size_t)j * S + t) * 2 + 0) * ld + m];
+        wv[i][j][1] = W[(((size_t)j * S + t) * 2 + 1) * ld + m];
+        gu[i][j] = g_up[((size_t)j * S + t) * ld + m];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = t0 + i;
+      if (t < S) {
+        const float ux = us[t * 3 + 0], uy = us[t * 3 + 1];
+        const float npx = px + P.dt * vx, npy = py + P.dt * vy;
+        const float nvx = a21 * px + a2[i][0] * vx + dtm * ux, nvy = a21 * py + a2[i][1] * vy + dtm * uy;
+        px = npx; py = npy; vx = nvx; vy = nvy;             // d x_{t+1}
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float v = wv[i][j][0] * px + wv[i][j][1] * py - gu[i][j];
+          const int r = j * S + t;
+          if (v > best || (v == best && r < best_idx)) {   // smallest row index among equal values
+            best = v;
+            best_idx = r;
+          }
+        }
+      }
+    }
+  }
+  m_out[m] = best;
+  arg_out[m] = best_idx;
+}
+
 }  // namespace
+
+extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
+                                          const float* W, const float* g_up, const float* us, float* m_out,
+                                          int32_t* arg_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !g_up || !us ||
+      !m_out || !arg_out)
+    return RATO_EINVAL;
+  dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  hipLaunchKernelGGL(drone_rowmax_implicit_kernel, grid, block, 0, rato::as_stream(stream), *p, mass, A22, W, g_up,
+                     us, m_out, arg_out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
 
 extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int32_t R, int32_t S, int64_t M,
                                int64_t ld, const float* g_up, const float* us, int32_t n_u, float* m_out,

@@ -460,7 +460,8 @@ template <bool FACT>
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
     rato_drone_params P, int tile_base, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
-    float* __restrict__ W, float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
+    float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
+    float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
@@ -673,6 +674,11 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
           W[(((size_t)j * S + t) * 2 + 0) * ld + m] = -(2.0f * q00[j] * dx + qs[j] * dy);
           W[(((size_t)j * S + t) * 2 + 1) * ld + m] = -(qs[j] * dx + 2.0f * q11[j] * dy);
         }
+        if (A22) {                         // the step-Jacobian table itself (implicit consumers)
+          const float2_t at = A2[t * ROWS_SAMPLES + lane];
+          A22[((size_t)t * 2 + 0) * ld + m] = at.x;
+          A22[((size_t)t * 2 + 1) * ld + m] = at.y;
+        }
       }
       float m0x = 1.0f, m0y = 1.0f, m1x = 0.0f, m1y = 0.0f;  // mu_{t+1} = e_0^T (x and y axes)
       float accx = 0.0f, accy = 0.0f;                        // sum_s mu_{s+1}[1] u_s  per axis
@@ -788,14 +794,15 @@ extern "C" int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld, int32
 }
 
 extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
-                                    const float* mass, const float* Qsym, float* G, float* W, float* g_up,
-                                    float* Z, float* part, int32_t cols_per_thread,
+                                    const float* mass, const float* Qsym, float* G, float* W, float* A22,
+                                    float* g_up, float* Z, float* part, int32_t cols_per_thread,
                                     int32_t samples_per_lane, void* stream) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part) return RATO_EINVAL;
   int32_t cpt = cols_per_thread, spl = samples_per_lane;
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   if (W && cpt != -1) return RATO_EINVAL;  // the factored output exists for the row-parallel kernel only
+  if (A22 && !W) return RATO_EINVAL;       // the step-Jacobian table goes with the factored output
   hipStream_t st = rato::as_stream(stream);
   if (cpt == -1) {
     const size_t lds = rows_lds_bytes(p->S);
@@ -836,10 +843,10 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
     }
     if (W)
       hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(n_tiles, split), dim3(ROWS_NW * RATO_WAVE), lds, st,
-                         *p, 0, us, dW, mass, Qsym, G, W, g_up, Z, part);
+                         *p, 0, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     else
       hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(n_tiles, split), dim3(ROWS_NW * RATO_WAVE), lds, st,
-                         *p, 0, us, dW, mass, Qsym, G, W, g_up, Z, part);
+                         *p, 0, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

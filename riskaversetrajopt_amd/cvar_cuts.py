@@ -34,6 +34,7 @@ class CvarCutSolver:
         self.alpha = alpha
         self.nU = n_u * S
         self.u_min, self.u_max = float(u_min), float(u_max)
+        self.implicit = None        # drone: (rato_drone_params, mass, A22) -> Jacobian-free evaluation of m(u)
         n = self.nU + 1
         Pu = sp.kron(sp.eye(S), sp.csc_matrix(2.0 * dt * np.asarray(Rcost, dtype=np.float64)))
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
@@ -60,9 +61,17 @@ class CvarCutSolver:
         S, M, n_u = self.S, self.M, self.n_u
         self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
         self.us_dev.copy_(self.u_host, non_blocking=True)
-        _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld, _lib.ptr(g_up_raw),
-                                            _lib.ptr(self.us_dev), n_u, _lib.ptr(self.m), _lib.ptr(self.arg),
-                                            _lib.current_stream()), "rato_saa_rowmax")
+        if self.implicit is not None:
+            import ctypes as C
+            p, mass, A22 = self.implicit
+            _lib.check(self.lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(A22), _lib.ptr(W),
+                                                           _lib.ptr(g_up_raw), _lib.ptr(self.us_dev),
+                                                           _lib.ptr(self.m), _lib.ptr(self.arg),
+                                                           _lib.current_stream()), "rato_drone_rowmax_implicit")
+        else:
+            _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
+                                                _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(self.m),
+                                                _lib.ptr(self.arg), _lib.current_stream()), "rato_saa_rowmax")
         stats.risk_stats_device(self.m, self.alpha, workspace=self.ws, out=self.res[:stats.N_STATS])
         if S > 1:
             _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,

@@ -205,7 +205,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None, factored=None):
+                         want_Z=True, events=None, factored=None, want_A22=False):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -216,6 +216,8 @@ class Model:
            g_up [n_obs][S][M], Z [M]  (views of row-stride-ld buffers),
            du_sum [S][6] (float64: sums over samples of dx_S/du_{s,axis}),
            rhs_sum [6]   (float64: sums of -v_final + v_final_du.u)
+        ``want_A22`` (factored output only): also keep the step-Jacobian table A22 [S][2][M] — with W and g_up
+           the whole linearization in 11 S numbers per sample (rato_drone_rowmax_implicit evaluates G.u from it).
         ``out``: a dict returned by an earlier call (same shapes) whose buffers are reused.
         ``events``: optional (start, end) torch.cuda.Event pair recorded tightly around the
         linearize launch on the launch stream (bench.py's roofline timing).
@@ -235,6 +237,11 @@ class Model:
         Wf = None
         if factored:
             Wf = o["_W"] if (o.get("_W") is not None and o["_W"].shape[-1] == ld) else self._empty(n_obs, S, 2, ld)
+        A22 = None
+        if want_A22:
+            if not factored:
+                raise _lib.RatoError("A22 goes with the factored output (row-parallel kernel)")
+            A22 = o["_A22"] if o.get("_A22") is not None else self._empty(S, 2, ld)
         g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
         Z = (o["_Z"] if "_Z" in o else self._empty(ld)) if want_Z else None
         part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) \
@@ -244,7 +251,7 @@ class Model:
             events[0].record()
         _lib.check(self._lib.rato_drone_linearize(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G), _lib.ptr(Wf),
-            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
+            _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
             "rato_drone_linearize")
         if events is not None:
             events[1].record()
@@ -253,7 +260,8 @@ class Model:
                 "du_sum": sums[:6 * S].view(S, 6), "rhs_sum": sums[6 * S:], "sums": sums,
                 "part": part, "M": M, "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt,
                 "samples_per_lane": spl, "tile": tile, "factored": bool(factored),
-                "W": (Wf[..., :M] if factored else None), "_W": Wf}
+                "W": (Wf[..., :M] if factored else None), "_W": Wf,
+                "A22": (A22[..., :M] if A22 is not None else None), "_A22": A22}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
@@ -441,14 +449,16 @@ class Model:
         return us_sol, t_risk_sol
 
     # ---- L4 at large M: reduced (u, slack) problem with device CVaR cuts ----------------------
-    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False):
+    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False, implicit=True):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
         planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
-        Same optimum as define/update_problem + solve; -> (us_sol (S,n_u), t_risk, info)."""
+        Same optimum as define/update_problem + solve; -> (us_sol (S,n_u), t_risk, info).
+        ``implicit``: evaluate the constraint rows of a candidate u from the step-Jacobian table (O(S) per sample,
+        rato_drone_rowmax_implicit) instead of reading the packed Jacobian (O(S^2), rato_saa_rowmax)."""
         if self.method != 'saa':
             raise NotImplementedError("the reduced solve covers the 'saa' method")
-        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None))
+        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit)
         self._lin_buffers = r
         M, S = r["M"], self.S
         cs = getattr(self, "_cut_solver", None)
@@ -459,6 +469,10 @@ class Model:
             self._cut_solver = cs
         final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
         final_rhs = r["rhs_sum"].cpu().numpy() / M
+        cs.implicit = None
+        if implicit:
+            dW, mass, Qsym, _ = self._inputs(None)
+            cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"])
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2),
                         tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info

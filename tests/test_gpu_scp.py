@@ -195,3 +195,69 @@ def test_driving_reduced_scp_matches_full_scp():
     assert np.isfinite(out["us"]).all()
     st = big.monte_carlo_statistics(out["us"], alpha=0.05)
     assert st["cvar"] < 0.2
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (50, 1000), (2, 5), (125, 70)])
+def test_rowmax_implicit_matches_explicit_and_oracle(S, M):
+    """m_i(u) = max_r (G_i u - g_up_i)_r from the step-Jacobian table (O(S) recursion, no Jacobian read) ==
+    the same from the packed Jacobian == the fp64 oracle's dense g_obs_du @ u."""
+    import ctypes as C
+    import torch
+    from riskaversetrajopt_amd import _lib
+    o, d = _drone(M, S)
+    us = graze(S)
+    r = d.linearize_device(us, want_A22=True)
+    assert r["A22"].shape == (S, 2, M)
+    rng = np.random.RandomState(4)
+    u_new = (us + 0.3 * rng.randn(S, 3)).astype(np.float32)
+    u_dev = torch.as_tensor(u_new, device=r["G"].device).contiguous()
+    lib = d._lib
+    ld = r["_g_up"].shape[-1]
+    dW, mass, Qsym, _ = d._inputs(None)
+    out = {}
+    for name in ("explicit", "implicit"):
+        m = torch.empty(M, dtype=torch.float32, device=u_dev.device)
+        a = torch.empty(M, dtype=torch.int32, device=u_dev.device)
+        if name == "explicit":
+            _lib.check(lib.rato_saa_rowmax(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), r["tile"], 3, S, M, ld,
+                                           _lib.ptr(r["_g_up"]), _lib.ptr(u_dev), 3, _lib.ptr(m), _lib.ptr(a),
+                                           _lib.current_stream()), "rato_saa_rowmax")
+        else:
+            p = d._params(M, ld)
+            _lib.check(lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(r["_A22"]),
+                                                      _lib.ptr(r["_W"]), _lib.ptr(r["_g_up"]), _lib.ptr(u_dev),
+                                                      _lib.ptr(m), _lib.ptr(a), _lib.current_stream()),
+                       "rato_drone_rowmax_implicit")
+        out[name] = (m.cpu().numpy().astype(np.float64), a.cpu().numpy())
+    # oracle: dense fp64 rows
+    _, _, _, gdu_o, gup_o = o.get_all_constraints_coeffs(us)                  # (M,3,S,3S), (M,3,S)
+    rows = (gdu_o.reshape(M, 3 * S, 3 * S) @ u_new.astype(np.float64).reshape(-1)) - gup_o.reshape(M, 3 * S)
+    m_o, a_o = rows.max(axis=1), rows.argmax(axis=1)
+    scale = max(1.0, np.abs(rows).max())
+    for name in ("explicit", "implicit"):
+        m, a = out[name]
+        assert np.max(np.abs(m - m_o)) < 2e-4 * scale, (name, np.max(np.abs(m - m_o)))
+        srt = np.sort(rows, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-3 * scale if S * 3 > 1 else np.ones(M, bool)
+        assert np.array_equal(a[clear], a_o[clear]), name
+    assert np.max(np.abs(out["implicit"][0] - out["explicit"][0])) < 2e-5 * scale
+
+
+def test_reduced_solve_implicit_equals_explicit_oracle_path():
+    from riskaversetrajopt_amd import scp
+    S, M = 20, 2000
+    _, d = _drone(M, S, alpha=0.1, seed=5)
+    start = scp.run_drone_reduced(d, num_scp_iters_max=6)["us"]      # a point on the SCP path (slack ~ 0)
+    us_i, t_i, info_i = d.solve_reduced(start, 6, implicit=True)
+    us_e, t_e, info_e = d.solve_reduced(start, 6, implicit=False)
+    assert info_i["status"] == info_e["status"] == 'solved' and info_i["cuts"] >= 1
+    assert info_i["slack"] < 1e-3
+    np.testing.assert_allclose(us_i, us_e, rtol=0, atol=5e-5)
+    assert abs(t_i - t_e) < 2e-4 and abs(info_i["slack"] - info_e["slack"]) < 1e-5
+    # far from the path (huge slack) the optimum is flat in u: same objective, not the same u
+    far = graze(S) * 0.7
+    _, _, fi = d.solve_reduced(far, 3, implicit=True)
+    _, _, fe = d.solve_reduced(far, 3, implicit=False)
+    Pd, q = d._cut_solver.P.toarray(), d._cut_solver.q
+    obj = lambda f: (lambda z: 0.5 * z @ Pd @ z + q @ z)(np.concatenate([f["us"].reshape(-1), [f["slack"]]]))
+    assert abs(obj(fi) - obj(fe)) < 1e-6 * abs(obj(fe))
