@@ -273,8 +273,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
 // Same structure as drone_linearize_rows_kernel: a workgroup owns 64 samples;
 //   phase 0  stage the noise tile, the controls and the (sample-independent) ego tables in LDS;
 //   phase 1  wave 0 rolls the 4-state pedestrian out and leaves K_k = dt w_r (I - n n^T)/r (3 floats)
-//            and the pedestrian position q_{k+1} (2 floats) in LDS: 20 B per sample-step;
-//   phase 2  all waves pull row tasks from an LDS queue and sweep row t with the 8-state adjoint
+//            and the pedestrian position q_{k+1} (2 floats) in LDS: 20 B per sample-step, publishing
+//            its progress in LDS after every step, then joins phase 2;
+//   phase 2  (overlapped with phase 1: row t only needs steps 0..t; rows are taken shortest first)
+//            all waves pull row tasks from an LDS queue and sweep row t with the 8-state adjoint
 //            eta_{t+1} = grad_x g_t = (-n, 0, 0, +n, 0, 0),  eta_k = eta_{k+1} J_k,
 //            d g_t / d u_{s,i} = dt * eta_{s+1}[2 + i]   (u_0 drives v_ego, u_1 drives phi_ego),
 //            accumulating the row's dot product with u for g_up (driving.py:295).
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   const size_t M = (size_t)P.M;
   const int S = P.S;
-  const int lane = threadIdx.x & (RATO_WAVE - 1), wave = threadIdx.x / RATO_WAVE;
+  const int lane = threadIdx.x & (RATO_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RATO_WAVE);   // scalar: wave-level branches stay scalar
   // (no __restrict__: QP[t] holds step t's noise until the rollout overwrites it with q_{t+1})
   cfloat4_t* EC = reinterpret_cast<cfloat4_t*>(car_lds_raw);                 // [S] (dt c, dt s, -dt v s, dt v c)
   cfloat2_t* KK = reinterpret_cast<cfloat2_t*>(EC + S);                      // [S][64] (k00, k01)
@@ -354,21 +357,28 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         US[t] = u2;
       }
     }
-    if (threadIdx.x == 0) *head = 0;
+    if (threadIdx.x == 0) {
+      head[0] = 0;
+      head[1] = 0;   // rollout progress: number of finished steps
+    }
   }
   __syncthreads();
 
-  // ---- phase 1: wave 0 rolls the pedestrian out (driving.py:145-158,196-203)
+  // ---- phase 1 (wave 0) overlapped with phase 2 (the other waves, then everybody): row t only needs steps
+  // 0..t, so the rows are swept shortest first behind the rollout, which publishes its progress in LDS.
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint* prog = (lds_vint*)(head + 1);
   if (wave == 0) {
     PedConsts c;
     c.w_s = w_s;
     c.w_r = w_r;
     c.cn = sqrtf(P.dt) * P.beta;
     float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+    cfloat2_t xi = QP[lane], e = EGOP[0];
     for (int t = 0; t < S; ++t) {
       const int slot = t * CROWS_SAMPLES + lane;
-      const cfloat2_t xi = QP[slot];
-      const cfloat2_t e = EGOP[t];
+      const int tn = (t + 1 < S) ? t + 1 : t;   // next step's inputs are fetched before this step's table stores
+      const cfloat2_t xi_n = QP[tn * CROWS_SAMPLES + lane], e_n = EGOP[tn];
       float n0, n1, rinv;
       ped_step(P, c, e.x, e.y, xi.x, xi.y, px, py, vx, vy, n0, n1, rinv);
       const float kr = P.dt * w_r * rinv;  // dt w_r (I - n n^T)/r at state t
@@ -381,22 +391,18 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       q.x = px;
       q.y = py;
       QP[slot] = q;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) *prog = t + 1;
+      xi = xi_n;
+      e = e_n;
     }
   }
-  __syncthreads();
 
-  // ---- Z = max_t g_t - tol (one wave; cheap)
-  if (Z && wave == CROWS_NW - 1) {
-    float zmax = -INFINITY;
-    for (int t = 0; t < S; ++t) {
-      const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e = EGOP[t + 1];
-      const float dx = e.x - q.x, dy = e.y - q.y;
-      zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
-    }
-    if (valid) Z[m] = zmax - P.tol;
-  }
-
-  // ---- phase 2: row tasks, longest first
+  // ---- phase 2: row tasks in ascending order (task S: Z = max_t g_t - tol from the q table)
+  auto wait_steps = [&](int need) {
+    while (*prog < need) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   constexpr int RT = CROWS_SAMPLES;
   const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * RT;
   float* __restrict__ Gt = G + (size_t)blockIdx.x * tile_floats + lane;
@@ -406,45 +412,59 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     return __builtin_amdgcn_readfirstlane(v);
   };
   int task = next_task();
-  while (task < S) {
-    const int t = S - 1 - task;
-    const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e1 = EGOP[t + 1];
-    const float dx = e1.x - q.x, dy = e1.y - q.y;
-    const float r = sqrtf(dx * dx + dy * dy);
-    const float n0 = dx / r, n1 = dy / r;
-    const float gt = -(r - P.d_min);                       // driving.py:223-230,269
-    float epx = -n0, epy = -n1, ev = 0.0f, eph = 0.0f;     // eta (ego part)
-    float qx = n0, qy = n1, qvx = 0.0f, qvy = 0.0f;        // eta (pedestrian part)
-    float acc = 0.0f;
-    float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * RT);
-    for (int k = t; k >= 1; --k) {
-      const int slot = k * CROWS_SAMPLES + lane;
-      const cfloat2_t kk = KK[slot];
-      const float k11 = K11[slot];
-      const cfloat4_t c = EC[k];
-      const cfloat2_t u2 = US[k - 1];
-      const float f0 = qvx * kk.x + qvy * kk.y, f1 = qvx * kk.y + qvy * k11;   // (eta_qv) K
-      const float nev = ev + epx * c.x + epy * c.y;
-      const float neph = eph + epx * c.z + epy * c.w;
-      const float nqvx = qvx + P.dt * qx;
-      const float nqvy = qvy + P.dt * qy - ks * (qvx + qvy);
-      epx -= f0;
-      epy -= f1;
-      qx += f0;
-      qy += f1;
-      ev = nev;
-      eph = neph;
-      qvx = nqvx;
-      qvy = nqvy;
-      const float o0 = P.dt * ev, o1 = P.dt * eph;         // d g_t / d u_{k-1, 0|1}
-      acc += o0 * u2.x + o1 * u2.y;
-      if (valid) {
-        float* __restrict__ o = Grow + (k - 1) * (2 * RT);
-        o[0] = o0;
-        o[RT] = o1;
+  while (task <= S) {
+    if (task == S) {
+      wait_steps(S);
+      if (Z) {
+        float zmax = -INFINITY;
+        for (int t = 0; t < S; ++t) {
+          const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e = EGOP[t + 1];
+          const float dx = e.x - q.x, dy = e.y - q.y;
+          zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
+        }
+        if (valid) Z[m] = zmax - P.tol;
       }
+    } else {
+      const int t = task;
+      wait_steps(t + 1);
+      const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e1 = EGOP[t + 1];
+      const float dx = e1.x - q.x, dy = e1.y - q.y;
+      const float r = sqrtf(dx * dx + dy * dy);
+      const float n0 = dx / r, n1 = dy / r;
+      const float gt = -(r - P.d_min);                       // driving.py:223-230,269
+      float epx = -n0, epy = -n1, ev = 0.0f, eph = 0.0f;     // eta (ego part)
+      float qx = n0, qy = n1, qvx = 0.0f, qvy = 0.0f;        // eta (pedestrian part)
+      float acc = 0.0f;
+      float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * RT);
+      for (int k = t; k >= 1; --k) {
+        const int slot = k * CROWS_SAMPLES + lane;
+        const cfloat2_t kk = KK[slot];
+        const float k11 = K11[slot];
+        const cfloat4_t c = EC[k];
+        const cfloat2_t u2 = US[k - 1];
+        const float f0 = qvx * kk.x + qvy * kk.y, f1 = qvx * kk.y + qvy * k11;   // (eta_qv) K
+        const float nev = ev + epx * c.x + epy * c.y;
+        const float neph = eph + epx * c.z + epy * c.w;
+        const float nqvx = qvx + P.dt * qx;
+        const float nqvy = qvy + P.dt * qy - ks * (qvx + qvy);
+        epx -= f0;
+        epy -= f1;
+        qx += f0;
+        qy += f1;
+        ev = nev;
+        eph = neph;
+        qvx = nqvx;
+        qvy = nqvy;
+        const float o0 = P.dt * ev, o1 = P.dt * eph;         // d g_t / d u_{k-1, 0|1}
+        acc += o0 * u2.x + o1 * u2.y;
+        if (valid) {
+          float* __restrict__ o = Grow + (k - 1) * (2 * RT);
+          o[0] = o0;
+          o[RT] = o1;
+        }
+      }
+      if (valid) g_up[(size_t)t * M + m] = -gt + acc;        // driving.py:295
     }
-    if (valid) g_up[(size_t)t * M + m] = -gt + acc;        // driving.py:295
     task = next_task();
   }
 }
