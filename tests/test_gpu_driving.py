@@ -152,3 +152,50 @@ def test_full_size_C3_properties():
     _, _, _, gdu_o, _ = sub.get_all_constraints_coeffs(us)
     gdu = d.expand_g_obs_du(Gp[..., torch.as_tensor(idx, device=g.device)])
     tol.assert_jac_close(gdu, gdu_o, what="g_obs_du (sampled)")
+
+
+def test_C5_shard_size_properties():
+    """BASELINE config 5 is driving M = 1e6 over 8 GPUs: one rank's shard is 125,000 samples.  Size-independent
+    properties at that size on one GPU (inputs drawn on the device), plus a sampled comparison with the oracle."""
+    import torch
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving, stats
+    from riskaversetrajopt_amd.driving import untile
+    S, M = 40, 125000
+    dev = torch.device("cuda:0")
+    dW, x0, ws, wr = driving.sample_uncertain_parameters_device(M, S, seed=11, device=dev)
+    d = driving.Model.from_device(S, dW, x0, ws, wr, 'saa', 0.05)
+    us = swerve(S)
+    r = d.linearize_device(us)
+    again = d.linearize_device(us)
+    assert bool((again["G"] == r["G"]).all()) and bool((again["g_up"] == r["g_up"]).all())   # run-to-run bitwise
+    # linearity: g_up + g == G.u through the packed layout
+    _, _, g = d.eval_device(us, want_g=True)
+    Gp = untile(r["G"], M)
+    u = torch.as_tensor(us, dtype=torch.float32, device=dev)
+    Gu = torch.zeros_like(g)
+    for t in range(1, S):
+        off = t * (t - 1) // 2
+        Gu[t] = (Gp[off:off + t] * u[:t, :, None]).sum(dim=(0, 1))
+    assert (r["g_up"] + g - Gu).abs().max().item() < 2e-3
+    Z_eval, _, _ = d.eval_device(us)
+    assert (Z_eval - r["Z"]).abs().max().item() <= 1e-5
+    # statistics: exact selection vs a host sort of the same fp32 Z
+    Zh = r["Z"].cpu().numpy().astype(np.float64)
+    st = stats.risk_stats(r["Z"], 0.05)
+    srt = np.sort(Zh)
+    k = M - int(np.floor(0.05 * M)) - 1
+    assert st["var"] == srt[k]
+    assert abs(st["cvar"] - (srt[k] + np.maximum(Zh - srt[k], 0).sum() / (0.05 * M))) < 1e-9 * max(1.0, abs(st["cvar"]))
+    # sampled Jacobian rows vs the fp64 oracle on the same (device-drawn) inputs
+    idx = np.arange(0, M, 9973)
+    ti = torch.as_tensor(idx, device=dev)
+    DWs = np.zeros((len(idx), S, 8))
+    DWs[:, :, 6:8] = dW[:, :, ti].permute(2, 0, 1).double().cpu().numpy()
+    from riskaversetrajopt_amd import driving_params as DP
+    ego0 = np.tile(np.asarray(DP.state_init, dtype=np.float64)[:4], (len(idx), 1))
+    sub = ocar.Model(np.concatenate([ego0, x0[:, ti].T.double().cpu().numpy()], axis=1),
+                     ws[ti].double().cpu().numpy(), wr[ti].double().cpu().numpy(), DWs)
+    _, _, _, gdu_o, gup_o = sub.get_all_constraints_coeffs(us)
+    tol.assert_jac_close(d.expand_g_obs_du(Gp[..., ti]), gdu_o, what="g_obs_du (sampled)")
+    np.testing.assert_allclose(r["g_up"][:, ti].T.cpu().numpy(), gup_o.reshape(len(idx), S), rtol=5e-5, atol=2e-4)
