@@ -20,12 +20,17 @@ constexpr float MU_NOM = 0.10f;  // hopper.py:68
 // on MI355X against the fp64 oracle over 5e4 samples x 40 contacts, p in [-3, 3]: max |error| 1.5e-6 on
 // h = fx - mu fz, 4e-8 on mu, 3.3e-6 on dh/dpx (tolerances 2e-5 / 2e-6 / 2e-5 in the tests), at about
 // half the time of the OCML sincosf path (0.20 -> 0.10 ms for the derivative kernel at M = 5e4).
-__device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
-  const float r = x * 0.15915494309189535f;  // 1/(2 pi)
-  sn = __builtin_amdgcn_sinf(r);
-  cs = __builtin_amdgcn_cosf(r);
-}
+// (__builtin_amdgcn_sinf / cosf on phases pre-scaled by 1/(2 pi))
 
+typedef float hfloat2 __attribute__((ext_vector_type(2)));
+
+// VALU-issue bound (measured: ~280 wave-instructions per contact before this form, 93 % of the issue rate), so the
+// instruction count is the roofline.  Features are processed in PAIRS with packed fp32 math (v_pk_fma_f32 /
+// v_pk_mul_f32: two features per instruction): per pair one packed FMA for the two phases (theta and tau are
+// pre-scaled to revolutions at load), 2 + 2 hardware sin / cos, and one packed FMA per accumulated quantity with
+// the loop-invariant products a*theta, a*theta^2 kept in registers.  The lambda-weighted Hessian sums are
+// reduced per wave with DPP into an LDS table and combined once per workgroup at the end (no barrier per
+// contact); lambda for a contact is fetched before that contact's trig block so that its latency is covered.
 template <bool DERIV>
 __global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
     int M_, int C, int cpg, const float* __restrict__ px, const float* __restrict__ fx,
@@ -33,65 +38,86 @@ __global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
     const float* __restrict__ tau, const float* __restrict__ lam, float* __restrict__ Z, int z_atomic,
     float* __restrict__ h, float* __restrict__ dh_dfz, float* __restrict__ dh_dpx,
     float* __restrict__ part_hess) {
+  static_assert(NF % 2 == 0, "features are processed in pairs");
+  constexpr int NP = NF / 2;
+  constexpr float INV_2PI = 0.15915494309189535f;
   const size_t M = (size_t)M_;
   const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
-  float fa[NF], fth[NF], ftau[NF];
+  hfloat2 fa[NP], rth[NP], rtau[NP];   // amplitude | theta / 2 pi | tau / 2 pi
+  hfloat2 ath[DERIV ? NP : 1], ath2[DERIV ? NP : 1];   // a theta | a theta^2
 #pragma unroll
-  for (int k = 0; k < NF; ++k) {
-    fa[k] = a[(size_t)k * M + m];
-    fth[k] = theta[(size_t)k * M + m];
-    ftau[k] = tau[(size_t)k * M + m];
+  for (int k = 0; k < NP; ++k) {
+    hfloat2 th, ta;
+    fa[k].x = a[(size_t)(2 * k) * M + m];
+    fa[k].y = a[(size_t)(2 * k + 1) * M + m];
+    th.x = theta[(size_t)(2 * k) * M + m];
+    th.y = theta[(size_t)(2 * k + 1) * M + m];
+    ta.x = tau[(size_t)(2 * k) * M + m];
+    ta.y = tau[(size_t)(2 * k + 1) * M + m];
+    rth[k] = th * INV_2PI;
+    rtau[k] = ta * INV_2PI;
+    if (DERIV) {
+      ath[k] = fa[k] * th;
+      ath2[k] = ath[k] * th;
+    }
   }
   const int c0 = blockIdx.y * cpg;
   const int c1 = min(C, c0 + cpg);
   float zmax = -INFINITY;
-  __shared__ float red[RATO_BLOCK / RATO_WAVE][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ float hess_lds[];   // [waves][cpg][2]
+  const bool want_hess = DERIV && part_hess;
   for (int c = c0; c < c1; ++c) {
     const float p = px[c], f_x = fx[c], f_z = fz[c];
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    float l = 0.0f;
+    if (want_hess && valid) l = lam[(size_t)c * M + m];   // consumed after the trig block
+    hfloat2 p2;
+    p2.x = p;
+    p2.y = p;
+    hfloat2 s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f}, s2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < NF; ++k) {
-      const float arg = fth[k] * p + ftau[k];
+    for (int k = 0; k < NP; ++k) {
+      const hfloat2 r = rth[k] * p2 + rtau[k];   // phase in revolutions (hardware trig unit)
+      hfloat2 cs;
+      cs.x = __builtin_amdgcn_cosf(r.x);
+      cs.y = __builtin_amdgcn_cosf(r.y);
+      s0 += fa[k] * cs;
       if (DERIV) {
-        float sn, cs;
-        fast_sincos(arg, sn, cs);
-        s0 += fa[k] * cs;
-        const float ath = fa[k] * fth[k];
-        s1 += ath * sn;
-        s2 += ath * fth[k] * cs;
-      } else {
-        s0 += fa[k] * __builtin_amdgcn_cosf(arg * 0.15915494309189535f);
+        hfloat2 sn;
+        sn.x = __builtin_amdgcn_sinf(r.x);
+        sn.y = __builtin_amdgcn_sinf(r.y);
+        s1 += ath[k] * sn;
+        s2 += ath2[k] * cs;
       }
     }
-    const float mu = MU_NOM + s0;
+    const float mu = MU_NOM + (s0.x + s0.y);
     const float hv = f_x - mu * f_z;  // hopper.py:322
     zmax = fmaxf(zmax, hv);
     if (valid) {
       if (h) h[(size_t)c * M + m] = hv;
       if (DERIV) {
         if (dh_dfz) dh_dfz[(size_t)c * M + m] = -mu;
-        if (dh_dpx) dh_dpx[(size_t)c * M + m] = s1 * f_z;  // -mu'(p) fz
+        if (dh_dpx) dh_dpx[(size_t)c * M + m] = (s1.x + s1.y) * f_z;  // -mu'(p) fz
       }
     }
-    if (DERIV && part_hess) {  // wave-uniform
-      const float l = valid ? lam[(size_t)c * M + m] : 0.0f;
-      const float d1 = rato::wave_sum(l * s1);        // lam * d2h/(dpx dfz) = -lam mu'
-      const float d2 = rato::wave_sum(l * s2 * f_z);  // lam * d2h/dpx^2   = -lam mu'' fz
+    if (want_hess) {  // wave-uniform
+      const float d1 = rato::wave_sum_dpp(l * (s1.x + s1.y));        // lam * d2h/(dpx dfz) = -lam mu'
+      const float d2 = rato::wave_sum_dpp(l * (s2.x + s2.y) * f_z);  // lam * d2h/dpx^2   = -lam mu'' fz
       if (lane == 0) {
-        red[wave][0] = d1;
-        red[wave][1] = d2;
+        hess_lds[(wave * cpg + (c - c0)) * 2 + 0] = d1;
+        hess_lds[(wave * cpg + (c - c0)) * 2 + 1] = d2;
       }
-      __syncthreads();
-      if (threadIdx.x < 2) {
-        float acc = 0.0f;
+    }
+  }
+  if (want_hess) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (c1 - c0) * 2; i += RATO_BLOCK) {
+      float acc = 0.0f;
 #pragma unroll
-        for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += red[w][threadIdx.x];
-        part_hess[((size_t)blockIdx.x * C + c) * 2 + threadIdx.x] = acc;
-      }
-      __syncthreads();
+      for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += hess_lds[w * cpg * 2 + i];   // fixed order
+      part_hess[((size_t)blockIdx.x * C + c0) * 2 + i] = acc;
     }
   }
   if (Z && valid) {
@@ -133,7 +159,7 @@ extern "C" int rato_hopper_slip(int32_t M, int32_t C, const float* px, const flo
   dim3 grid(nblk, groups), block(RATO_BLOCK);
   const bool deriv = dh_dfz || dh_dpx || part_hess;
   if (deriv)
-    hipLaunchKernelGGL(hopper_slip_kernel<true>, grid, block, 0, st, M, C, cpg, px, fx, fz, a, theta, tau, lam, Z,
+    hipLaunchKernelGGL(hopper_slip_kernel<true>, grid, block, (size_t)(RATO_BLOCK / RATO_WAVE) * cpg * 2 * sizeof(float), st, M, C, cpg, px, fx, fz, a, theta, tau, lam, Z,
                        z_atomic, h, dh_dfz, dh_dpx, part_hess);
   else
     hipLaunchKernelGGL(hopper_slip_kernel<false>, grid, block, 0, st, M, C, cpg, px, fx, fz, a, theta, tau, lam, Z,
