@@ -280,6 +280,22 @@ int rato_saa_tail_rows(const float* G, const float* W /* NULL or factor */, int6
                        const float* m_vals, const int32_t* arg, float tstar, float lambda,
                        const double* stats_dev, double alphaM, float* part, void* stream);
 
+/*
+ * Re-linearized cuts (cut recycling across SCP iterations).  A cut is a tail weighting w (from m_vals and the
+ * rato_risk_stats record that was computed on them) plus the arg-max row of every sample; it stays a valid cut
+ * under a NEW linearization:  CVaR(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}].
+ * K cuts kept in rings  m_base [slot][M], arg_base [slot][M], stats_base [slot][stats_stride >= 10 doubles]  are
+ * evaluated in one launch:
+ *   part[blk][k][0 .. 2(S-1))  block sums of w_i G_i[r_i, (s,g)]     (k-th entry of slots[], a device array)
+ *   part[blk][k][2(S-1)]       block sum  of w_i g_up_{i,r_i}
+ * Reduce with rato_sum_partials(part, nblk, K * (2(S-1) + 1), ...).
+ */
+int rato_saa_tail_rows_batch(const float* G, const float* W /* NULL or factor */, int64_t ld, int32_t tile,
+                             int32_t R, int32_t S, int64_t M, const float* g_up,
+                             const float* m_base, const int32_t* arg_base, const double* stats_base,
+                             int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM, float* part,
+                             void* stream);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,

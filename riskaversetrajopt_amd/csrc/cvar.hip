@@ -194,6 +194,93 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
   }
 }
 
+// Re-linearized cuts.  A cut of the CVaR constraint is a tail weighting (w_i in [0,1], sum = alpha M) plus one row
+// r_i per sample; under ANY linearization  CVaR_alpha(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}],
+// so the (w, r) of cuts found in the previous SCP iteration give valid cuts for the new one.  This kernel
+// evaluates K of them in one launch: blockIdx.y = k picks ring slot slots[k] (m values, arg-max rows and the
+// risk statistics that define w); part[blk][k][0 .. 2(S-1)) = block sums of w_i G_i[r_i, (s,g)],
+// part[blk][k][2(S-1)] = block sum of w_i g_up_{i,r_i}.
+template <int R>
+__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
+    const float* __restrict__ G, const float* __restrict__ W, long ld, int tileW, int S, long M,
+    const float* __restrict__ g_up, const float* __restrict__ m_base, const int* __restrict__ arg_base,
+    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
+    float* __restrict__ part) {
+  extern __shared__ float trb_lds[];   // [4 waves][2*(S-1) + 1]
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots[kk];
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  const double* __restrict__ st = stats_base + slot * stats_stride;
+  const float tstar = (float)st[0];
+  const double n_gt = st[8], n_eq = st[9];
+  const double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
+  const float lambda = (float)fmin(fmax(l, 0.0), 1.0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = m < M;
+  float w = 0.0f;
+  int t = 0, r = 0;
+  if (valid) {
+    const float mv = mvals[m];
+    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+    const int a = arg[m];
+    r = a / S;
+    t = a - r * S;
+  }
+  const size_t n_pairs = (size_t)S * (S - 1) / 2;
+  const bool fact = (W != nullptr);
+  const int RR = fact ? 1 : R;
+  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * RR * tileW) + (m % tileW);
+  const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
+  float w0 = w, w1 = w, wg = 0.0f;
+  if (w != 0.0f) {
+    wg = w * g_up[((size_t)r * S + t) * ld + m];
+    if (fact) {
+      w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m];
+      w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m];
+    }
+  }
+  const int rsel = fact ? 0 : r;
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  constexpr int SB = 8;
+  for (int sb = 0; sb < S - 1; sb += SB) {
+    float g0[SB], g1[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int s2 = sb + i;
+      g0[i] = 0.0f;
+      g1[i] = 0.0f;
+      if (w != 0.0f && s2 < t) {
+        const float* __restrict__ o = row + (size_t)s2 * (2 * RR * tileW);
+        g0[i] = o[rsel * tileW];
+        g1[i] = o[(RR + rsel) * tileW];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int s2 = sb + i;
+      if (s2 < S - 1) {
+        const float s0 = rato::wave_sum_dpp(w0 * g0[i]);
+        const float s1 = rato::wave_sum_dpp(w1 * g1[i]);
+        if (lane == 0) {
+          trb_lds[wave * nc + s2 * 2 + 0] = s0;
+          trb_lds[wave * nc + s2 * 2 + 1] = s1;
+        }
+      }
+    }
+  }
+  const float sg = rato::wave_sum_dpp(wg);
+  if (lane == 0) trb_lds[wave * nc + nw] = sg;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += trb_lds[wv * nc + i];
+    part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
+  }
+}
+
 // Jacobian-free form of rowmax for the drone: one lane per sample, one pass over the step-Jacobian table
 // A22 [S][2][ld], W [3][S][2][ld] and g_up [3][S][ld] (11 S floats per sample).  (G_i u)_{j,t} =
 // W[j,t,x] dp_x(t+1) + W[j,t,y] dp_y(t+1) with d x_{k+1} = A_k d x_k + B u_k, d x_0 = 0 — the forward form of
@@ -289,6 +376,27 @@ extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int
                        n_u, m_out, arg_out);
   else
     return RATO_EINVAL;
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_saa_tail_rows_batch(const float* G, const float* W, int64_t ld, int32_t tile, int32_t R, int32_t S,
+                                        int64_t M, const float* g_up, const float* m_base, const int32_t* arg_base,
+                                        const double* stats_base, int64_t stats_stride, const int32_t* slots,
+                                        int32_t K, double alphaM, float* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!G || !g_up || !m_base || !arg_base || !stats_base || !slots || !part || M <= 0 || S < 2 || K < 1 || K > 65535 ||
+      ld < M || stats_stride < 10 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
+    return RATO_EINVAL;
+  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (S - 1) + 1) * sizeof(float);
+  dim3 grid((unsigned)rato::nblocks_for((int32_t)M), (unsigned)K), block(RATO_BLOCK);
+  hipStream_t st = rato::as_stream(stream);
+  if (R == 3)
+    hipLaunchKernelGGL(tail_rows_batch_kernel<3>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, g_up, m_base,
+                       arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
+  else
+    hipLaunchKernelGGL(tail_rows_batch_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, g_up, m_base,
+                       arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

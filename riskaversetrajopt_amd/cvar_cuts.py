@@ -17,6 +17,12 @@ evaluates m(u) (one streaming read of G, rato_saa_rowmax), CVaR/VaR (rato_risk_s
 (1/(alpha M)) sum_{tail} G_i[r*_i, :] (rato_saa_tail_rows).  The optimum is the optimum of the reference's
 QP (same feasible set and objective after projecting out y, t), so SCP iterates are comparable; checked
 against the full QP at small M in tests/test_gpu_scp.py.
+
+Cut recycling.  A cut is a tail weighting w (sum = alpha M) and one row r_i per sample; under ANY linearization
+CVaR(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}].  The (w, r) of the cuts that were active at
+the previous SCP iteration's solution are therefore kept on the device (rings of m values / arg-max rows / risk
+statistics) and re-evaluated against the new linearization in ONE launch (rato_saa_tail_rows_batch) before the
+loop starts: near convergence consecutive linearizations are close and the master starts almost solved.
 """
 import time
 
@@ -28,7 +34,8 @@ from . import _lib, dense_qp, stats
 
 
 class CvarCutSolver:
-    def __init__(self, lib, device, *, n_u, S, M, ld, R, alpha, dt, Rcost, slack_penalty, u_min, u_max):
+    def __init__(self, lib, device, *, n_u, S, M, ld, R, alpha, dt, Rcost, slack_penalty, u_min, u_max,
+                 recycle=True):
         self.lib, self.device = lib, device
         self.n_u, self.S, self.M, self.ld, self.R = n_u, S, M, ld, R
         self.alpha = alpha
@@ -41,24 +48,38 @@ class CvarCutSolver:
         self.q = np.zeros(n)
         self.q[-1] = float(slack_penalty)
         self.c_s = (M * (1.0 - alpha) - 1.0) / (alpha * M)
-        # device scratch
+        # device scratch.  Every oracle call writes into one slot of three rings (m values, arg-max rows,
+        # [statistics (10) | subgradient sums (2(S-1))]); slots of cuts worth recycling survive the solve.
         e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=device)
-        self.m = e(M)
-        self.arg = e(M, dt=torch.int32)
-        self.part = e((M + 255) // 256, 2 * (S - 1)) if S > 1 else None
+        self.recycle = recycle
+        self.keep_max = 48
+        self.cap = (160 if recycle else 1) + 1          # last slot: scratch for calls beyond the ring
+        self.nres = stats.N_STATS + 2 * max(S - 1, 0)
+        self.ring_m = e(self.cap, M)
+        self.ring_arg = e(self.cap, M, dt=torch.int32)
+        self.ring_res = torch.zeros((self.cap, self.nres), dtype=torch.float64, device=device)
+        self.keep = []                                   # slots kept from the previous solve
+        self.nblk = (M + 255) // 256
+        self.part = e(self.nblk, 2 * (S - 1)) if S > 1 else None
+        self.nc = 2 * max(S - 1, 0) + 1
+        self.part_b = e(self.nblk, self.keep_max * self.nc) if (recycle and S > 1) else None
+        self.sums_b = torch.zeros(self.keep_max * self.nc, dtype=torch.float64, device=device)
+        self.sums_b_host = torch.zeros(self.keep_max * self.nc, dtype=torch.float64).pin_memory()
+        self.slots_dev = torch.zeros(self.keep_max, dtype=torch.int32, device=device)
+        self.slots_host = torch.zeros(self.keep_max, dtype=torch.int32).pin_memory()
         self.ws = torch.empty(lib.rato_risk_stats_workspace_bytes(M), dtype=torch.uint8, device=device)
-        # one device record [statistics (10) | subgradient sums (2(S-1))] and its pinned host mirror
-        nres = stats.N_STATS + 2 * max(S - 1, 0)
-        self.res = torch.zeros(nres, dtype=torch.float64, device=device)
-        self.res_host = torch.zeros(nres, dtype=torch.float64).pin_memory()
+        self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
         self.u_host = torch.zeros((S, n_u), dtype=torch.float32).pin_memory()
         self.us_dev = e(S, n_u)
 
     # ---- device oracle -----------------------------------------------------
-    def evaluate(self, G, W, tile, g_up_raw, u_vec):
+    def evaluate(self, G, W, tile, g_up_raw, u_vec, slot=None):
         """-> (phi = CVaR_alpha(m(u)), t* = VaR, g (nU,) subgradient of phi).  One upload of u, four stream-
-        ordered calls, ONE read-back (statistics + subgradient sums)."""
+        ordered calls, ONE read-back (statistics + subgradient sums).  ``slot``: ring slot that receives the
+        call's m values / arg-max rows / statistics (default: the scratch slot)."""
         S, M, n_u = self.S, self.M, self.n_u
+        slot = self.cap - 1 if slot is None else slot
+        m_buf, arg_buf, res = self.ring_m[slot], self.ring_arg[slot], self.ring_res[slot]
         self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
         self.us_dev.copy_(self.u_host, non_blocking=True)
         if self.implicit is not None:
@@ -66,27 +87,48 @@ class CvarCutSolver:
             p, mass, A22 = self.implicit
             _lib.check(self.lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(A22), _lib.ptr(W),
                                                            _lib.ptr(g_up_raw), _lib.ptr(self.us_dev),
-                                                           _lib.ptr(self.m), _lib.ptr(self.arg),
+                                                           _lib.ptr(m_buf), _lib.ptr(arg_buf),
                                                            _lib.current_stream()), "rato_drone_rowmax_implicit")
         else:
             _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
-                                                _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(self.m),
-                                                _lib.ptr(self.arg), _lib.current_stream()), "rato_saa_rowmax")
-        stats.risk_stats_device(self.m, self.alpha, workspace=self.ws, out=self.res[:stats.N_STATS])
+                                                _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(m_buf),
+                                                _lib.ptr(arg_buf), _lib.current_stream()), "rato_saa_rowmax")
+        stats.risk_stats_device(m_buf, self.alpha, workspace=self.ws, out=res[:stats.N_STATS])
         if S > 1:
             _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
-                                                   _lib.ptr(self.m),
-                                                   _lib.ptr(self.arg), 0.0, 0.0, _lib.ptr(self.res),
+                                                   _lib.ptr(m_buf),
+                                                   _lib.ptr(arg_buf), 0.0, 0.0, _lib.ptr(res),
                                                    float(self.alpha * M), _lib.ptr(self.part),
                                                    _lib.current_stream()), "rato_saa_tail_rows")
-            stats.sum_partials(self.part, out=self.res[stats.N_STATS:])
-        self.res_host.copy_(self.res, non_blocking=True)
+            stats.sum_partials(self.part, out=res[stats.N_STATS:])
+        self.res_host.copy_(res, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         r = self.res_host.numpy()
         g = np.zeros(self.nU)
         if S > 1:
             g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:].reshape(S - 1, 2) / (self.alpha * M)
         return float(r[1]), float(r[0]), g
+
+    def relinearize_kept_cuts(self, G, W, tile, g_up_raw):
+        """The kept cuts under the current linearization -> (rows (K, nU), rhs (K,)):  rows[k].u - c_s s <= rhs[k].
+        One batched launch + one partial-sum launch + one read-back."""
+        K, S, M, n_u = len(self.keep), self.S, self.M, self.n_u
+        if K == 0 or S < 2:
+            return np.zeros((0, self.nU)), np.zeros(0)
+        self.slots_host[:K] = torch.as_tensor(self.keep, dtype=torch.int32)
+        self.slots_dev.copy_(self.slots_host, non_blocking=True)
+        part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
+        _lib.check(self.lib.rato_saa_tail_rows_batch(
+            _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(g_up_raw), _lib.ptr(self.ring_m),
+            _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
+            float(self.alpha * M), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
+        stats.sum_partials(part, out=self.sums_b[:K * self.nc])
+        self.sums_b_host.copy_(self.sums_b, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / (self.alpha * M)
+        rows = np.zeros((K, self.nU))
+        rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
+        return rows, r[:, self.nc - 1].copy()
 
     # ---- master QP (host, exact: dense_qp) -----------------------------------------
     def solve(self, *args, **kwargs):
@@ -116,28 +158,45 @@ class CvarCutSolver:
         t0 = time.perf_counter()
         master = dense_qp.Master(Pd, self.q, F, f)      # equality elimination + whitening once per SCP iteration
         master.add_rows(-I[nU:], [0.0])                 # slack >= 0
-        in_master = np.zeros(2 * nU, dtype=bool)        # control bounds enter lazily: only the violated ones
+        n_rows = 1
+        cut_rows = []                                   # (row of the master, ring slot) of every CVaR cut
+        kept = list(self.keep) if (self.recycle and with_cvar) else []
         info["master_s"] += time.perf_counter() - t0
+        if kept:
+            t0 = time.perf_counter()
+            rows, rhs = self.relinearize_kept_cuts(G, W, tile, g_up_raw)
+            info["oracle_s"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            master.add_rows(np.hstack([rows, np.full((len(kept), 1), -self.c_s)]), rhs)
+            cut_rows += [(n_rows + k, slot) for k, slot in enumerate(kept)]
+            n_rows += len(kept)
+            info["master_s"] += time.perf_counter() - t0
+        free = [sl for sl in range(self.cap - 1) if sl not in set(kept)]
+        in_master = np.zeros(2 * nU, dtype=bool)        # control bounds enter lazily: only the violated ones
+        lam = np.zeros(0)
         for it in range(max_cuts + 1):
             t0 = time.perf_counter()
             while True:
-                z, _ = master.solve()
+                z, lam = master.solve()
                 hi = (z[:nU] > self.u_max + 1e-9) & ~in_master[:nU]
                 lo = (z[:nU] < self.u_min - 1e-9) & ~in_master[nU:]
                 if not (hi.any() or lo.any()):
                     break
                 if hi.any():
                     master.add_rows(I[:nU][hi], np.full(int(hi.sum()), self.u_max))
+                    n_rows += int(hi.sum())
                     in_master[:nU] |= hi
                 if lo.any():
                     master.add_rows(-I[:nU][lo], np.full(int(lo.sum()), -self.u_min))
+                    n_rows += int(lo.sum())
                     in_master[nU:] |= lo
             info["master_s"] += time.perf_counter() - t0
             u_vec, s = z[:nU], z[nU]
             if not with_cvar:
                 break
             t0 = time.perf_counter()
-            phi, tstar, g = self.evaluate(G, W, tile, g_up_raw, u_vec)
+            slot = free.pop() if free else None
+            phi, tstar, g = self.evaluate(G, W, tile, g_up_raw, u_vec, slot)
             info["oracle_s"] += time.perf_counter() - t0
             viol = phi - self.c_s * s
             if verbose:
@@ -149,7 +208,20 @@ class CvarCutSolver:
                 break
             # phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= g_k.u_k - phi_k
             master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [float(g @ u_vec - phi)])
+            if slot is not None:
+                cut_rows.append((n_rows, slot))
+            n_rows += 1
             n_cuts += 1
+        if self.recycle and with_cvar:
+            # keep the cuts that carry a multiplier at the solution (newest first), plus the newest few
+            act = [sl for row, sl in reversed(cut_rows) if row < lam.shape[0] and lam[row] > 1e-12]
+            recent = [sl for _, sl in reversed(cut_rows)][:4]
+            keep = []
+            for sl in act + recent:
+                if sl not in keep:
+                    keep.append(sl)
+            self.keep = keep[:self.keep_max]
+            info["recycled"] = len(kept)
         info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=float(tstar + s),
                     cuts=n_cuts, phi=float(phi), status=status)
         return info

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--reduced", action="store_true",
-                    help="drone: solve every subproblem in (u, slack) with device CVaR cuts (scales to M = 1e5)")
+                    help="solve every subproblem in (u, slack) with device CVaR cuts (scales to M = 1e6)")
     ap.add_argument("--define-only-M", type=int, default=100000,
                     help="also time linearize+means+statistics alone at this M (0 = skip)")
     args = ap.parse_args()
@@ -36,6 +36,23 @@ def main():
         t_all = time.perf_counter()
         out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=True)
         line = {"system": "drone", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",
+                "M": args.M, "S": args.S, "alpha": args.alpha, "iters": args.iters,
+                "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
+                "oracle_median_s": float(np.median(out["oracle_s"])), "cuts_median": float(np.median(out["cuts"])),
+                "cuts_max": int(out["cuts"].max()), "cumulative_s": float(out["cumulative_s"][-1]),
+                "wall_s": time.perf_counter() - t_all, "L2_error_last": float(out["L2_error"][-1])}
+        st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)
+        line["in_sample"] = {k: st[k] for k in ("var", "cvar", "frac_satisfied")}
+        print(json.dumps(line))
+        return
+    if args.system == "driving" and args.reduced:
+        from riskaversetrajopt_amd import driving
+        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(args.M, args.S, seed=0)
+        model = driving.Model.from_device(args.S, dW, x0, ws, wr, 'saa', args.alpha)
+        model.solve_reduced(model.initial_guess_us_mat(), 1)             # warm-up
+        t_all = time.perf_counter()
+        out = scp.run_driving_reduced(model, num_scp_iters_max=args.iters, verbose=True)
+        line = {"system": "driving", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",
                 "M": args.M, "S": args.S, "alpha": args.alpha, "iters": args.iters,
                 "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
                 "oracle_median_s": float(np.median(out["oracle_s"])), "cuts_median": float(np.median(out["cuts"])),

@@ -261,3 +261,45 @@ def test_reduced_solve_implicit_equals_explicit_oracle_path():
     Pd, q = d._cut_solver.P.toarray(), d._cut_solver.q
     obj = lambda f: (lambda z: 0.5 * z @ Pd @ z + q @ z)(np.concatenate([f["us"].reshape(-1), [f["slack"]]]))
     assert abs(obj(fi) - obj(fe)) < 1e-6 * abs(obj(fe))
+
+
+def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
+    """Cuts kept from one SCP iteration and re-linearized against the next one (rato_saa_tail_rows_batch) are
+    valid lower bounds of the new CVaR function, tight where nothing changed, and leave the SCP path unchanged."""
+    from riskaversetrajopt_amd import scp
+    S, M = 20, 3000
+    _, d = _drone(M, S, alpha=0.1, seed=7)
+    start = scp.run_drone_reduced(d, num_scp_iters_max=5)["us"]
+    us1, _, info1 = d.solve_reduced(start, 5)
+    cs = d._cut_solver
+    assert cs.recycle and len(cs.keep) >= 1
+    r = d._lin_buffers                                   # the linearization the kept cuts were found on
+    rows, rhs = cs.relinearize_kept_cuts(r["G"], r["_W"], r["tile"], r["_g_up"])
+    assert rows.shape == (len(cs.keep), 3 * S) and np.all(rows.reshape(-1, S, 3)[:, :, 2] == 0)
+    rng = np.random.RandomState(1)
+    best_at_solution = -np.inf
+    for trial in range(6):
+        u = us1.reshape(-1) + (0.0 if trial == 0 else 0.05) * rng.randn(3 * S)
+        phi, _, _ = cs.evaluate(r["G"], r["_W"], r["tile"], r["_g_up"], u)
+        lower = rows @ u - rhs
+        assert np.all(lower <= phi + 2e-5 * max(1.0, abs(phi))), (trial, lower.max(), phi)      # valid cuts
+        if trial == 0:
+            best_at_solution = lower.max() - phi
+    assert abs(best_at_solution) < 2e-5                  # ... and tight at the point they were generated around
+    # a different linearization point: still valid
+    r2 = d.linearize_device(start * 0.9, want_A22=True)
+    rows2, rhs2 = cs.relinearize_kept_cuts(r2["G"], r2["_W"], r2["tile"], r2["_g_up"])
+    cs.implicit = (d._params(M, r2["_g_up"].shape[-1]), d._inputs(None)[1], r2["_A22"])
+    for trial in range(4):
+        u = us1.reshape(-1) + 0.05 * rng.randn(3 * S)
+        phi, _, _ = cs.evaluate(r2["G"], r2["_W"], r2["tile"], r2["_g_up"], u)
+        assert np.all(rows2 @ u - rhs2 <= phi + 2e-5 * max(1.0, abs(phi)))
+    # same SCP path with and without recycling
+    _, da = _drone(M, S, alpha=0.1, seed=7)
+    _, db = _drone(M, S, alpha=0.1, seed=7)
+    a = scp.run_drone_reduced(da, num_scp_iters_max=12)
+    db.solve_reduced(db.initial_guess_us_mat(), 0)       # creates the solver
+    db._cut_solver.recycle = False
+    b = scp.run_drone_reduced(db, num_scp_iters_max=12)
+    np.testing.assert_allclose(a["us"], b["us"], rtol=0, atol=1e-4)
+    assert a["cuts"][-3:].sum() <= b["cuts"][-3:].sum()
