@@ -446,8 +446,8 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 #endif               // 4 = timeline: part[tile][0..7] <- wall_clock64 at block start / after phase 0 / after phase 1 / end
 
 __host__ __device__ inline size_t rows_lds_floats(int S) {
-  // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | XS[6][64] | head (+pad)
-  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 6 * ROWS_SAMPLES + 4;
+  // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | queue head + rollout progress (+pad)
+  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 4;
 }
 
 // grid = (tiles, row_split): blockIdx.y > 0 only for the tiles of an incomplete last "round" (and for
@@ -475,8 +475,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   float* AZ = reinterpret_cast<float*>(PP + (size_t)S * ROWS_SAMPLES);  // [S][64] a22z
   float2_t* US = reinterpret_cast<float2_t*>(AZ + (size_t)S * ROWS_SAMPLES);  // [S] (ux, uy)
   float* UZ = reinterpret_cast<float*>(US + S);                     // [S]
-  float* XS = UZ + S;                                               // [6][64] x_S
-  int* head = reinterpret_cast<int*>(XS + 6 * ROWS_SAMPLES);
+  int* head = reinterpret_cast<int*>(UZ + S);                       // [0] task queue, [1..2] rollout progress x, y
 
   const int tile = tile_base + blockIdx.x;
   const int part_id = blockIdx.y, row_split = gridDim.y;
