@@ -96,6 +96,14 @@ class DroneWork:
             self.variant = "cols_per_thread=%d samples_per_lane=%d jacobian=%s" % (
                 r["cols_per_thread"], r["samples_per_lane"], "factored(W,Phi)" if self.fact else "products")
             self.kernel = "drone_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "drone_linearize_kernel"
+            # the kernels write Z and the partial sums straight into the record the all-gather sends (dist.Record)
+            from riskaversetrajopt_amd import dist as rdist
+            self.records = []
+            for o in self.outs:
+                ld = o["_Z"].numel()
+                rec = rdist.Record(6 * self.S + 6, self.M, device, z_row=ld)
+                o["_Z"], o["sums"] = rec.Z_row[:ld], rec.sums
+                self.records.append(rec)
         else:
             self.kernel = "drone_eval_kernel"
 
@@ -167,6 +175,12 @@ class DrivingWork:
             keys = ("G", "g_up", "Z", "final_du", "final_rhs")
             r2 = self.model.linearize_device(self.us, cols_per_thread=self.cpt)
             self.outs = [{k: r[k] for k in keys}, {k: r2[k] for k in keys}]
+            from riskaversetrajopt_amd import dist as rdist
+            self.records = []                                # Z is written straight into the all-gather's send buffer
+            for o in self.outs:
+                rec = rdist.Record(0, self.M, device)
+                o["Z"] = rec.Z
+                self.records.append(rec)
             self.variant = "cols_per_thread=%d" % r["cols_per_thread"]
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
@@ -333,7 +347,10 @@ def main():
             if pipelined:
                 for t in (sums, r["Z"]):
                     t.record_stream(side)
-            sums, Z_all = rdist.exchange(sums, r["Z"])        # the one collective (no-op at N=1)
+            if getattr(work, "records", None):                # zero-copy record: [sums | Z] already in place
+                sums, Z_all = rdist.exchange_record(work.records[slot])
+            else:
+                sums, Z_all = rdist.exchange(sums, r["Z"])    # the one collective (no-op at N=1)
             stats.risk_stats_device(Z_all, args.alpha, workspace=wss[slot], out=stats_out[slot])
             if pipelined:
                 ev_free[slot].record(side)

@@ -296,6 +296,17 @@ int rato_saa_tail_rows_batch(const float* G, const float* W /* NULL or factor */
                              int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM, float* part,
                              void* stream);
 
+/* ---------------------------------------------------------------- multi-GPU */
+
+/*
+ * The path shards over samples; the only exchange of an evaluation is ONE all-gather (RCCL) of each rank's record
+ *   [ fp64 partial sums (n_sums) | fp32 Z row (>= M_local floats) ]      (rec_bytes each, a multiple of 8).
+ * rato_unpack_records turns the gathered buffer (world records) into  Z_all [world * M_local]  (rank order) and
+ * total [n_sums] = the partial sums added in rank order (bitwise identical on every rank), in one launch.
+ */
+int rato_unpack_records(const void* all, int32_t world, int32_t n_sums, int64_t M_local, int64_t rec_bytes,
+                        double* total, float* Z_all, void* stream);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,

@@ -49,6 +49,8 @@ SIGNATURES = {
     "rato_saa_tail_rows_batch": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                            c_float_p, c_float_p, c_float_p, c_float_p, C.c_int64, c_float_p,
                                            C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_unpack_records": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_float_p, c_float_p,
+                                      c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),

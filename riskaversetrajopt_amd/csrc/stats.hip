@@ -367,7 +367,44 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
   }
 }
 
+// ------------------------------------------------------------ gathered records
+// After the one all-gather of an evaluation every rank holds world records [fp64 sums (n_sums) | fp32 Z row];
+// one launch turns them into the contiguous Z (rank order) and the totals summed in rank order (bitwise
+// identical on every rank) -- instead of a handful of slice / copy / add launches per step.
+__global__ __launch_bounds__(RATO_BLOCK) void unpack_records_kernel(const unsigned char* __restrict__ all, int world,
+                                                                    int n_sums, long M_local, long rec_bytes,
+                                                                    double* __restrict__ total,
+                                                                    float* __restrict__ Z_all) {
+  const long n = (long)world * M_local;
+  for (long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * RATO_BLOCK) {
+    const long r = i / M_local, j = i - r * M_local;
+    Z_all[i] = reinterpret_cast<const float*>(all + r * rec_bytes + 8L * n_sums)[j];
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < n_sums; c += RATO_BLOCK) {
+      double acc = reinterpret_cast<const double*>(all)[c];
+      for (int r = 1; r < world; ++r) acc += reinterpret_cast<const double*>(all + (long)r * rec_bytes)[c];
+      total[c] = acc;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int rato_unpack_records(const void* all, int32_t world, int32_t n_sums, int64_t M_local, int64_t rec_bytes,
+                                   double* total, float* Z_all, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!all || (!total && n_sums > 0) || !Z_all || world < 1 || n_sums < 0 || M_local <= 0 || rec_bytes < 8L * n_sums + 4 * M_local ||
+      rec_bytes % 8 != 0)
+    return RATO_EINVAL;
+  long nb = ((long)world * M_local + RATO_BLOCK * 4 - 1) / (RATO_BLOCK * 4);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(unpack_records_kernel, dim3((unsigned)nb), dim3(RATO_BLOCK), 0, rato::as_stream(stream),
+                     static_cast<const unsigned char*>(all), world, n_sums, (long)M_local, (long)rec_bytes, total, Z_all);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
 
 extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale, double* out,
                                  void* stream) {

@@ -82,3 +82,53 @@ def exchange(sums64, Z32, group=None):
     for r in range(1, world):          # fixed (rank) order: bitwise identical on every rank
         total += sums[r]
     return total.view(sums64.shape), Z_all
+
+
+class Record:
+    """One rank's [fp64 sums | fp32 Z row] record in ONE buffer, so that the producers (sum_partials, the
+    linearize / eval kernels) write straight into what the all-gather sends: no pack step, and one unpack launch
+    (rato_unpack_records) on the receiving side.  ``z_row`` >= M_local is the producer's row stride (ld)."""
+
+    def __init__(self, n_sums, M_local, device, z_row=None):
+        z_row = M_local if z_row is None else int(z_row)
+        if z_row < M_local:
+            raise ValueError("z_row < M_local")
+        z_row += z_row % 2                               # record length: a multiple of 8 bytes
+        self.n_sums, self.M_local, self.rec_bytes = int(n_sums), int(M_local), 8 * int(n_sums) + 4 * z_row
+        self.buf = torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device)
+        self.sums = self.buf[:8 * n_sums].view(torch.float64)
+        self.Z_row = self.buf[8 * n_sums:].view(torch.float32)
+        self.Z = self.Z_row[:M_local]
+        self._all = self._Z_all = self._total = None
+
+    def _buffers(self, world):
+        if self._all is None or self._all.numel() != world * self.rec_bytes:
+            dev = self.buf.device
+            self._all = torch.empty(world * self.rec_bytes, dtype=torch.uint8, device=dev)
+            self._Z_all = torch.empty(world * self.M_local, dtype=torch.float32, device=dev)
+            self._total = torch.empty(self.n_sums, dtype=torch.float64, device=dev)
+        return self._all, self._Z_all, self._total
+
+
+def exchange_record(rec, group=None):
+    """``exchange`` for a Record: -> (total sums (n_sums,) fp64, Z_all (world * M_local,) fp32)."""
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and os.environ.get("RATO_FORCE_DIST") != "1"):
+        return rec.sums, rec.Z
+    world = dist.get_world_size(group)
+    all_, Z_all, total = rec._buffers(world)
+    dist.all_gather_into_tensor(all_, rec.buf, group=group)
+    if all_.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        _lib.check(lib.rato_unpack_records(_lib.ptr(all_), world, rec.n_sums, rec.M_local, rec.rec_bytes,
+                                           _lib.ptr(total), _lib.ptr(Z_all), _lib.current_stream()),
+                   "rato_unpack_records")
+    else:                                                # host tensors (gloo tests): same layout, torch views
+        v = all_.view(world, rec.rec_bytes)
+        sums = v[:, :8 * rec.n_sums].contiguous().view(torch.float64).view(world, rec.n_sums)
+        total.copy_(sums[0])
+        for r in range(1, world):
+            total += sums[r]
+        Z_all.copy_(v[:, 8 * rec.n_sums:].contiguous().view(torch.float32)[:, :rec.M_local].reshape(-1))
+    return total, Z_all

@@ -35,6 +35,12 @@ def _worker(rank, world, port, M_total, tmpdir):
     total, Z_all = rdist.exchange(sums_local, Z_local)
     np.save(os.path.join(tmpdir, f"Z_{rank}.npy"), Z_all.numpy())
     np.save(os.path.join(tmpdir, f"sums_{rank}.npy"), total.numpy())
+    # the zero-copy record (producers write into the send buffer; row stride > M_local, odd -> padded)
+    rec = rdist.Record(7, hi - lo, "cpu", z_row=hi - lo + 3)
+    rec.sums.copy_(sums_local)
+    rec.Z.copy_(Z_local)
+    total_r, Z_all_r = rdist.exchange_record(rec)
+    assert torch.equal(total_r, total) and torch.equal(Z_all_r, Z_all) and rec.rec_bytes % 8 == 0
     dist.barrier()
     dist.destroy_process_group()
 

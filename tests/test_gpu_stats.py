@@ -95,3 +95,29 @@ def test_count_nonfinite():
     x[-1] = -float("inf")
     assert stats.count_nonfinite(x) == 3
     assert stats.count_nonfinite(torch.full((70000,), float("nan"), device="cuda")) == 70000
+
+
+def test_unpack_records_matches_host_layout():
+    """rato_unpack_records: gathered [fp64 sums | fp32 Z row] records -> contiguous Z (rank order) and the sums
+    added in rank order; bit-identical to the host restatement of the same layout."""
+    import torch
+    from riskaversetrajopt_amd import _lib, dist as rdist
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    for world, n_sums, M_local, z_row in ((1, 5, 7, 7), (3, 306, 1000, 1000), (8, 6, 1237, 1240), (2, 0, 64, 64)):
+        recs = [rdist.Record(n_sums, M_local, "cuda:0", z_row=z_row) for _ in range(world)]
+        for r in recs:
+            if n_sums:
+                r.sums.copy_(torch.as_tensor(rng.randn(n_sums) * 1e3))
+            r.Z_row.copy_(torch.as_tensor(rng.randn(r.Z_row.numel()).astype(np.float32)))
+        all_ = torch.cat([r.buf for r in recs])
+        total = torch.empty(max(n_sums, 1), dtype=torch.float64, device="cuda:0")
+        Z_all = torch.empty(world * M_local, dtype=torch.float32, device="cuda:0")
+        _lib.check(lib.rato_unpack_records(_lib.ptr(all_), world, n_sums, M_local, recs[0].rec_bytes, _lib.ptr(total),
+                                           _lib.ptr(Z_all), _lib.current_stream()), "rato_unpack_records")
+        assert torch.equal(Z_all, torch.cat([r.Z for r in recs]))
+        if n_sums:
+            ref = recs[0].sums.clone()
+            for r in recs[1:]:
+                ref += r.sums
+            assert torch.equal(total[:n_sums], ref)
