@@ -110,7 +110,7 @@ __device__ __forceinline__ void ped_step(const rato_car_params& P, const PedCons
                                          float& n0, float& n1, float& rinv) {
   const float dx = ex - px, dy = ey - py;
   const float r2 = dx * dx + dy * dy;
-  rinv = 1.0f / sqrtf(r2);
+  rinv = __builtin_amdgcn_rsqf(r2);  // v_rsq_f32 (1 ulp); r2 = squared ego-pedestrian distance, O(1..100) m^2
   n0 = dx * rinv;
   n1 = dy * rinv;
   const float common = c.w_s * (P.speed_ped_des - vy);  // added to BOTH components (:156-157)
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
     float n0, n1, rinv;
     ped_step(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy, n0, n1, rinv);
     const float dx = ego[(t + 1) * 4 + 0] - px, dy = ego[(t + 1) * 4 + 1] - py;
-    const float gt = -(sqrtf(dx * dx + dy * dy) - P.d_min);  // driving.py:223-230,269
+    const float d2 = dx * dx + dy * dy;
+    const float gt = -(d2 * __builtin_amdgcn_rsqf(d2) - P.d_min);  // -(||p_e - p_p|| - d_min): driving.py:223-230,269
     zmax = fmaxf(zmax, gt);
     if (g) g[(size_t)t * M + m] = gt;
     if (xs) {
