@@ -57,6 +57,62 @@ def solve(P, q, A_eq, b_eq, A_in, b_in):
     return x0 + N @ w, lam
 
 
+def nnls_warm(A, b, passive0=None, maxiter=None):
+    """Lawson-Hanson NNLS  min |A y - b|, y >= 0  started from a guess of the passive (positive) set.
+
+    A cutting-plane loop solves a sequence of problems that differ by one column; the active-set method started
+    from the previous passive set needs a handful of least-squares solves instead of one per positive variable.
+    Termination is the KKT test of the original algorithm (dual w = A'(b - A y) <= tol on the zero set, y > 0 on
+    the passive set; tol = 10 max(m,n) eps |A|_1 as in scipy).  -> (y, passive mask, converged)."""
+    m, n = A.shape
+    if maxiter is None:
+        maxiter = 3 * n + 10
+    tol = 10.0 * max(m, n) * np.finfo(np.float64).eps * max(np.abs(A).sum(axis=0).max(initial=0.0), 1e-300)
+    y = np.zeros(n)
+    P = np.zeros(n, dtype=bool)
+    if passive0 is not None and len(passive0):
+        k = min(n, len(passive0))
+        P[:k] = np.asarray(passive0[:k], dtype=bool)
+        for _ in range(n + 1):                      # warm start: keep the part of the guess that is positive
+            if not P.any():
+                break
+            s = np.linalg.lstsq(A[:, P], b, rcond=None)[0]
+            if np.all(s > 0.0):
+                y[P] = s
+                break
+            idx = np.flatnonzero(P)
+            P[idx[s <= 0.0]] = False
+    for _ in range(maxiter):
+        w = A.T @ (b - A @ y)
+        w[P] = -np.inf
+        j = int(np.argmax(w))
+        if not (w[j] > tol):
+            return y, P, True
+        P[j] = True
+        while True:
+            idx = np.flatnonzero(P)
+            s = np.linalg.lstsq(A[:, idx], b, rcond=None)[0]
+            if np.all(s > 0.0):
+                y[:] = 0.0
+                y[idx] = s
+                break
+            neg = s <= 0.0
+            yi = y[idx]
+            denom = yi[neg] - s[neg]
+            alpha = np.min(np.where(denom > 0.0, yi[neg] / np.where(denom > 0.0, denom, 1.0), 0.0))
+            yi = yi + alpha * (s - yi)
+            drop = neg & (yi <= 1e-300 + 0.0 * yi)   # the variables that hit zero leave the passive set
+            if not drop.any():
+                drop = neg                           # rounding: force progress
+            yi[drop] = 0.0
+            y[:] = 0.0
+            y[idx] = yi
+            P[idx[drop]] = False
+            if not P.any():
+                break
+    return y, P, False
+
+
 class Master:
     """The same solve with the equality elimination and the Cholesky whitening done ONCE, and inequality rows
     appended incrementally (a cutting-plane loop adds one row per iteration)."""
@@ -79,6 +135,9 @@ class Master:
         self.G = np.zeros((0, self.N.shape[1]))
         self.h = np.zeros(0)
         self.sc = np.zeros(0)
+        self.passive = np.zeros(0, dtype=bool)      # passive set of the last solve (warm start of the next one)
+        self.warm = True
+        self.vnorm = 0.0                            # |v| of the last solve (scale of the next one)
 
     def add_rows(self, A_in, b_in):
         A_in = np.atleast_2d(np.asarray(A_in, dtype=np.float64))
@@ -95,13 +154,25 @@ class Master:
             v = np.zeros(self.N.shape[1])
             lam = np.zeros(0)
         else:
-            A_n = np.vstack([self.G.T, self.h[None, :]])
+            # The NNLS residual's last component is 1/(1 + |v|^2): with |v| ~ 1e4 (an optimum far out, e.g. a large
+            # slack) the KKT tolerance of the NNLS would accept constraint violations of tol (1 + |v|^2).  Solve for
+            # v / sigma instead, sigma ~ |v| (previous solve, or the lower bound max_j h_j: rows are unit vectors).
+            sigma = max(1.0, self.vnorm, float(self.h.max(initial=0.0)))
+            A_n = np.vstack([self.G.T, (self.h / sigma)[None, :]])
             b_n = np.zeros(A_n.shape[0])
             b_n[-1] = 1.0
-            y, _ = nnls(A_n, b_n, maxiter=20 * A_n.shape[1])
+            ok = False
+            if self.warm:
+                y, P, ok = nnls_warm(A_n, b_n, self.passive)
+                if ok:
+                    self.passive = P
+            if not ok:                               # cold fallback: scipy's Lawson-Hanson
+                y, _ = nnls(A_n, b_n, maxiter=20 * A_n.shape[1])
+                self.passive = y > 0.0
             r = A_n @ y - b_n
             if abs(r[-1]) < 1e-14:
                 raise InfeasibleError("master QP infeasible")
-            v = -r[:-1] / r[-1]
-            lam = (y / (-r[-1])) / self.sc
+            v = -sigma * r[:-1] / r[-1]
+            lam = sigma * (y / (-r[-1])) / self.sc
+            self.vnorm = float(np.linalg.norm(v))
         return self.x0 + self.NLinvT @ (v - self.Linv_c), lam

@@ -59,3 +59,53 @@ def test_incremental_master_equals_one_shot():
     np.testing.assert_allclose(x2, dense_qp.solve(P, q, A_eq, b_eq, np.vstack([A1, A2]), np.concatenate([b1, b2]))[0],
                                atol=1e-9)
     assert lam.shape == (15,) and np.all(lam >= 0)
+
+
+def test_warm_started_nnls_equals_scipy_on_a_growing_problem():
+    """The cutting-plane usage: columns are appended one at a time and every solve starts from the previous
+    passive set; each solution must equal scipy's cold Lawson-Hanson solution."""
+    from scipy.optimize import nnls
+    rng = np.random.RandomState(4)
+    for m, n_final in ((30, 60), (146, 120), (8, 40)):
+        A = rng.randn(m, n_final)
+        b = rng.randn(m)
+        passive = np.zeros(0, dtype=bool)
+        for n in range(1, n_final + 1, 3):
+            y, passive, ok = dense_qp.nnls_warm(A[:, :n], b, passive)
+            assert ok
+            y_ref, _ = nnls(A[:, :n], b, maxiter=50 * n)
+            # the fitted vector A y (projection of b on the cone) is unique; y itself only when the passive
+            # columns are independent (n <= m here)
+            np.testing.assert_allclose(A[:, :n] @ y, A[:, :n] @ y_ref, rtol=0, atol=1e-8 * max(1.0, np.abs(b).max()))
+            if n <= m:
+                np.testing.assert_allclose(y, y_ref, rtol=1e-7, atol=1e-9)
+            assert np.all(y >= 0.0) and np.array_equal(passive, y > 0.0)
+    # degenerate input: duplicate columns and a zero column
+    A = rng.randn(12, 5)
+    A = np.hstack([A, A[:, :2], np.zeros((12, 1))])
+    b = rng.randn(12)
+    y, _, ok = dense_qp.nnls_warm(A, b, np.ones(8, dtype=bool))
+    y_ref, rn = nnls(A, b)
+    assert ok and abs(np.linalg.norm(A @ y - b) - rn) < 1e-10
+
+
+def test_master_warm_and_cold_paths_agree():
+    rng = np.random.RandomState(12)
+    n = 40
+    L = rng.randn(n, n)
+    Pm = L @ L.T + np.eye(n)
+    q = rng.randn(n)
+    A_eq = rng.randn(3, n)
+    xf = rng.randn(n)
+    b_eq = A_eq @ xf
+    warm, cold = dense_qp.Master(Pm, q, A_eq, b_eq), dense_qp.Master(Pm, q, A_eq, b_eq)
+    cold.warm = False
+    for it in range(40):
+        a = rng.randn(1, n)
+        bb = a @ xf + rng.rand(1) * 0.5
+        warm.add_rows(a, bb)
+        cold.add_rows(a, bb)
+        xw, lw = warm.solve()
+        xc, lc = cold.solve()
+        np.testing.assert_allclose(xw, xc, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(lw, lc, rtol=1e-6, atol=1e-9)
