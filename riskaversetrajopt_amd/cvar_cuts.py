@@ -33,6 +33,20 @@ import torch
 from . import _lib, dense_qp, stats
 
 
+_CTL = []
+
+
+def _threadpool_controller():
+    """threadpoolctl scans the loaded libraries when a controller is built (~1 ms): build it once."""
+    if not _CTL:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _CTL.append(ThreadpoolController())
+        except ImportError:                       # pragma: no cover
+            _CTL.append(None)
+    return _CTL[0]
+
+
 class CvarCutSolver:
     def __init__(self, lib, device, *, n_u, S, M, ld, R, alpha, dt, Rcost, slack_penalty, u_min, u_max,
                  recycle=True):
@@ -80,29 +94,30 @@ class CvarCutSolver:
         S, M, n_u = self.S, self.M, self.n_u
         slot = self.cap - 1 if slot is None else slot
         m_buf, arg_buf, res = self.ring_m[slot], self.ring_arg[slot], self.ring_res[slot]
+        tstream = torch.cuda.current_stream()
+        st = _lib.C.c_void_p(tstream.cuda_stream)        # one stream lookup per call
         self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
         self.us_dev.copy_(self.u_host, non_blocking=True)
         if self.implicit is not None:
-            import ctypes as C
             p, mass, A22 = self.implicit
-            _lib.check(self.lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(A22), _lib.ptr(W),
+            _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), _lib.ptr(W),
                                                            _lib.ptr(g_up_raw), _lib.ptr(self.us_dev),
                                                            _lib.ptr(m_buf), _lib.ptr(arg_buf),
-                                                           _lib.current_stream()), "rato_drone_rowmax_implicit")
+                                                           st), "rato_drone_rowmax_implicit")
         else:
             _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
                                                 _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(m_buf),
-                                                _lib.ptr(arg_buf), _lib.current_stream()), "rato_saa_rowmax")
-        stats.risk_stats_device(m_buf, self.alpha, workspace=self.ws, out=res[:stats.N_STATS])
+                                                _lib.ptr(arg_buf), st), "rato_saa_rowmax")
+        stats.risk_stats_device(m_buf, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
             _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
                                                    _lib.ptr(m_buf),
                                                    _lib.ptr(arg_buf), 0.0, 0.0, _lib.ptr(res),
                                                    float(self.alpha * M), _lib.ptr(self.part),
-                                                   _lib.current_stream()), "rato_saa_tail_rows")
-            stats.sum_partials(self.part, out=res[stats.N_STATS:])
+                                                   st), "rato_saa_tail_rows")
+            stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
         self.res_host.copy_(res, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        tstream.synchronize()
         r = self.res_host.numpy()
         g = np.zeros(self.nU)
         if S > 1:
@@ -137,11 +152,10 @@ class CvarCutSolver:
         The master QP is tiny (3S+1 variables): a BLAS pool with one thread per host core (256 on the MI355X
         boxes) makes every call slower AND starves the thread that feeds the GPU (measured: 2.9 ms instead of
         0.65 ms per oracle call), so the loop runs under a 4-thread limit."""
-        try:
-            from threadpoolctl import threadpool_limits
-        except ImportError:                       # pragma: no cover
+        ctl = _threadpool_controller()
+        if ctl is None:                           # pragma: no cover
             return self._solve(*args, **kwargs)
-        with threadpool_limits(limits=4):
+        with ctl.limit(limits=4):
             return self._solve(*args, **kwargs)
 
     def _solve(self, G, W, tile, g_up_raw, final_du, final_rhs, *, with_cvar=True, tol=1e-7, max_cuts=400,

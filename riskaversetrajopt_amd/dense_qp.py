@@ -127,11 +127,22 @@ class Master:
             self.N = sla.null_space(A_eq)
         else:
             self.x0, self.N = np.zeros(n), np.eye(n)
-        H = self.N.T @ P @ self.N
-        c = self.N.T @ (P @ self.x0 + q)
-        self.L = np.linalg.cholesky(H)
-        self.Linv_c = sla.solve_triangular(self.L, c, lower=True)
-        self.NLinvT = sla.solve_triangular(self.L, self.N.T, lower=True).T      # N L^-T  (n x k)
+        if np.count_nonzero(P - np.diag(np.diagonal(P))) == 0 and A_eq is not None and len(A_eq):
+            # diagonal Hessian (the SCP master: 2 dt R blocks and the slack penalty): whiten FIRST, x = D^-1/2 xt,
+            # then the null-space basis of the scaled equalities is orthonormal in the whitened metric, the reduced
+            # Hessian is the identity and no Cholesky factorization is needed
+            d = 1.0 / np.sqrt(np.diagonal(P))
+            Nt = sla.null_space(A_eq * d[None, :])                               # orthonormal, (A_eq D^-1/2) Nt = 0
+            self.N = d[:, None] * Nt
+            self.L = None
+            self.Linv_c = self.N.T @ (P @ self.x0 + q)                           # H = I
+            self.NLinvT = self.N
+        else:
+            H = self.N.T @ P @ self.N
+            c = self.N.T @ (P @ self.x0 + q)
+            self.L = np.linalg.cholesky(H)
+            self.Linv_c = sla.solve_triangular(self.L, c, lower=True)
+            self.NLinvT = sla.solve_triangular(self.L, self.N.T, lower=True).T      # N L^-T  (n x k)
         self.G = np.zeros((0, self.N.shape[1]))
         self.h = np.zeros(0)
         self.sc = np.zeros(0)

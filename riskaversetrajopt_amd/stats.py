@@ -23,9 +23,9 @@ def _as_device_f32(Z, device=None):
     return torch.as_tensor(np.asarray(Z, dtype=np.float32), device=device or 'cuda:0')
 
 
-def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None):
+def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):
     """Z: device tensor (M,) fp32 -> device tensor double[10] (see rato_saa.h).
-    Asynchronous on the current stream."""
+    Asynchronous on the current stream (``stream``: an already looked-up ``_lib.current_stream()``)."""
     lib = _lib.load()
     Z = _as_device_f32(Z)
     M = Z.numel()
@@ -35,7 +35,8 @@ def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=Non
     if out is None:
         out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
     _lib.check(lib.rato_risk_stats(_lib.ptr(Z), M, float(alpha), float(thr), _lib.ptr(workspace),
-                                   workspace.numel(), _lib.ptr(out), _lib.current_stream()),
+                                   workspace.numel(), _lib.ptr(out),
+                                   _lib.current_stream() if stream is None else stream),
                "rato_risk_stats")
     return out
 
@@ -56,7 +57,7 @@ def monte_carlo_avar(Z_samples, alpha):
     return risk_stats(Z_samples, alpha)["cvar"]
 
 
-def sum_partials(part, scale=1.0, out=None):
+def sum_partials(part, scale=1.0, out=None, stream=None):
     """part: device (nblocks, ...) fp32 -> device double tensor of shape part.shape[1:]
     holding scale * sum over blocks (fixed order, fp64)."""
     lib = _lib.load()
@@ -66,7 +67,7 @@ def sum_partials(part, scale=1.0, out=None):
     if out is None:
         out = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
     _lib.check(lib.rato_sum_partials(_lib.ptr(part), nblocks, ncols, float(scale), _lib.ptr(out),
-                                     _lib.current_stream()), "rato_sum_partials")
+                                     _lib.current_stream() if stream is None else stream), "rato_sum_partials")
     return out
 
 

@@ -109,3 +109,33 @@ def test_master_warm_and_cold_paths_agree():
         xc, lc = cold.solve()
         np.testing.assert_allclose(xw, xc, rtol=0, atol=1e-9)
         np.testing.assert_allclose(lw, lc, rtol=1e-6, atol=1e-9)
+
+
+def test_master_diagonal_hessian_fast_path_equals_general_solver():
+    """The SCP master has a diagonal Hessian: the whitened null-space path (no Cholesky) must give what the general
+    dense solver gives."""
+    rng = np.random.RandomState(21)
+    n = 31
+    d = rng.rand(n) * 5.0 + 0.1
+    d[-1] = 1e4                                   # the slack penalty
+    Pm = np.diag(d)
+    q = np.zeros(n)
+    q[-1] = 1e4
+    A_eq = rng.randn(6, n)
+    A_eq[:, -1] = 0.0
+    xf = rng.randn(n)
+    b_eq = A_eq @ xf
+    m = dense_qp.Master(Pm, q, A_eq, b_eq)
+    assert m.L is None                            # fast path taken
+    rows, rhs = [], []
+    for it in range(25):
+        a = rng.randn(1, n)
+        bb = a @ xf + rng.rand(1) * 0.3
+        rows.append(a)
+        rhs.append(bb)
+        m.add_rows(a, bb)
+        x, lam = m.solve()
+        x_ref, lam_ref = dense_qp.solve(Pm + 1e-300 * np.ones((n, n)) * 0, q, A_eq, b_eq, np.vstack(rows), np.concatenate(rhs))
+        np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(A_eq @ x, b_eq, atol=1e-9)
+        assert np.all(np.vstack(rows) @ x <= np.concatenate(rhs) + 1e-9)
