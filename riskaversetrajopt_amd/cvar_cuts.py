@@ -23,6 +23,11 @@ CVaR(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}].  The (w, r
 the previous SCP iteration's solution are therefore kept on the device (rings of m values / arg-max rows / risk
 statistics) and re-evaluated against the new linearization in ONE launch (rato_saa_tail_rows_batch) before the
 loop starts: near convergence consecutive linearizations are close and the master starts almost solved.
+
+Sharded over GPUs (``group``: a torch.distributed group, one rank per GPU, equal shards): every rank keeps the
+Jacobian of its samples; a cut costs one all-gather of the m shards (the exact VaR needs all of them; every rank
+then runs the same selection), and one rank-ordered sum of the 2(S-1) subgradient partial sums.  Every rank
+solves the same tiny master; rank 0's solution is broadcast so that the ranks cannot drift apart.
 """
 import time
 
@@ -31,6 +36,7 @@ import scipy.sparse as sp
 import torch
 
 from . import _lib, dense_qp, stats
+from . import dist as rdist
 
 
 _CTL = []
@@ -49,9 +55,11 @@ def _threadpool_controller():
 
 class CvarCutSolver:
     def __init__(self, lib, device, *, n_u, S, M, ld, R, alpha, dt, Rcost, slack_penalty, u_min, u_max,
-                 recycle=True):
+                 recycle=True, group=None, world=1):
         self.lib, self.device = lib, device
         self.n_u, self.S, self.M, self.ld, self.R = n_u, S, M, ld, R
+        self.group, self.world = group, int(world)      # M = samples of THIS rank; M * world in total
+        self.M_total = M * self.world
         self.alpha = alpha
         self.nU = n_u * S
         self.u_min, self.u_max = float(u_min), float(u_max)
@@ -61,7 +69,7 @@ class CvarCutSolver:
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
         self.q = np.zeros(n)
         self.q[-1] = float(slack_penalty)
-        self.c_s = (M * (1.0 - alpha) - 1.0) / (alpha * M)
+        self.c_s = (self.M_total * (1.0 - alpha) - 1.0) / (alpha * self.M_total)
         # device scratch.  Every oracle call writes into one slot of three rings (m values, arg-max rows,
         # [statistics (10) | subgradient sums (2(S-1))]); slots of cuts worth recycling survive the solve.
         e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=device)
@@ -81,7 +89,7 @@ class CvarCutSolver:
         self.sums_b_host = torch.zeros(self.keep_max * self.nc, dtype=torch.float64).pin_memory()
         self.slots_dev = torch.zeros(self.keep_max, dtype=torch.int32, device=device)
         self.slots_host = torch.zeros(self.keep_max, dtype=torch.int32).pin_memory()
-        self.ws = torch.empty(lib.rato_risk_stats_workspace_bytes(M), dtype=torch.uint8, device=device)
+        self.ws = torch.empty(lib.rato_risk_stats_workspace_bytes(self.M_total), dtype=torch.uint8, device=device)
         self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
         self.u_host = torch.zeros((S, n_u), dtype=torch.float32).pin_memory()
         self.us_dev = e(S, n_u)
@@ -108,20 +116,23 @@ class CvarCutSolver:
             _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
                                                 _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(m_buf),
                                                 _lib.ptr(arg_buf), st), "rato_saa_rowmax")
-        stats.risk_stats_device(m_buf, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
+        m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
+        stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
             _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
                                                    _lib.ptr(m_buf),
                                                    _lib.ptr(arg_buf), 0.0, 0.0, _lib.ptr(res),
-                                                   float(self.alpha * M), _lib.ptr(self.part),
+                                                   float(self.alpha * self.M_total), _lib.ptr(self.part),
                                                    st), "rato_saa_tail_rows")
             stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
+            if self.world > 1:
+                res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
         r = self.res_host.numpy()
         g = np.zeros(self.nU)
         if S > 1:
-            g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:].reshape(S - 1, 2) / (self.alpha * M)
+            g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:].reshape(S - 1, 2) / (self.alpha * self.M_total)
         return float(r[1]), float(r[0]), g
 
     def relinearize_kept_cuts(self, G, W, tile, g_up_raw):
@@ -136,11 +147,13 @@ class CvarCutSolver:
         _lib.check(self.lib.rato_saa_tail_rows_batch(
             _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(g_up_raw), _lib.ptr(self.ring_m),
             _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
-            float(self.alpha * M), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
+            float(self.alpha * self.M_total), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
         stats.sum_partials(part, out=self.sums_b[:K * self.nc])
+        if self.world > 1:
+            self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
         self.sums_b_host.copy_(self.sums_b, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / (self.alpha * M)
+        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / (self.alpha * self.M_total)
         rows = np.zeros((K, self.nU))
         rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
         return rows, r[:, self.nc - 1].copy()
@@ -204,6 +217,8 @@ class CvarCutSolver:
                     master.add_rows(-I[:nU][lo], np.full(int(lo.sum()), -self.u_min))
                     n_rows += int(lo.sum())
                     in_master[nU:] |= lo
+            if self.world > 1:                      # every rank solved the same master; keep them bit-identical
+                z = rdist.broadcast_from_rank0(z, self.device, self.group)
             info["master_s"] += time.perf_counter() - t0
             u_vec, s = z[:nU], z[nU]
             if not with_cvar:
@@ -234,7 +249,14 @@ class CvarCutSolver:
             for sl in act + recent:
                 if sl not in keep:
                     keep.append(sl)
-            self.keep = keep[:self.keep_max]
+            keep = keep[:self.keep_max]
+            if self.world > 1:                      # same decision on every rank (slot numbering is identical)
+                pad = np.full(self.keep_max + 1, -1.0)
+                pad[0] = len(keep)
+                pad[1:1 + len(keep)] = keep
+                pad = rdist.broadcast_from_rank0(pad, self.device, self.group)
+                keep = [int(v) for v in pad[1:1 + int(pad[0])]]
+            self.keep = keep
             info["recycled"] = len(kept)
         info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=float(tstar + s),
                     cuts=n_cuts, phi=float(phi), status=status)

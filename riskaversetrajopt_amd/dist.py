@@ -132,3 +132,43 @@ def exchange_record(rec, group=None):
             total += sums[r]
         Z_all.copy_(v[:, 8 * rec.n_sums:].contiguous().view(torch.float32)[:, :rec.M_local].reshape(-1))
     return total, Z_all
+
+
+# ---- small helpers for the sharded cutting-plane oracle (cvar_cuts.py) ---------------------------------------
+def _staged(t, group):
+    """gloo has no device collectives: stage through the host (tests: two ranks on one GPU)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def gather_concat(t, group=None):
+    """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank)."""
+    world = dist.get_world_size(group)
+    src = t.contiguous()
+    if _staged(src, group):
+        host = src.cpu()
+        out = torch.empty(world * host.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(t.device)
+    out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out
+
+
+def sum_in_rank_order(t, group=None):
+    """Sum of a small tensor over the ranks, added in rank order: bitwise identical on every rank."""
+    world = dist.get_world_size(group)
+    parts = gather_concat(t.reshape(-1), group).view(world, -1)
+    total = parts[0].clone()
+    for r in range(1, world):
+        total += parts[r]
+    return total.view(t.shape)
+
+
+def broadcast_from_rank0(arr, device, group=None):
+    """numpy float64 array -> rank 0's copy on every rank."""
+    import numpy as np
+    t = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64))
+    if dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    return t.cpu().numpy()

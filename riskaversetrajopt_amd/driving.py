@@ -322,6 +322,14 @@ class Model:
         return us_sol, t_risk_sol
 
     # ---- L4 at large M: reduced (u, slack) problem with device CVaR cuts ----------------------
+    def shard(self, group=None):
+        """This Model is one shard of a sample-sharded batch (see drone_risk.Model.shard): the cutting-plane oracle
+        of ``solve_reduced`` then runs across the ranks.  (The final rows are sample independent: nothing else to merge.)"""
+        import torch.distributed as tdist
+        self._group, self._world = group, tdist.get_world_size(group)
+        self._cut_solver = None
+        return self
+
     def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-7, verbose=False):
         """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
         scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint."""
@@ -334,7 +342,8 @@ class Model:
         if cs is None:
             cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=M, R=1, alpha=self.alpha,
                                          dt=self.dt, Rcost=P.R, slack_penalty=self.SLACK_PENALTY,
-                                         u_min=self.u_min, u_max=self.u_max)
+                                         u_min=self.u_min, u_max=self.u_max,
+                                         group=getattr(self, "_group", None), world=getattr(self, "_world", 1))
             self._cut_solver = cs
         info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
                         r["final_rhs"].double().cpu().numpy(), with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)

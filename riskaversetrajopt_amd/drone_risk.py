@@ -449,6 +449,15 @@ class Model:
         return us_sol, t_risk_sol
 
     # ---- L4 at large M: reduced (u, slack) problem with device CVaR cuts ----------------------
+    def shard(self, group=None):
+        """Declare this Model one shard of a sample-sharded batch (one process per GPU, torch.distributed already
+        initialised, equal shard sizes): ``solve_reduced`` then merges the sample means and runs the cutting-plane
+        oracle across the ranks (cvar_cuts.py); every rank returns the same iterate."""
+        import torch.distributed as tdist
+        self._group, self._world = group, tdist.get_world_size(group)
+        self._cut_solver = None
+        return self
+
     def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False, implicit=True):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
@@ -461,14 +470,21 @@ class Model:
         r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit)
         self._lin_buffers = r
         M, S = r["M"], self.S
+        world = getattr(self, "_world", 1)
         cs = getattr(self, "_cut_solver", None)
         if cs is None:
             cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=r["_g_up"].shape[-1],
                                          R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
-                                         slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max)
+                                         slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max,
+                                         group=getattr(self, "_group", None), world=world)
             self._cut_solver = cs
-        final_du = self.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M)
-        final_rhs = r["rhs_sum"].cpu().numpy() / M
+        sums = r["sums"]
+        if world > 1:                                     # sample means over ALL shards, summed in rank order
+            from . import dist as rdist
+            sums = rdist.sum_in_rank_order(sums, getattr(self, "_group", None))
+        sums = sums.cpu().numpy()
+        final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / (M * world))
+        final_rhs = sums[6 * S:] / (M * world)
         cs.implicit = None
         if implicit:
             dW, mass, Qsym, _ = self._inputs(None)

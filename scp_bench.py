@@ -26,32 +26,43 @@ def main():
                     help="also time linearize+means+statistics alone at this M (0 = skip)")
     args = ap.parse_args()
     import torch
-    from riskaversetrajopt_amd import scp
+    from riskaversetrajopt_amd import scp, dist as rdist
     np.random.seed(0)
+    # under torchrun (--reduced only): --M samples PER GPU, the cutting-plane oracle runs across the ranks
+    rank, world, local = rdist.init_from_env() if args.reduced else (0, 1, 0)
+    if world > 1:
+        torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
     if args.system == "drone" and args.reduced:
         from riskaversetrajopt_amd import drone_risk, drone_utils
-        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(args.M, args.S, seed=0)
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank, device=dev)
         model = drone_risk.Model.from_device(args.S, dW, mass, Qsym, 'saa', args.alpha, M=args.M)
+        if world > 1:
+            model.shard()
         model.solve_reduced(model.initial_guess_us_mat(), 2)             # warm-up (allocations, first launches)
         t_all = time.perf_counter()
-        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=True)
+        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=(rank == 0))
         line = {"system": "drone", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",
-                "M": args.M, "S": args.S, "alpha": args.alpha, "iters": args.iters,
+                "M": args.M, "M_total": args.M * world, "n_gpus": world, "S": args.S, "alpha": args.alpha,
+                "iters": args.iters,
                 "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
                 "oracle_median_s": float(np.median(out["oracle_s"])), "cuts_median": float(np.median(out["cuts"])),
                 "cuts_max": int(out["cuts"].max()), "cumulative_s": float(out["cumulative_s"][-1]),
                 "wall_s": time.perf_counter() - t_all, "L2_error_last": float(out["L2_error"][-1])}
-        st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)
+        st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)          # this rank's shard
         line["in_sample"] = {k: st[k] for k in ("var", "cvar", "frac_satisfied")}
-        print(json.dumps(line))
+        if rank == 0:
+            print(json.dumps(line))
         return
     if args.system == "driving" and args.reduced:
         from riskaversetrajopt_amd import driving
-        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(args.M, args.S, seed=0)
+        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank, device=dev)
         model = driving.Model.from_device(args.S, dW, x0, ws, wr, 'saa', args.alpha)
+        if world > 1:
+            model.shard()
         model.solve_reduced(model.initial_guess_us_mat(), 1)             # warm-up
         t_all = time.perf_counter()
-        out = scp.run_driving_reduced(model, num_scp_iters_max=args.iters, verbose=True)
+        out = scp.run_driving_reduced(model, num_scp_iters_max=args.iters, verbose=(rank == 0))
         line = {"system": "driving", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",
                 "M": args.M, "S": args.S, "alpha": args.alpha, "iters": args.iters,
                 "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
@@ -96,3 +107,6 @@ def main():
 
 if __name__ == "__main__":
     main()
+    import torch.distributed as _dist
+    if _dist.is_available() and _dist.is_initialized():
+        _dist.destroy_process_group()

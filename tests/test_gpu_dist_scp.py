@@ -1,0 +1,85 @@
+"""GPU: the sample-sharded reduced SCP (Model.shard + cvar_cuts with a process group).  Two ranks share the one
+GPU of the test box (gloo, collectives staged through the host); each owns half of the samples.  Both ranks must
+return the single-process iterate on the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _samples(M, S):
+    from oracle import drone as od
+    return od.sample_uncertain_parameters(np.random.RandomState(5), 'saa', M=M, S=S)
+
+
+def _worker(rank, world, port, M, S, iters, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, drone_risk, scp
+    rdist.init_from_env(backend="gloo")
+    DWs, masses, Q = _samples(M, S)
+    lo, hi = rdist.shard_bounds(M, rank, world)
+    model = drone_risk.Model(S, DWs[lo:hi], masses[lo:hi], Q[lo:hi], 'saa', 0.1).shard()
+    out = scp.run_drone_reduced(model, num_scp_iters_max=iters)
+    np.save(os.path.join(tmpdir, f"us_{rank}.npy"), out["us"])
+    np.save(os.path.join(tmpdir, f"cuts_{rank}.npy"), out["cuts"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_reduced_scp_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from riskaversetrajopt_amd import drone_risk, scp
+    M, S, iters, world = 2000, 20, 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), M, S, iters, str(tmp_path)), nprocs=world, join=True)
+    us0, us1 = np.load(tmp_path / "us_0.npy"), np.load(tmp_path / "us_1.npy")
+    assert np.array_equal(us0, us1)                                   # the ranks stay bit-identical
+    assert np.array_equal(np.load(tmp_path / "cuts_0.npy"), np.load(tmp_path / "cuts_1.npy"))
+    DWs, masses, Q = _samples(M, S)
+    single = scp.run_drone_reduced(drone_risk.Model(S, DWs, masses, Q, 'saa', 0.1), num_scp_iters_max=iters)
+    # same cuts up to fp32 summation order inside the shards
+    np.testing.assert_allclose(us0, single["us"], rtol=0, atol=2e-5)
+
+
+def _car_samples(M, S):
+    from oracle import driving as ocar
+    return ocar.sample_uncertain_parameters(np.random.RandomState(3), M, 'saa', S)
+
+
+def _car_worker(rank, world, port, M, S, iters, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, driving, scp
+    rdist.init_from_env(backend="gloo")
+    lo, hi = rdist.shard_bounds(M, rank, world)
+    samples = tuple(np.asarray(a)[lo:hi] for a in _car_samples(M, S))
+    model = driving.Model(hi - lo, 'saa', 0.05, S=S, samples=samples).shard()
+    out = scp.run_driving_reduced(model, num_scp_iters_max=iters)
+    np.save(os.path.join(tmpdir, f"car_us_{rank}.npy"), out["us"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_driving_reduced_scp_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from riskaversetrajopt_amd import driving, scp
+    M, S, iters, world = 3000, 20, 6, 2
+    mp.spawn(_car_worker, args=(world, _free_port(), M, S, iters, str(tmp_path)), nprocs=world, join=True)
+    us0, us1 = np.load(tmp_path / "car_us_0.npy"), np.load(tmp_path / "car_us_1.npy")
+    assert np.array_equal(us0, us1)
+    single = scp.run_driving_reduced(driving.Model(M, 'saa', 0.05, S=S, samples=_car_samples(M, S)),
+                                     num_scp_iters_max=iters)
+    np.testing.assert_allclose(us0, single["us"], rtol=0, atol=5e-5)
