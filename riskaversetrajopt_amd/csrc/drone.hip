@@ -773,7 +773,13 @@ bool plan(int32_t M, int32_t S, int32_t ld, int32_t* cpt, int32_t* spl) {
     *spl = 1;
     return S >= 2 && rows_lds_bytes(S) <= ROWS_LDS_MAX;
   }
-  if (*spl == 0) *spl = (M >= 65536 && ld % 4 == 0) ? 4 : ((M >= 32768 && ld % 2 == 0) ? 2 : 1);
+  if (*spl == 0) {
+    *spl = (M >= 65536 && ld % 4 == 0) ? 4 : ((M >= 32768 && ld % 2 == 0) ? 2 : 1);
+    // a given column count restricts the lane widths that exist for it
+    if (*cpt == 16 || *cpt == 32) *spl = 1;
+    if (*cpt == 8 && *spl == 4) *spl = (ld % 2 == 0) ? 2 : 1;
+    if (*cpt == 2 && *spl != 4) *cpt = 0;  // 2 columns exist for 4-sample lanes only: let the default pick
+  }
   if (*cpt == 0) *cpt = (*spl == 4) ? 4 : ((*spl == 2) ? 8 : (M >= 65536 ? 8 : 4));
   if (*spl != 1 && *spl != 2 && *spl != 4) return false;
   if (ld % *spl != 0) return false;
