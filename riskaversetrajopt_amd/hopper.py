@@ -85,6 +85,26 @@ class Model:
         return np.stack([x[..., 0] + x[..., 3] * np.sin(x[..., 2]),
                          x[..., 1] - x[..., 3] * np.cos(x[..., 2])], axis=-1)
 
+    def end_effector_x_derivatives(self, x):
+        """Chain-rule factors of the (sample-independent) map state -> end-effector x position p = x0 + x3 sin x2
+        (hopper.py:166-171) that carry dh/dpx and d2h/dpx2 to the NLP variables (x0, x2, x3) in jac_g / the
+        Hessian (hopper.py:569,577-580):  -> (J (...,3) = dp/d(x0,x2,x3),  H (...,3,3) = d2p/d(x0,x2,x3)^2)."""
+        x = np.asarray(x, dtype=np.float64)
+        s, c = np.sin(x[..., 2]), np.cos(x[..., 2])
+        J = np.stack([np.ones_like(s), x[..., 3] * c, s], axis=-1)
+        H = np.zeros(x.shape[:-1] + (3, 3))
+        H[..., 1, 1] = -x[..., 3] * s
+        H[..., 1, 2] = H[..., 2, 1] = c
+        return J, H
+
+    def contact_chain(self, Z):
+        """The factors above at the contact steps of ``contact_inputs(Z)``: J (C,3), H (C,3,3).  With the device
+        outputs:  dh_ic/d(x0,x2,x3)_c = dh_dpx[i,c] J[c];  sum_i lam_ic d2h_ic/d(.)2 = D2[c] J[c] J[c]' + (sum_i lam_ic
+        dh_dpx[i,c]) H[c];  mixed with fz: D1[c] J[c]."""
+        xs_mat, _ = self.convert_z_to_xs_us_mats(Z)
+        xc = np.concatenate([xs_mat[:self.time_jump], xs_mat[self.time_land:-1]])
+        return self.end_effector_x_derivatives(xc)
+
     def contact_inputs(self, Z):
         """Contact-phase mask of hopper.py:305-311 -> (px (C,), forces (C,2))."""
         xs_mat, us_mat = self.convert_z_to_xs_us_mats(Z)

@@ -103,3 +103,48 @@ def test_monte_carlo_verification():
     h = model.no_slip_values(px, forces)
     np.testing.assert_array_equal(Zs, h.max(1))
     np.testing.assert_array_equal(ok, Zs <= 1e-6)
+
+
+def test_end_effector_chain_factors_match_finite_differences():
+    """dp/d(x0,x2,x3) and its Hessian for p = x0 + x3 sin x2 (hopper.py:166-171): the sample-independent chain that
+    carries the kernel's dh/dpx, d2h/dpx2 to the NLP variables."""
+    from oracle import hopper as oh
+    rng = np.random.RandomState(0)
+    o = oh.Model(*oh.sample_friction_fields(np.random.RandomState(1), 4))
+    x = rng.randn(7, 8)
+    J, H = o.end_effector_x_derivatives(x)
+    eps = 1e-6
+    for col, k in enumerate((0, 2, 3)):
+        xp, xm = x.copy(), x.copy()
+        xp[:, k] += eps
+        xm[:, k] -= eps
+        fd = (o.end_effector_position(xp)[:, 0] - o.end_effector_position(xm)[:, 0]) / (2 * eps)
+        np.testing.assert_allclose(J[:, col], fd, atol=1e-8)
+        Jp, _ = o.end_effector_x_derivatives(xp)
+        Jm, _ = o.end_effector_x_derivatives(xm)
+        np.testing.assert_allclose(H[:, :, col], (Jp - Jm) / (2 * eps), atol=1e-7)
+
+
+def test_slip_rows_chain_to_state_variables():
+    """d h_ic / d (x0, x2, x3) at a contact step = dh_dpx[i,c] * J[c]  (the formula documented in contact_chain),
+    against finite differences of the slip rows through the full variable vector."""
+    from oracle import hopper as oh
+    S, M = 30, 3
+    o = oh.Model(*oh.sample_friction_fields(np.random.RandomState(1), M), method='saa', alpha=0.1, S=S)
+    rng = np.random.RandomState(2)
+    Z = rng.randn(o.num_vars) * 0.3
+    px, forces = o.contact_inputs(Z)
+    _, _, dh_dpx = o.slip_partials(px, forces)
+    J, _ = o.contact_chain(Z)
+    steps = np.concatenate([np.arange(0, o.time_jump), np.arange(o.time_land, S)])
+    eps = 1e-6
+    for c in (0, 5, len(steps) - 1):
+        t = steps[c]
+        for col, k in enumerate((0, 2, 3)):
+            idx = t * oh.n_x + k                         # xs_vec is the 'F' flatten of (n_x, S+1): entry (k, t)
+            Zp, Zm = Z.copy(), Z.copy()
+            Zp[idx] += eps
+            Zm[idx] -= eps
+            hp = o.no_slip_values(*o.contact_inputs(Zp))[:, c]
+            hm = o.no_slip_values(*o.contact_inputs(Zm))[:, c]
+            np.testing.assert_allclose((hp - hm) / (2 * eps), dh_dpx[:, c] * J[c, col], rtol=1e-5, atol=1e-8)
