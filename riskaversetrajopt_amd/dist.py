@@ -32,8 +32,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RATO_DIST_BACKEND=gloo: functional test of the multi-rank path where the ranks share one GPU
+            backend = os.environ.get("RATO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
+        if os.environ.get("RATO_SINGLE_GPU") == "1":
+            local = 0                                   # every rank on cuda:0 (tests on a 1-GPU box; gloo only)
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
@@ -75,8 +78,7 @@ def exchange(sums64, Z32, group=None):
     world = dist.get_world_size(group)
     n_sums, M_local = sums64.numel(), Z32.numel()
     rec = pack_record(sums64.reshape(-1).to(torch.float64), Z32.to(torch.float32))
-    out = torch.empty(world * rec.numel(), dtype=torch.uint8, device=rec.device)
-    dist.all_gather_into_tensor(out, rec, group=group)
+    out = gather_concat(rec, group)
     sums, Z_all = unpack_records(out, world, n_sums, M_local)
     total = sums[0].clone()
     for r in range(1, world):          # fixed (rank) order: bitwise identical on every rank
@@ -117,7 +119,12 @@ def exchange_record(rec, group=None):
         return rec.sums, rec.Z
     world = dist.get_world_size(group)
     all_, Z_all, total = rec._buffers(world)
-    dist.all_gather_into_tensor(all_, rec.buf, group=group)
+    if _staged(rec.buf, group):                          # gloo + device tensors: stage through the host
+        host = torch.empty(all_.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, rec.buf.cpu(), group=group)
+        all_.copy_(host)
+    else:
+        dist.all_gather_into_tensor(all_, rec.buf, group=group)
     if all_.is_cuda:
         from . import _lib
         lib = _lib.load()

@@ -83,3 +83,48 @@ def test_sharded_driving_reduced_scp_equals_single_process(tmp_path):
     single = scp.run_driving_reduced(driving.Model(M, 'saa', 0.05, S=S, samples=_car_samples(M, S)),
                                      num_scp_iters_max=iters)
     np.testing.assert_allclose(us0, single["us"], rtol=0, atol=5e-5)
+
+
+def _lin_worker(rank, world, port, M, S, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, drone_risk, stats
+    rdist.init_from_env(backend="gloo")
+    DWs, masses, Q = _samples(M, S)
+    lo, hi = rdist.shard_bounds(M, rank, world)
+    model = drone_risk.Model(S, DWs[lo:hi], masses[lo:hi], Q[lo:hi], 'saa', 0.1)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    r = model.linearize_device(us)
+    # the bench's zero-copy record: the kernels write Z and the sums straight into the send buffer
+    rec = rdist.Record(6 * S + 6, hi - lo, "cuda:0", z_row=r["_Z"].numel())
+    r["_Z"], r["sums"] = rec.Z_row[:r["_Z"].numel()], rec.sums
+    r = model.linearize_device(us, out=r)
+    total, Z_all = rdist.exchange_record(rec)
+    st = stats.risk_stats_device(Z_all, 0.1).cpu().numpy()
+    np.save(os.path.join(tmpdir, f"lin_{rank}.npy"), np.concatenate([total.cpu().numpy(), st, Z_all.double().cpu().numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_record_exchange_equals_single_process(tmp_path):
+    """One bench step on two ranks (linearize -> record all-gather -> unpack kernel -> statistics on the gathered Z)
+    == the same step on the full batch in one process."""
+    import torch.multiprocessing as mp
+    from riskaversetrajopt_amd import drone_risk, stats
+    M, S, world = 3000, 20, 2
+    mp.spawn(_lin_worker, args=(world, _free_port(), M, S, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "lin_0.npy"), np.load(tmp_path / "lin_1.npy")
+    assert np.array_equal(a, b)                                       # bitwise identical on both ranks
+    DWs, masses, Q = _samples(M, S)
+    model = drone_risk.Model(S, DWs, masses, Q, 'saa', 0.1)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    r = model.linearize_device(us)
+    n = 6 * S + 6
+    np.testing.assert_array_equal(a[n + 10:], r["Z"].double().cpu().numpy())         # Z: same kernel, rank order
+    st = stats.risk_stats_device(r["Z"], 0.1).cpu().numpy()
+    np.testing.assert_array_equal(a[n:n + 10], st)                                   # exact selection on the same Z
+    np.testing.assert_allclose(a[:n], r["sums"].cpu().numpy(), rtol=1e-6, atol=1e-4)  # fp32 block partials differ
