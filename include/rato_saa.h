@@ -53,7 +53,9 @@ extern "C" {
 #define RATO_DRONE_NOBS 3   /* drone_params.py:34-43: n_obs = 3 */
 #define RATO_HOPPER_NFEAT 30 /* hopper.py:69: num_mu_features = 30 */
 
-/* ABI version, bumped on any signature/layout change. */
+/* ABI version, bumped on any signature/layout change (2: factored Jacobian W / A22 outputs, CVaR-cut oracle
+ * entry points, record unpack).  The Python binding refuses a library that reports another version. */
+#define RATO_ABI_VERSION 2
 int rato_abi_version(void);
 
 /* ------------------------------------------------------------------ drone */

@@ -6,6 +6,7 @@ import os
 from . import _build
 
 _LIB = None
+ABI_VERSION = 2              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -88,6 +89,9 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the .so is stale: loud by design
         fn.restype = res
         fn.argtypes = args
+    if lib.rato_abi_version() != ABI_VERSION:
+        raise RatoError(f"{path} reports ABI version {lib.rato_abi_version()}, this binding needs {ABI_VERSION}: "
+                        "rebuild with `python -m riskaversetrajopt_amd._build`")
     _LIB = lib
     return lib
 
