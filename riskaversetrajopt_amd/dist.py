@@ -131,7 +131,10 @@ def exchange_record(rec, group=None):
         _lib.check(lib.rato_unpack_records(_lib.ptr(all_), world, rec.n_sums, rec.M_local, rec.rec_bytes,
                                            _lib.ptr(total), _lib.ptr(Z_all), _lib.current_stream()),
                    "rato_unpack_records")
-    else:                                                # host tensors (gloo tests): same layout, torch views
+    else:
+        # HOST tensors only (the world-size-2 gloo tests of the exchange logic, which run without a GPU): the same
+        # byte layout re-sliced with torch views.  This is record plumbing, not a CPU version of any kernel of the
+        # hot path -- those exist on the device only and raise RatoError without the HIP library.
         v = all_.view(world, rec.rec_bytes)
         sums = v[:, :8 * rec.n_sums].contiguous().view(torch.float64).view(world, rec.n_sums)
         total.copy_(sums[0])
