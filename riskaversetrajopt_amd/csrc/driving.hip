@@ -25,43 +25,82 @@ namespace {
 __host__ __device__ inline size_t ego_off_Eu(int S) { return (size_t)(S + 1) * 4; }
 __host__ __device__ inline size_t ego_off_Epos(int S) { return ego_off_Eu(S) + (size_t)(S + 1) * 2; }
 __host__ __device__ inline size_t ego_total(int S) { return ego_off_Epos(S) + (size_t)(S + 1) * 2 * 2 * S; }
+inline size_t ego_lds_bytes(int S) {   // car_ego_kernel's tables: 6S+4 floats, then 3(S+1) doubles
+  return (size_t)((6 * S + 4 + 1) & ~1) * sizeof(float) + (size_t)(S + 1) * 3 * sizeof(double);
+}
 
-// One block.  Thread 0 rolls the ego out (driving.py:166-173); then one thread per
-// control column propagates E (4 rows) through A^e_t = d ego_{t+1} / d ego_t.
+// One block, the sample-independent prologue of every driving call (driving.py:166-173 and its control
+// sensitivity).  The first version rolled the ego out on ONE thread, re-evaluated sincosf in every (column, step) and
+// went through global memory between its stages: 30 us, 18 % of a linearize call at M = 1e5.  Here
+//   A  thread t folds the trajectory up to step t in fp64 (rounded once) and evaluates sin / cos(phi_t),
+//   D  one thread per control column propagates E (4 rows) through A^e_t = d ego_{t+1} / d ego_t from the tables,
+// with the ego table in LDS; the per-step tangents Epos / Eu are written only when the caller needs them
+// (want_E: the forward/column linearize kernel; not the row-parallel kernel, not eval).
 __global__ __launch_bounds__(RATO_BLOCK) void car_ego_kernel(rato_car_params P, const float* __restrict__ us,
                                                             float* __restrict__ scratch,
                                                             float* __restrict__ final_du,
-                                                            float* __restrict__ final_rhs) {
+                                                            float* __restrict__ final_rhs, int want_E) {
+  extern __shared__ __attribute__((aligned(8))) float ego_lds[];   // v | ph | x | y [S+1] each | cs | sn [S] each | fp64 v, cos, sin [S+1] each
   const int S = P.S, NC = 2 * S;
+  float* sv = ego_lds;
+  float* sph = sv + (S + 1);
+  float* sx = sph + (S + 1);
+  float* sy = sx + (S + 1);
+  float* scs = sy + (S + 1);
+  float* ssn = scs + S;
+  double* dv = reinterpret_cast<double*>(ego_lds + ((6 * S + 4 + 1) & ~1));
+  double* dcs = dv + (S + 1);
+  double* dsn = dcs + (S + 1);
   float* ego = scratch;
   float* Eu = scratch + ego_off_Eu(S);
   float* Epos = scratch + ego_off_Epos(S);
-  if (threadIdx.x == 0) {
-    float x = P.ego_init[0], y = P.ego_init[1], v = P.ego_init[2], ph = P.ego_init[3];
-    ego[0] = x; ego[1] = y; ego[2] = v; ego[3] = ph;
-    for (int t = 0; t < S; ++t) {
-      float sn, cs;
-      sincosf(ph, &sn, &cs);
-      const float xn = x + P.dt * v * cs, yn = y + P.dt * v * sn;
-      const float vn = v + P.dt * us[t * 2 + 0], pn = ph + P.dt * us[t * 2 + 1];
-      x = xn; y = yn; v = vn; ph = pn;
-      ego[(t + 1) * 4 + 0] = x; ego[(t + 1) * 4 + 1] = y; ego[(t + 1) * 4 + 2] = v; ego[(t + 1) * 4 + 3] = ph;
+  // one thread per step folds the trajectory in fp64 and rounds once (identical to the row-parallel kernel's
+  // in-kernel tables, so eval and linearize see the same ego)
+  const double dt = P.dt;
+  for (int t = threadIdx.x; t <= S; t += RATO_BLOCK) {
+    double v = P.ego_init[2], ph = P.ego_init[3];
+    for (int k = 0; k < t; ++k) {
+      v += dt * (double)us[k * 2 + 0];
+      ph += dt * (double)us[k * 2 + 1];
+    }
+    double sn, cs;
+    sincos(ph, &sn, &cs);
+    dv[t] = v;
+    dcs[t] = cs;
+    dsn[t] = sn;
+    sv[t] = (float)v;
+    sph[t] = (float)ph;
+    if (t < S) {
+      scs[t] = (float)cs;
+      ssn[t] = (float)sn;
     }
   }
-  __threadfence_block();
   __syncthreads();
+  for (int t = threadIdx.x; t <= S; t += RATO_BLOCK) {
+    double x = P.ego_init[0], y = P.ego_init[1];
+    for (int k = 0; k < t; ++k) {
+      x += dt * dv[k] * dcs[k];
+      y += dt * dv[k] * dsn[k];
+    }
+    sx[t] = (float)x;
+    sy[t] = (float)y;
+    ego[t * 4 + 0] = sx[t]; ego[t * 4 + 1] = sy[t]; ego[t * 4 + 2] = sv[t]; ego[t * 4 + 3] = sph[t];
+  }
+  __syncthreads();
+  if (!final_du && !final_rhs && !want_E) return;   // eval: the trajectory is all that is needed
+  // D: control columns
   __shared__ float red[RATO_BLOCK / RATO_WAVE][4];
   float rhs_acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = threadIdx.x; c < NC; c += RATO_BLOCK) {
     const int s = c >> 1, i = c & 1;
     const float uc = us[c];
     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-    Epos[(size_t)(0 * 2 + 0) * NC + c] = 0.f;
-    Epos[(size_t)(0 * 2 + 1) * NC + c] = 0.f;
+    if (want_E) {
+      Epos[(size_t)(0 * 2 + 0) * NC + c] = 0.f;
+      Epos[(size_t)(0 * 2 + 1) * NC + c] = 0.f;
+    }
     for (int t = 0; t < S; ++t) {
-      const float v = ego[t * 4 + 2], ph = ego[t * 4 + 3];
-      float sn, cs;
-      sincosf(ph, &sn, &cs);
+      const float v = sv[t], sn = ssn[t], cs = scs[t];
       const float n0 = e0 + P.dt * cs * e2 - P.dt * v * sn * e3;
       const float n1 = e1 + P.dt * sn * e2 + P.dt * v * cs * e3;
       float n2 = e2, n3 = e3;
@@ -69,8 +108,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_ego_kernel(rato_car_params P, 
         if (i == 0) n2 += P.dt; else n3 += P.dt;
       }
       e0 = n0; e1 = n1; e2 = n2; e3 = n3;
-      Epos[(size_t)((t + 1) * 2 + 0) * NC + c] = e0;
-      Epos[(size_t)((t + 1) * 2 + 1) * NC + c] = e1;
+      if (want_E) {
+        Epos[(size_t)((t + 1) * 2 + 0) * NC + c] = e0;
+        Epos[(size_t)((t + 1) * 2 + 1) * NC + c] = e1;
+      }
     }
     if (final_du) {
       final_du[0 * NC + c] = e0; final_du[1 * NC + c] = e1; final_du[2 * NC + c] = e2; final_du[3 * NC + c] = e3;
@@ -89,8 +130,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_ego_kernel(rato_car_params P, 
 #pragma unroll
     for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += red[w][threadIdx.x];
     // val_final = -(x_S[:4] - goal) + v_final_du . u   (driving.py:288)
-    final_rhs[threadIdx.x] = -(ego[S * 4 + threadIdx.x] - P.ego_goal[threadIdx.x]) + acc;
+    const float xS = (threadIdx.x == 0) ? sx[S] : ((threadIdx.x == 1) ? sy[S] : ((threadIdx.x == 2) ? sv[S] : sph[S]));
+    final_rhs[threadIdx.x] = -(xS - P.ego_goal[threadIdx.x]) + acc;
   }
+  if (!want_E) return;
+  __threadfence_block();
+  __syncthreads();
   // Eu[t] = Epos[t] . u  (one thread per (t, axis); fixed summation order)
   for (int idx = threadIdx.x; idx < (S + 1) * 2; idx += RATO_BLOCK) {
     float acc = 0.f;
@@ -291,16 +336,20 @@ typedef float cfloat4_t __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t car_rows_lds_floats(int S) {
   // KK float2 + QP float2 + K11 float per (k, lane) | EGOP float2[S+1] | EC float4[S] | US float2[S] | head (+pad)
-  return (size_t)S * CROWS_SAMPLES * 5 + (size_t)(S + 1) * 2 + (size_t)S * 4 + (size_t)S * 2 + 4;
+  // | ego v, phi [S+1] each | 8 x 4 reduction slots (final rows, workgroup 0) | fp64 v, cos, sin [S+1] each
+  return (size_t)S * CROWS_SAMPLES * 5 + (size_t)(S + 1) * 2 + (size_t)S * 4 + (size_t)S * 2 + 4 +
+         (size_t)(S + 1) * 2 + 32 + (size_t)(S + 1) * 6 + 2;
 }
 
 __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel(
     rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
-    const float* __restrict__ scratch, float* __restrict__ G, float* __restrict__ g_up, float* __restrict__ Z) {
+    float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
+    float* __restrict__ Z) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   const size_t M = (size_t)P.M;
   const int S = P.S;
+  constexpr int NT = CROWS_NW * RATO_WAVE;
   const int lane = threadIdx.x & (RATO_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RATO_WAVE);   // scalar: wave-level branches stay scalar
   // (no __restrict__: QP[t] holds step t's noise until the rollout overwrites it with q_{t+1})
@@ -311,20 +360,90 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   cfloat2_t* US = EGOP + (S + 1);                                            // [S]
   float* K11 = reinterpret_cast<float*>(US + S);                             // [S][64]
   int* head = reinterpret_cast<int*>(K11 + (size_t)S * CROWS_SAMPLES);
+  float* SV = reinterpret_cast<float*>(head + 4);                            // [S+1] ego speed
+  float* SPH = SV + (S + 1);                                                 // [S+1] ego heading
+  float* RED = SPH + (S + 1);                                                // [8][4]
+  double* DV = reinterpret_cast<double*>(car_lds_raw + (((reinterpret_cast<unsigned char*>(RED + 32) - car_lds_raw) + 7) & ~size_t(7)));
+  double* DCS = DV + (S + 1);                                                // fp64 speed | cos | sin of the ego
+  double* DSN = DCS + (S + 1);
 
   const size_t m_raw = (size_t)blockIdx.x * CROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
   const float w_s = w_speed[m], w_r = w_rep[m];
   const float ks = P.dt * w_s;
-  const float* __restrict__ ego = scratch;
 
-  // ---- phase 0: stage noise, controls, ego tables
+  // ---- phase 0: controls, then the noise tile requested, then the (sample-independent) ego tables computed by
+  // this workgroup WHILE those loads are in flight (they queue behind the chip-wide store stream for ~10 us): the
+  // separate one-workgroup ego prologue launch (10-30 us in front of every linearize call) is gone.
+  {
+    for (int t = threadIdx.x; t < S; t += NT) {
+      cfloat2_t u2;
+      u2.x = us[t * 2 + 0];
+      u2.y = us[t * 2 + 1];
+      US[t] = u2;
+    }
+    if (threadIdx.x == 0) {
+      head[0] = 0;
+      head[1] = 0;   // rollout progress: number of finished steps
+    }
+  }
+  __syncthreads();
   {
     float* QPf = reinterpret_cast<float*>(QP);
     const int nrows = 2 * S;
     constexpr int MAXR = 16;
-    for (int r0 = wave; r0 < nrows; r0 += CROWS_NW * MAXR) {
+    float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+      const int r = wave + i * CROWS_NW;
+      tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
+    }
+    // ego trajectory (driving.py:166-173), one thread per step, folded in fp64 and rounded once: the ego is
+    // sample independent, so this costs a microsecond per workgroup and keeps the 40-step accumulation error of
+    // the positions (x ~ 20 m, fp32 ulp 2e-6) out of every sample's distance / normal / Jacobian
+    const double dt = P.dt;
+    for (int t = threadIdx.x; t <= S; t += NT) {
+      double v = P.ego_init[2], ph = P.ego_init[3];
+      for (int k = 0; k < t; ++k) {
+        const cfloat2_t u2 = US[k];
+        v += dt * (double)u2.x;
+        ph += dt * (double)u2.y;
+      }
+      double sn, cs;
+      sincos(ph, &sn, &cs);   // once per step
+      DV[t] = v;
+      DCS[t] = cs;
+      DSN[t] = sn;
+      SV[t] = (float)v;
+      SPH[t] = (float)ph;
+      if (t < S) {
+        cfloat4_t c;
+        c.x = (float)(dt * cs);
+        c.y = (float)(dt * sn);
+        c.z = (float)(-dt * v * sn);
+        c.w = (float)(dt * v * cs);
+        EC[t] = c;
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t <= S; t += NT) {
+      double x = P.ego_init[0], y = P.ego_init[1];
+      for (int k = 0; k < t; ++k) {
+        x += dt * DV[k] * DCS[k];
+        y += dt * DV[k] * DSN[k];
+      }
+      cfloat2_t e;
+      e.x = (float)x;
+      e.y = (float)y;
+      EGOP[t] = e;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+      const int r = wave + i * CROWS_NW;
+      if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp0[i];
+    }
+    for (int r0 = wave + CROWS_NW * MAXR; r0 < nrows; r0 += CROWS_NW * MAXR) {   // long horizons: further batches
       float tmp[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -337,33 +456,46 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp[i];
       }
     }
-    for (int t = threadIdx.x; t <= S; t += CROWS_NW * RATO_WAVE) {
-      cfloat2_t e;
-      e.x = ego[t * 4 + 0];
-      e.y = ego[t * 4 + 1];
-      EGOP[t] = e;
-      if (t < S) {
-        const float v = ego[t * 4 + 2], ph = ego[t * 4 + 3];
-        float sn, cs;
-        sincosf(ph, &sn, &cs);
-        cfloat4_t c;
-        c.x = P.dt * cs;
-        c.y = P.dt * sn;
-        c.z = -P.dt * v * sn;
-        c.w = P.dt * v * cs;
-        EC[t] = c;
-        cfloat2_t u2;
-        u2.x = us[t * 2 + 0];
-        u2.y = us[t * 2 + 1];
-        US[t] = u2;
-      }
-    }
-    if (threadIdx.x == 0) {
-      head[0] = 0;
-      head[1] = 0;   // rollout progress: number of finished steps
-    }
   }
   __syncthreads();
+  // final rows (sample independent: driving.py:283-288, :311): workgroup 0 propagates one control column per thread
+  if (blockIdx.x == 0 && (final_du || final_rhs)) {
+    const int NC = 2 * S;
+    float rhs_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = threadIdx.x; c < NC; c += NT) {
+      const int s = c >> 1, i = c & 1;
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+      for (int t = 0; t < S; ++t) {
+        const cfloat4_t k = EC[t];
+        const float n0 = e0 + k.x * e2 + k.z * e3;
+        const float n1 = e1 + k.y * e2 + k.w * e3;
+        float n2 = e2, n3 = e3;
+        if (t == s) {
+          if (i == 0) n2 += P.dt; else n3 += P.dt;
+        }
+        e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+      }
+      if (final_du) {
+        final_du[0 * NC + c] = e0; final_du[1 * NC + c] = e1; final_du[2 * NC + c] = e2; final_du[3 * NC + c] = e3;
+      }
+      const float uc = (i == 0) ? US[s].x : US[s].y;
+      rhs_acc[0] += e0 * uc; rhs_acc[1] += e1 * uc; rhs_acc[2] += e2 * uc; rhs_acc[3] += e3 * uc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sres = rato::wave_sum(rhs_acc[r]);
+      if (lane == 0) RED[wave * 4 + r] = sres;
+    }
+    __syncthreads();
+    if (final_rhs && threadIdx.x < 4) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < CROWS_NW; ++w) acc += RED[w * 4 + threadIdx.x];
+      const float xS = (threadIdx.x == 0) ? EGOP[S].x : ((threadIdx.x == 1) ? EGOP[S].y
+                                                        : ((threadIdx.x == 2) ? SV[S] : SPH[S]));
+      final_rhs[threadIdx.x] = -(xS - P.ego_goal[threadIdx.x]) + acc;   // driving.py:288
+    }
+  }
 
   // ---- phase 1 (wave 0) overlapped with phase 2 (the other waves, then everybody): row t only needs steps
   // 0..t, so the rows are swept shortest first behind the rollout, which publishes its progress in LDS.
@@ -471,7 +603,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
 }
 
 bool params_ok(const rato_car_params* p) {
-  return p && p->M > 0 && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
+  return p && p->M > 0 && p->S > 0 && p->S <= 1024 && p->dt > 0.0f;   // 1024: the ego prologue's LDS tables (48 KB)
 }
 
 template <int SPT>
@@ -496,8 +628,8 @@ extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const fl
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
-  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, (float*)nullptr,
-                     (float*)nullptr);
+  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), ego_lds_bytes(p->S), st, *p, us, ego_scratch,
+                     (float*)nullptr, (float*)nullptr, 0);
   hipLaunchKernelGGL(car_eval_kernel, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW, x0_ped,
                      w_speed, w_rep, ego_scratch, Z, xs, g);
   RATO_LAUNCH_CHECK();
@@ -540,9 +672,13 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
   if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
     return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
-  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), 0, st, *p, us, ego_scratch, final_du, final_rhs);
   int32_t spt = cols_per_thread, tile = 0;
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
+  // the ego prologue (trajectory + per-step tangents Epos, Eu) serves the forward/column kernel; the row-parallel
+  // kernel builds its ego tables itself, under the latency of its noise loads
+  if (spt != -1)
+    hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), ego_lds_bytes(p->S), st, *p, us, ego_scratch,
+                       final_du, final_rhs, 1);
   if (spt == -1) {
     const size_t lds = car_rows_lds_bytes(p->S);
     static std::atomic<size_t> lds_attr_set{64 * 1024};   // cached: capture-safe after the first call
@@ -554,7 +690,7 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     }
     dim3 grid((p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES), block(CROWS_NW * RATO_WAVE);
     hipLaunchKernelGGL(car_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                       ego_scratch, G, g_up, Z);
+                       final_du, final_rhs, G, g_up, Z);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
