@@ -286,7 +286,10 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
 // ---- single-workgroup form for small M (<= RS_SINGLE_MAX): the whole selection in ONE launch (Z is a few tens of
 // KB and L2-resident; five ~5 us launches become one ~10 us launch).  Same arithmetic, fixed reduction order.
 constexpr int RS1_T = 1024;
-constexpr long RS_SINGLE_MAX = 1 << 14;  // measured: at M = 1e5 one workgroup (LDS atomic contention) is slower than 5 launches
+// Measured per call (tools/stats_time.py): one workgroup 15 / 19 / 24 / 36 us at M = 1e3 / 4e3 / 1e4 / 1.6e4 against
+// ~25 us for the six launches at any M <= 1e5 (launch-bound); and 8 us instead of 46 us of HOST issue time.  (Wave-level
+// aggregation of the LDS histogram updates was tried and bought nothing: the cost is passes and barriers, not conflicts.)
+constexpr long RS_SINGLE_MAX = 1 << 13;
 
 __device__ __forceinline__ double block_sum_1024(double v, double* red) {
   v = rato::wave_sum(v);

@@ -13,7 +13,7 @@ def _np_stats(Z32, alpha, thr=1e-6):
                 frac=np.mean(Z32 <= np.float32(thr)), mean=Z.mean(), max=Z.max())
 
 
-@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 10000, 123457, 1 << 14, (1 << 14) + 1, 1 << 20])
+@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 123457, 1 << 14, 1 << 20])
 @pytest.mark.parametrize("alpha", [0.01, 0.05, 0.3, 1.0])
 def test_risk_stats_exact(M, alpha):
     from riskaversetrajopt_amd import stats
