@@ -54,8 +54,8 @@ extern "C" {
 #define RATO_HOPPER_NFEAT 30 /* hopper.py:69: num_mu_features = 30 */
 
 /* ABI version, bumped on any signature/layout change (2: factored Jacobian W / A22 outputs, CVaR-cut oracle
- * entry points, record unpack).  The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 2
+ * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes).  The Python binding refuses a library that reports another version. */
+#define RATO_ABI_VERSION 3
 int rato_abi_version(void);
 
 /* ------------------------------------------------------------------ drone */
@@ -266,8 +266,32 @@ int rato_saa_rowmax(const float* G, const float* W /* NULL, or the factor of a f
  * rato_saa_rowmax to fp32 rounding.   us [S][3] (n_u = 3); p supplies M, ld, S, dt, kp.
  */
 int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
+                               int32_t a22_axes /* 2: [S][2][ld] of rato_drone_linearize; 3: [S][3][ld] of
+                                                   rato_drone_linearize_generators */,
                                const float* W, const float* g_up, const float* us,
                                float* m_out, int32_t* arg_out, void* stream);
+
+/*
+ * Generators-only linearization (drone): A22 [S][3 axes][ld], W [3 obs][S][2][ld], g_up [3 obs][S][ld], Z [M] or
+ * NULL, part [ceil(M/256)][6S+6] (per-block sums, layout of rato_drone_linearize) -- the whole linearization in
+ * 12 S numbers per sample and NO Jacobian entries: Phi[t,s,a] = e_0' A_t ... A_{s+1} B is regenerated from A22 by
+ * the consumers (rato_drone_rowmax_implicit for G.u, rato_drone_tail_rows_implicit for rows of G).  60 B per
+ * sample-step of HBM traffic instead of 245 B; what a reduced SCP iteration needs (Model.solve_reduced).
+ */
+int rato_drone_linearize_generators(const rato_drone_params* p, const float* us, const float* dW,
+                                    const float* mass, const float* Qsym,
+                                    float* A22, float* W, float* g_up, float* Z, float* part, void* stream);
+
+/*
+ * rato_saa_tail_rows / rato_saa_tail_rows_batch for the drone without reading the Jacobian: the arg-max row of
+ * every tail sample is regenerated from A22 (adjoint sweep from its t*).  slots == NULL: one cut in slot 0 of the
+ * rings (K = 1).  part [ceil(M/256)][K][2(S-1) + 1] as in rato_saa_tail_rows_batch.
+ */
+int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass, const float* A22, int32_t a22_axes,
+                                  const float* W, const float* g_up,
+                                  const float* m_base, const int32_t* arg_base, const double* stats_base,
+                                  int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
+                                  float* part, void* stream);
 
 /*
  * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =

@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 2              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 3              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -32,7 +32,12 @@ SIGNATURES = {
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 10 + [C.c_int32, C.c_int32, c_stream]),
-    "rato_drone_rowmax_implicit": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
+    "rato_drone_rowmax_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32] +
+                                   [c_float_p] * 5 + [c_stream]),
+    "rato_drone_linearize_generators": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [c_stream]),
+    "rato_drone_tail_rows_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32] +
+                                      [c_float_p] * 5 + [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p,
+                                                         c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

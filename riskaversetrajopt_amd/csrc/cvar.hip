@@ -281,12 +281,103 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
   }
 }
 
+// Jacobian-free tail rows for the drone (single cut or K kept cuts, like tail_rows_batch_kernel): the arg-max row
+// (j*, t*) of a tail sample is  W[j*,t*,a] Phi[t*,s,a],  Phi[t*, k-1, a] = (mu_k)[1] dt/m  with  mu_{t*+1} = e_0',
+// mu_k = mu_{k+1} A_k  -- the adjoint sweep of the linearize kernel, regenerated here from A22.  The lanes walk k
+// from S-1 down together; a lane joins at k = t*_i.  Output layout of tail_rows_batch_kernel.
+__global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
+    rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22, int a22_axes,
+    const float* __restrict__ W, const float* __restrict__ g_up, const float* __restrict__ m_base,
+    const int* __restrict__ arg_base, const double* __restrict__ stats_base, long stats_stride,
+    const int* __restrict__ slots, double alphaM, float* __restrict__ part) {
+  extern __shared__ float tri_lds[];   // [4 waves][2*(S-1) + 1]
+  const int S = P.S;
+  const long M = P.M, ld = P.ld;
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots ? slots[kk] : 0;
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  const double* __restrict__ st = stats_base + slot * stats_stride;
+  const float tstar = (float)st[0];
+  const double n_gt = st[8], n_eq = st[9];
+  const double lq = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
+  const float lambda = (float)fmin(fmax(lq, 0.0), 1.0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m_raw = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = m_raw < M;
+  const long m = valid ? m_raw : M - 1;
+  float w = 0.0f;
+  int t = 0, r = 0;
+  if (valid) {
+    const float mv = mvals[m];
+    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+    const int a = arg[m];
+    r = a / S;
+    t = a - r * S;
+  }
+  float w0 = 0.0f, w1 = 0.0f, wg = 0.0f, a21 = 0.0f, dtm = 0.0f;
+  if (w != 0.0f) {
+    const float inv_m = 1.0f / mass[m];
+    a21 = -P.kp * P.dt * inv_m;
+    dtm = P.dt * inv_m;
+    w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m] * dtm;
+    w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m] * dtm;
+    wg = w * g_up[((size_t)r * S + t) * ld + m];
+  }
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  float m0x = 0.0f, m1x = 0.0f, m0y = 0.0f, m1y = 0.0f;
+  constexpr int SB = 8;
+  for (int kb = S - 1; kb >= 1; kb -= SB) {
+    float ax[SB], ay[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {   // the a22 of the batch for the lanes that are in the sweep at that step
+      const int k = kb - i;
+      const bool on = (w != 0.0f) && k >= 1 && k <= t;
+      ax[i] = on ? A22[((size_t)k * a22_axes + 0) * ld + m] : 0.0f;
+      ay[i] = on ? A22[((size_t)k * a22_axes + 1) * ld + m] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int k = kb - i;
+      if (k >= 1) {   // wave-uniform
+        const bool on = (w != 0.0f) && k <= t;
+        if (on && k == t) {
+          m0x = 1.0f; m1x = 0.0f; m0y = 1.0f; m1y = 0.0f;   // mu_{t*+1} = e_0'
+        }
+        float cx = 0.0f, cy = 0.0f;
+        if (on) {
+          const float n0x = m0x + m1x * a21, n1x = m0x * P.dt + m1x * ax[i];
+          const float n0y = m0y + m1y * a21, n1y = m0y * P.dt + m1y * ay[i];
+          m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
+          cx = w0 * m1x;
+          cy = w1 * m1y;
+        }
+        const float s0 = rato::wave_sum_dpp(cx);
+        const float s1 = rato::wave_sum_dpp(cy);
+        if (lane == 0) {
+          tri_lds[wave * nc + (k - 1) * 2 + 0] = s0;
+          tri_lds[wave * nc + (k - 1) * 2 + 1] = s1;
+        }
+      }
+    }
+  }
+  const float sg = rato::wave_sum_dpp(wg);
+  if (lane == 0) tri_lds[wave * nc + nw] = sg;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += tri_lds[wv * nc + i];
+    part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
+  }
+}
+
 // Jacobian-free form of rowmax for the drone: one lane per sample, one pass over the step-Jacobian table
 // A22 [S][2][ld], W [3][S][2][ld] and g_up [3][S][ld] (11 S floats per sample).  (G_i u)_{j,t} =
 // W[j,t,x] dp_x(t+1) + W[j,t,y] dp_y(t+1) with d x_{k+1} = A_k d x_k + B u_k, d x_0 = 0 — the forward form of
 // the adjoint sweep that produced Phi (drone.hip), so the values agree with rowmax_kernel<3, true> to rounding.
 __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
-    rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22,
+    rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22, int a22_axes,
     const float* __restrict__ W, const float* __restrict__ g_up, const float* __restrict__ us,
     float* __restrict__ m_out, int* __restrict__ arg_out) {
   const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
@@ -305,8 +396,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = (t0 + i < S) ? t0 + i : S - 1;
-      a2[i][0] = A22[((size_t)t * 2 + 0) * ld + m];
-      a2[i][1] = A22[((size_t)t * 2 + 1) * ld + m];
+      a2[i][0] = A22[((size_t)t * a22_axes + 0) * ld + m];
+      a2[i][1] = A22[((size_t)t * a22_axes + 1) * ld + m];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         wv[i][j][0] = W[(((size_t)j * S + t) * 2 + 0) * ld + m];
@@ -341,15 +432,15 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
 }  // namespace
 
 extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
-                                          const float* W, const float* g_up, const float* us, float* m_out,
-                                          int32_t* arg_out, void* stream) {
+                                          int32_t a22_axes, const float* W, const float* g_up, const float* us,
+                                          float* m_out, int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
   if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !g_up || !us ||
-      !m_out || !arg_out)
+      !m_out || !arg_out || (a22_axes != 2 && a22_axes != 3))
     return RATO_EINVAL;
   dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  hipLaunchKernelGGL(drone_rowmax_implicit_kernel, grid, block, 0, rato::as_stream(stream), *p, mass, A22, W, g_up,
-                     us, m_out, arg_out);
+  hipLaunchKernelGGL(drone_rowmax_implicit_kernel, grid, block, 0, rato::as_stream(stream), *p, mass, A22, a22_axes, W,
+                     g_up, us, m_out, arg_out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
@@ -376,6 +467,23 @@ extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int
                        n_u, m_out, arg_out);
   else
     return RATO_EINVAL;
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass, const float* A22,
+                                             int32_t a22_axes, const float* W, const float* g_up,
+                                             const float* m_base, const int32_t* arg_base, const double* stats_base,
+                                             int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
+                                             float* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!p || p->M <= 0 || p->S < 2 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !g_up || !m_base ||
+      !arg_base || !stats_base || !part || K < 1 || K > 65535 || stats_stride < 10 || (a22_axes != 2 && a22_axes != 3))
+    return RATO_EINVAL;
+  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (p->S - 1) + 1) * sizeof(float);
+  dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
+  hipLaunchKernelGGL(drone_tail_rows_implicit_kernel, grid, block, lds, rato::as_stream(stream), *p, mass, A22,
+                     a22_axes, W, g_up, m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

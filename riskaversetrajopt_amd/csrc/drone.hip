@@ -101,6 +101,127 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
   if (Z) Z[m] = zmax - P.tol;
 }
 
+// ---------------------------------------------------------------------------
+// Generators-only linearization: the whole linearization of a sample as 12 S numbers -- the state-dependent entry of
+// the step Jacobian for the three axes (A22), the row gradients W and g_up -- WITHOUT the S(S-1) entries of Phi
+// (Phi[t,s,a] = e_0' A_t ... A_{s+1} B is generated from A22 by whoever needs it: rato_drone_rowmax_implicit,
+// rato_drone_tail_rows_implicit).  One lane per sample, no LDS tables: a forward pass (rollout + the linear
+// response dx(u_bar) for g_up) that is HBM-read bound like the eval kernel, then the backward final-state
+// adjoint over the a22 the lane has just written.  60 B per sample-step instead of 245 B (factored) / 613 B (products).
+__global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
+    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
+    const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ A22,
+    float* __restrict__ W, float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
+  const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;
+  const int S = P.S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const SampleConsts c = load_consts(P, mass, Qsym, ld, m);
+  float p[3], v[3], dp[2] = {0.0f, 0.0f}, dv[2] = {0.0f, 0.0f};   // state | response of the linearized x, y axes to u_bar
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    p[a] = P.x_init[a];
+    v[a] = P.x_init[3 + a];
+  }
+  float zmax = -INFINITY;
+  float xi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
+  for (int t = 0; t < S; ++t) {
+    float nxt[3];
+    const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
+#pragma unroll
+    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
+    float a22[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      a22[a] = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v[a])) * c.inv_m;   // A_t[1,1] at the state BEFORE the step
+      if (valid) A22[((size_t)t * 3 + a) * ld + m] = a22[a];
+    }
+    // d x_{t+1} = A_t d x_t + B u_t  (x, y): the forward form of the adjoint row sweep; d p(t+1) = (Phi u_bar)[t]
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float ndp = dp[a] + P.dt * dv[a];
+      const float ndv = c.a21 * dp[a] + a22[a] * dv[a] + c.dtm * us[t * 3 + a];
+      dp[a] = ndp;
+      dv[a] = ndv;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) {
+      const float dx = p[0] - P.obs_xy[j][0], dy = p[1] - P.obs_xy[j][1];
+      const float gj = 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
+      const float wx = -(2.0f * c.q00[j] * dx + c.qs[j] * dy), wy = -(c.qs[j] * dx + 2.0f * c.q11[j] * dy);
+      zmax = fmaxf(zmax, gj);
+      if (valid) {
+        W[(((size_t)j * S + t) * 2 + 0) * ld + m] = wx;
+        W[(((size_t)j * S + t) * 2 + 1) * ld + m] = wy;
+        g_up[((size_t)j * S + t) * ld + m] = -gj + wx * dp[0] + wy * dp[1];   // -g + (grad g) . u   (drone_risk.py:278)
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
+  }
+  if (Z && valid) Z[m] = zmax - P.tol;
+  // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
+  // (drone_risk.py:271): adjoint from S over the a22 this lane wrote above (same thread: program order)
+  extern __shared__ float gen_red[];   // [waves][S + 1][6]: per-wave sums, combined once after the sweep
+  constexpr int NWV = RATO_BLOCK / RATO_WAVE;
+  float mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mP0[a] = 1.0f; mP1[a] = 0.0f; mV0[a] = 0.0f; mV1[a] = 1.0f; dP[a] = 0.0f; dV[a] = 0.0f;
+  }
+  for (int s2 = S - 1; s2 >= 0; --s2) {
+    float eP[3], eV[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      eP[a] = mP1[a] * c.dtm;
+      eV[a] = mV1[a] * c.dtm;
+      const float ua = us[s2 * 3 + a];
+      dP[a] += eP[a] * ua;
+      dV[a] += eV[a] * ua;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float sp = rato::wave_sum_dpp(valid ? eP[a] : 0.0f);
+      const float sv = rato::wave_sum_dpp(valid ? eV[a] : 0.0f);
+      if (lane == 0) {
+        gen_red[(wave * (S + 1) + s2) * 6 + a] = sp;
+        gen_red[(wave * (S + 1) + s2) * 6 + 3 + a] = sv;
+      }
+    }
+    if (s2 > 0) {  // mu_s = mu_{s+1} A_s
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float a22 = A22[((size_t)s2 * 3 + a) * ld + m];
+        const float nP0 = mP0[a] + mP1[a] * c.a21, nP1 = mP0[a] * P.dt + mP1[a] * a22;
+        const float nV0 = mV0[a] + mV1[a] * c.a21, nV1 = mV0[a] * P.dt + mV1[a] * a22;
+        mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float rp = rato::wave_sum_dpp(valid ? (-(p[a] - P.x_final[a]) + dP[a]) : 0.0f);
+    const float rv = rato::wave_sum_dpp(valid ? (-(v[a] - P.x_final[3 + a]) + dV[a]) : 0.0f);
+    if (lane == 0) {
+      gen_red[(wave * (S + 1) + S) * 6 + a] = rp;
+      gen_red[(wave * (S + 1) + S) * 6 + 3 + a] = rv;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 6 * S + 6; i += RATO_BLOCK) {   // [s*6 + e] and, last, the 6 rhs entries
+    float acc = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) acc += gen_red[w * (S + 1) * 6 + i];   // fixed order
+    part[(size_t)blockIdx.x * (6 * S + 6) + i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(RATO_BLOCK) void drone_obstacle_kernel(rato_drone_params P,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ Qsym,
@@ -788,6 +909,20 @@ bool plan(int32_t M, int32_t S, int32_t ld, int32_t* cpt, int32_t* spl) {
   return ok;
 }
 }  // namespace
+
+extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const float* us, const float* dW,
+                                               const float* mass, const float* Qsym, float* A22, float* W,
+                                               float* g_up, float* Z, float* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || !us || !dW || !mass || !Qsym || !A22 || !W || !g_up || !part) return RATO_EINVAL;
+  dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(float);
+  if (lds > 64 * 1024) return RATO_EINVAL;
+  hipLaunchKernelGGL(drone_linearize_generators_kernel, grid, block, lds, rato::as_stream(stream), *p, us, dW, mass,
+                     Qsym, A22, W, g_up, Z, part);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
 
 extern "C" int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld, int32_t* cols_per_thread,
                                          int32_t* samples_per_lane, int32_t* tile) {

@@ -63,7 +63,9 @@ class CvarCutSolver:
         self.alpha = alpha
         self.nU = n_u * S
         self.u_min, self.u_max = float(u_min), float(u_max)
-        self.implicit = None        # drone: (rato_drone_params, mass, A22) -> Jacobian-free evaluation of m(u)
+        # drone: (rato_drone_params, mass, A22, a22_axes) -> Jacobian-free evaluation of m(u); with G = None in
+        # evaluate / relinearize_kept_cuts the tail rows are regenerated from A22 as well (generators-only mode)
+        self.implicit = None
         n = self.nU + 1
         Pu = sp.kron(sp.eye(S), sp.csc_matrix(2.0 * dt * np.asarray(Rcost, dtype=np.float64)))
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
@@ -76,14 +78,14 @@ class CvarCutSolver:
         self.recycle = recycle
         self.keep_max = 48
         self.cap = (160 if recycle else 1) + 1          # last slot: scratch for calls beyond the ring
-        self.nres = stats.N_STATS + 2 * max(S - 1, 0)
+        self.nres = stats.N_STATS + 2 * max(S - 1, 0) + 1     # statistics | subgradient sums | (implicit: sum w g_up)
         self.ring_m = e(self.cap, M)
         self.ring_arg = e(self.cap, M, dt=torch.int32)
         self.ring_res = torch.zeros((self.cap, self.nres), dtype=torch.float64, device=device)
         self.keep = []                                   # slots kept from the previous solve
         self.nblk = (M + 255) // 256
-        self.part = e(self.nblk, 2 * (S - 1)) if S > 1 else None
         self.nc = 2 * max(S - 1, 0) + 1
+        self.part = e(self.nblk, self.nc) if S > 1 else None
         self.part_b = e(self.nblk, self.keep_max * self.nc) if (recycle and S > 1) else None
         self.sums_b = torch.zeros(self.keep_max * self.nc, dtype=torch.float64, device=device)
         self.sums_b_host = torch.zeros(self.keep_max * self.nc, dtype=torch.float64).pin_memory()
@@ -107,8 +109,8 @@ class CvarCutSolver:
         self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
         self.us_dev.copy_(self.u_host, non_blocking=True)
         if self.implicit is not None:
-            p, mass, A22 = self.implicit
-            _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), _lib.ptr(W),
+            p, mass, A22, axes = self.implicit
+            _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W),
                                                            _lib.ptr(g_up_raw), _lib.ptr(self.us_dev),
                                                            _lib.ptr(m_buf), _lib.ptr(arg_buf),
                                                            st), "rato_drone_rowmax_implicit")
@@ -118,21 +120,30 @@ class CvarCutSolver:
                                                 _lib.ptr(arg_buf), st), "rato_saa_rowmax")
         m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
         stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
-        if S > 1:
+        nw = 2 * (S - 1)
+        if S > 1 and G is None:                  # generators-only linearization: rows regenerated from A22
+            p, mass, A22, axes = self.implicit
+            _lib.check(self.lib.rato_drone_tail_rows_implicit(
+                _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(g_up_raw), _lib.ptr(m_buf),
+                _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alpha * self.M_total),
+                _lib.ptr(self.part), st), "rato_drone_tail_rows_implicit")
+            stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
+        elif S > 1:
+            part = self.part.view(-1)[:self.nblk * nw].view(self.nblk, nw)
             _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
                                                    _lib.ptr(m_buf),
                                                    _lib.ptr(arg_buf), 0.0, 0.0, _lib.ptr(res),
-                                                   float(self.alpha * self.M_total), _lib.ptr(self.part),
+                                                   float(self.alpha * self.M_total), _lib.ptr(part),
                                                    st), "rato_saa_tail_rows")
-            stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
-            if self.world > 1:
-                res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
+            stats.sum_partials(part, out=res[stats.N_STATS:stats.N_STATS + nw], stream=st)
+        if S > 1 and self.world > 1:
+            res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
         r = self.res_host.numpy()
         g = np.zeros(self.nU)
         if S > 1:
-            g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:].reshape(S - 1, 2) / (self.alpha * self.M_total)
+            g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:stats.N_STATS + nw].reshape(S - 1, 2) / (self.alpha * self.M_total)
         return float(r[1]), float(r[0]), g
 
     def relinearize_kept_cuts(self, G, W, tile, g_up_raw):
@@ -144,10 +155,18 @@ class CvarCutSolver:
         self.slots_host[:K] = torch.as_tensor(self.keep, dtype=torch.int32)
         self.slots_dev.copy_(self.slots_host, non_blocking=True)
         part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
-        _lib.check(self.lib.rato_saa_tail_rows_batch(
-            _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(g_up_raw), _lib.ptr(self.ring_m),
-            _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
-            float(self.alpha * self.M_total), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
+        if G is None:
+            p, mass, A22, axes = self.implicit
+            _lib.check(self.lib.rato_drone_tail_rows_implicit(
+                _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(g_up_raw),
+                _lib.ptr(self.ring_m), _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres,
+                _lib.ptr(self.slots_dev), K, float(self.alpha * self.M_total), _lib.ptr(part),
+                _lib.current_stream()), "rato_drone_tail_rows_implicit")
+        else:
+            _lib.check(self.lib.rato_saa_tail_rows_batch(
+                _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(g_up_raw), _lib.ptr(self.ring_m),
+                _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
+                float(self.alpha * self.M_total), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
         stats.sum_partials(part, out=self.sums_b[:K * self.nc])
         if self.world > 1:
             self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))

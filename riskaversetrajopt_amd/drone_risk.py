@@ -263,6 +263,31 @@ class Model:
                 "W": (Wf[..., :M] if factored else None), "_W": Wf,
                 "A22": (A22[..., :M] if A22 is not None else None), "_A22": A22}
 
+    def linearize_generators_device(self, us_mat, inputs=None, out=None):
+        """Generators-only linearization (rato_drone_linearize_generators): A22 [S][3][M], W [n_obs][S][2][M],
+        g_up [n_obs][S][M], Z [M] and the sample sums -- everything ``solve_reduced`` needs -- without the S(S-1)
+        Jacobian entries per sample (60 B instead of 245 B of HBM traffic per sample-step).  Same dict keys as
+        ``linearize_device`` with G = None."""
+        dW, mass, Qsym, M = self._inputs(inputs)
+        ld, S = mass.numel(), self.S
+        us = self._us_device(us_mat)
+        o = out if out is not None else {}
+        A22 = o["_A22"] if (o.get("_A22") is not None and o["_A22"].shape[1] == 3) else self._empty(S, 3, ld)
+        Wf = o["_W"] if o.get("_W") is not None else self._empty(n_obs, S, 2, ld)
+        g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
+        Z = o["_Z"] if o.get("_Z") is not None else self._empty(ld)
+        nblk = (M + 255) // 256
+        part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) else self._empty(nblk, 6 * S + 6)
+        p = self._params(M, ld)
+        _lib.check(self._lib.rato_drone_linearize_generators(
+            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(A22), _lib.ptr(Wf),
+            _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()), "rato_drone_linearize_generators")
+        sums = stats.sum_partials(part, out=o.get("sums"))
+        return {"G": None, "g_up": g_up[..., :M], "Z": Z[:M], "du_sum": sums[:6 * S].view(S, 6),
+                "rhs_sum": sums[6 * S:], "sums": sums, "part": part, "M": M, "_g_up": g_up, "_Z": Z,
+                "tile": 64, "factored": True, "W": Wf[..., :M], "_W": Wf, "A22": A22[..., :M], "_A22": A22,
+                "a22_axes": 3}
+
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
         S = self.S
@@ -458,17 +483,27 @@ class Model:
         self._cut_solver = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False, implicit=True):
+    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False, implicit=True, generators_only=None):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
         planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
         Same optimum as define/update_problem + solve; -> (us_sol (S,n_u), t_risk, info).
         ``implicit``: evaluate the constraint rows of a candidate u from the step-Jacobian table (O(S) per sample,
-        rato_drone_rowmax_implicit) instead of reading the packed Jacobian (O(S^2), rato_saa_rowmax)."""
+        rato_drone_rowmax_implicit) instead of reading the packed Jacobian (O(S^2), rato_saa_rowmax).
+        ``generators_only`` (default: same as ``implicit``): do not even write the Jacobian -- linearize to
+        (A22, W, g_up) only and regenerate the few rows the subgradients need (rato_drone_tail_rows_implicit)."""
         if self.method != 'saa':
             raise NotImplementedError("the reduced solve covers the 'saa' method")
-        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit)
-        self._lin_buffers = r
+        if generators_only is None:
+            generators_only = implicit
+        if generators_only and not implicit:
+            raise ValueError("generators_only needs the implicit oracle")
+        if generators_only:
+            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None))
+            self._gen_buffers = r
+        else:
+            r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit)
+            self._lin_buffers = r
         M, S = r["M"], self.S
         world = getattr(self, "_world", 1)
         cs = getattr(self, "_cut_solver", None)
@@ -488,7 +523,7 @@ class Model:
         cs.implicit = None
         if implicit:
             dW, mass, Qsym, _ = self._inputs(None)
-            cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"])
+            cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2),
                         tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info

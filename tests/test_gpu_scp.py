@@ -224,7 +224,7 @@ def test_rowmax_implicit_matches_explicit_and_oracle(S, M):
                                            _lib.current_stream()), "rato_saa_rowmax")
         else:
             p = d._params(M, ld)
-            _lib.check(lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(r["_A22"]),
+            _lib.check(lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(r["_A22"]), 2,
                                                       _lib.ptr(r["_W"]), _lib.ptr(r["_g_up"]), _lib.ptr(u_dev),
                                                       _lib.ptr(m), _lib.ptr(a), _lib.current_stream()),
                        "rato_drone_rowmax_implicit")
@@ -275,7 +275,8 @@ def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
     us1, _, info1 = d.solve_reduced(start, 5)
     cs = d._cut_solver
     assert cs.recycle and len(cs.keep) >= 1
-    r = d._lin_buffers                                   # the linearization the kept cuts were found on
+    r = d._gen_buffers                                   # the (generators-only) linearization of the kept cuts
+    assert r["G"] is None
     rows, rhs = cs.relinearize_kept_cuts(r["G"], r["_W"], r["tile"], r["_g_up"])
     assert rows.shape == (len(cs.keep), 3 * S) and np.all(rows.reshape(-1, S, 3)[:, :, 2] == 0)
     rng = np.random.RandomState(1)
@@ -291,7 +292,7 @@ def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
     # a different linearization point: still valid
     r2 = d.linearize_device(start * 0.9, want_A22=True)
     rows2, rhs2 = cs.relinearize_kept_cuts(r2["G"], r2["_W"], r2["tile"], r2["_g_up"])
-    cs.implicit = (d._params(M, r2["_g_up"].shape[-1]), d._inputs(None)[1], r2["_A22"])
+    cs.implicit = (d._params(M, r2["_g_up"].shape[-1]), d._inputs(None)[1], r2["_A22"], 2)
     for trial in range(4):
         u = us1.reshape(-1) + 0.05 * rng.randn(3 * S)
         phi, _, _ = cs.evaluate(r2["G"], r2["_W"], r2["tile"], r2["_g_up"], u)
@@ -305,3 +306,53 @@ def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
     b = scp.run_drone_reduced(db, num_scp_iters_max=12)
     np.testing.assert_allclose(a["us"], b["us"], rtol=0, atol=1e-4)
     assert a["cuts"][-3:].sum() <= b["cuts"][-3:].sum()
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (50, 1000), (2, 5), (125, 70)])
+def test_generators_only_linearization_matches_the_jacobian_kernel(S, M):
+    """rato_drone_linearize_generators (A22, W, g_up, Z, sums; no Jacobian entries) == the same quantities of the
+    row-parallel Jacobian kernel, and the rows regenerated from A22 (rato_drone_tail_rows_implicit) == the rows read
+    from Phi (rato_saa_tail_rows_batch)."""
+    import ctypes as C
+    import torch
+    from riskaversetrajopt_amd import _lib, stats
+    o, d = _drone(M, S)
+    us = graze(S)
+    full = d.linearize_device(us, want_A22=True)
+    gen = d.linearize_generators_device(us)
+    assert gen["G"] is None and gen["A22"].shape == (S, 3, M)
+    np.testing.assert_allclose(gen["A22"][:, :2].cpu().numpy(), full["A22"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    Wf = full["W"].cpu().numpy()                     # W = -(Q+Q')(p - o): |Q| ~ 1e2..1e3 amplifies the last-bit
+    np.testing.assert_allclose(gen["W"].cpu().numpy(), Wf, rtol=1e-5, atol=2e-5 * np.abs(Wf).max())   # differences of p
+    np.testing.assert_allclose(gen["g_up"].cpu().numpy(), full["g_up"].cpu().numpy(), rtol=5e-5, atol=2e-4)
+    np.testing.assert_allclose(gen["Z"].cpu().numpy(), full["Z"].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(gen["sums"].cpu().numpy(), full["sums"].cpu().numpy(), rtol=2e-5, atol=2e-3)
+    _, _, _, _, gup_o = o.get_all_constraints_coeffs(us)
+    np.testing.assert_allclose(gen["g_up"].permute(2, 0, 1).cpu().numpy(), gup_o, rtol=5e-5, atol=2e-4)
+    if S < 2:
+        return
+    # rows of tail samples: implicit (from A22) vs explicit (from Phi), K = 3 synthetic cuts
+    lib, dev = d._lib, gen["_W"].device
+    ld, K, nw = gen["_g_up"].shape[-1], 3, 2 * (S - 1)
+    rng = np.random.RandomState(8)
+    m_base = torch.as_tensor(rng.randn(K, M).astype(np.float32), device=dev)
+    arg_base = torch.as_tensor(rng.randint(0, 3 * S, size=(K, M)).astype(np.int32), device=dev)
+    stats_base = torch.zeros((K, 10), dtype=torch.float64, device=dev)
+    for k in range(K):
+        stats.risk_stats_device(m_base[k], 0.2, out=stats_base[k])
+    slots = torch.as_tensor(np.array([2, 0, 1], dtype=np.int32), device=dev)
+    nblk = (M + 255) // 256
+    pa = torch.zeros((nblk, K, nw + 1), device=dev)
+    pb = torch.zeros((nblk, K, nw + 1), device=dev)
+    p = d._params(M, ld)
+    mass = d._inputs(None)[1]
+    _lib.check(lib.rato_drone_tail_rows_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(gen["_A22"]), 3, _lib.ptr(gen["_W"]),
+                                                 _lib.ptr(gen["_g_up"]), _lib.ptr(m_base), _lib.ptr(arg_base),
+                                                 _lib.ptr(stats_base), 10, _lib.ptr(slots), K, 0.2 * M, _lib.ptr(pa),
+                                                 _lib.current_stream()), "rato_drone_tail_rows_implicit")
+    _lib.check(lib.rato_saa_tail_rows_batch(_lib.ptr(full["G"]), _lib.ptr(full["_W"]), ld, full["tile"], 3, S, M,
+                                            _lib.ptr(full["_g_up"]), _lib.ptr(m_base), _lib.ptr(arg_base),
+                                            _lib.ptr(stats_base), 10, _lib.ptr(slots), K, 0.2 * M, _lib.ptr(pb),
+                                            _lib.current_stream()), "rato_saa_tail_rows_batch")
+    a, b = pa.sum(0).double().cpu().numpy(), pb.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
