@@ -130,3 +130,31 @@ def load_results(path, n):
 def run_driving_reduced(model, num_scp_iters_max=15, verbose=False):
     """driving.py:486-513 with ``Model.solve_reduced`` subproblems (same loop as run_drone_reduced)."""
     return run_drone_reduced(model, num_scp_iters_max=num_scp_iters_max, verbose=verbose)
+
+
+def monte_carlo_report(mc_model, us_list, alpha, verbose=False):
+    """The out-of-sample validation block of the reference's scripts (drone_risk.py:697-725, driving.py:672-700):
+    every solution in ``us_list`` (the SAA repeats of one alpha) is evaluated on the Monte-Carlo model's fresh
+    samples (M = 10000 there) -- fraction of samples that satisfy the constraints, AVaR_alpha of the max constraint
+    value, control cost -- and the mean / median over the repeats are reported.  One rollout kernel + one exact
+    selection per solution, all on the device.  -> dict of per-solution arrays and the aggregates."""
+    frac, avar, var, cost = [], [], [], []
+    for us in us_list:
+        st = mc_model.monte_carlo_statistics(us, alpha=alpha)
+        frac.append(st["frac_satisfied"])
+        avar.append(st["cvar"])
+        var.append(st["var"])
+        cost.append(mc_model.monte_carlo_cost(us))
+        if verbose:
+            print("B_satisfied_vec =", frac[-1])
+    out = {"frac_satisfied": np.array(frac), "avar": np.array(avar), "var": np.array(var), "cost": np.array(cost)}
+    for k in ("frac_satisfied", "avar", "cost"):
+        out[k + "_mean"], out[k + "_median"] = float(np.mean(out[k])), float(np.median(out[k]))
+    if verbose:
+        print("percentage safe (mean) =", out["frac_satisfied_mean"])
+        print("avar (mean) =", out["avar_mean"])
+        print("cost (mean) =", out["cost_mean"])
+        print("percentage safe (median) =", out["frac_satisfied_median"])
+        print("avar (median) =", out["avar_median"])
+        print("cost (median) =", out["cost_median"])
+    return out

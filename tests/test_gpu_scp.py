@@ -356,3 +356,23 @@ def test_generators_only_linearization_matches_the_jacobian_kernel(S, M):
                                             _lib.current_stream()), "rato_saa_tail_rows_batch")
     a, b = pa.sum(0).double().cpu().numpy(), pb.sum(0).double().cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
+
+
+def test_monte_carlo_report_matches_oracle():
+    """scp.monte_carlo_report (drone_risk.py:697-725): per-solution fraction safe / AVaR / cost on fresh samples
+    and their mean / median over the repeats, against the oracle's Monte-Carlo functions."""
+    from oracle import drone as od, stats as ostats
+    from riskaversetrajopt_amd import drone_risk, scp
+    S, M, alpha = 20, 2000, 0.1
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(77), 'saa', M=M, S=S)
+    o = od.Model(S, DWs, masses, Q, 'saa', alpha)
+    d = drone_risk.Model(S, DWs, masses, Q, 'saa', alpha)
+    us_list = [graze(S) * f for f in (0.2, 0.6, 1.0)]
+    rep = scp.monte_carlo_report(d, us_list, alpha)
+    for i, us in enumerate(us_list):
+        ok, Z = o.monte_carlo_no_collisions_constraint_verification(us)
+        near = np.sum(np.abs(Z - 1e-6) < 1e-4) / M
+        assert abs(rep["frac_satisfied"][i] - ok.mean()) <= near + 1e-12
+        assert abs(rep["avar"][i] - ostats.monte_carlo_avar(Z, alpha)) < 2e-4 * max(1.0, abs(rep["avar"][i]))
+        assert abs(rep["cost"][i] - o.monte_carlo_cost(us)) < 1e-9 * max(1.0, rep["cost"][i])
+    assert rep["avar_median"] == np.median(rep["avar"]) and rep["cost_mean"] == np.mean(rep["cost"])
