@@ -456,7 +456,14 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
+  // Grid: 4 elements per thread up to 256 workgroups, then more elements per thread (every workgroup flushes its
+  // LDS histogram with global atomics: at M ~ 1e6 of CLUSTERED values 1000 workgroups hammering the same few bins
+  // cost 60 us per call, 256 workgroups 33 us; tools/stats_time.py), capped at RS_MAX_BLOCKS for very large M.
   long nb = (M + RATO_BLOCK * 4 - 1) / (RATO_BLOCK * 4);
+  if (nb > 256) {
+    nb = (M + RATO_BLOCK * 16 - 1) / (RATO_BLOCK * 16);
+    if (nb < 256) nb = 256;
+  }
   if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb), block(RATO_BLOCK);

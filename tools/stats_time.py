@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from riskaversetrajopt_amd import stats
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
-for M in (1000, 4096, 10000, 16384, 100000, 1000000):
+for M in (1000, 4096, 10000, 16384, 100000, 800000, 1000000, 8000000):
     for name, Z in (("clustered", 0.9 + 0.05 * torch.randn(M, generator=g, device=dev)),
                     ("spread", torch.randn(M, generator=g, device=dev) * torch.exp(8 * torch.rand(M, generator=g, device=dev)))):
         ws = torch.zeros(stats._lib.load().rato_risk_stats_workspace_bytes(M), dtype=torch.uint8, device=dev)
