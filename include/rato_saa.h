@@ -47,15 +47,22 @@ extern "C" {
 
 #define RATO_OK 0
 #define RATO_EINVAL (-1)
-#define RATO_EHIP (-1000)
+#define RATO_ENONFINITE (-2) /* a checked output holds NaN/Inf: the reference only prints
+                                "[solve]: Problem infeasible." (drone_risk.py:458-459) and carries on.
+                                Raised by the facades (check_finite=True) from rato_count_nonfinite_acc. */
+#define RATO_ENOCOMM (-3)    /* librccl could not be bound at run time (rato_comm_*) */
+#define RATO_EHIP (-1000)    /* RATO_EHIP - hipError_t */
+#define RATO_ERCCL (-2000)   /* RATO_ERCCL - ncclResult_t */
 
 #define RATO_TILE 256        /* samples per Jacobian tile (= workgroup size) */
 #define RATO_DRONE_NOBS 3   /* drone_params.py:34-43: n_obs = 3 */
 #define RATO_HOPPER_NFEAT 30 /* hopper.py:69: num_mu_features = 30 */
 
 /* ABI version, bumped on any signature/layout change (2: factored Jacobian W / A22 outputs, CVaR-cut oracle
- * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes).  The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 3
+ * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes; 4: rato_comm_*
+ * (RCCL behind the ABI), rato_car_separation_distances, rato_count_nonfinite_acc, Philox sampler entry points).  The
+ * Python binding refuses a library that reports another version. */
+#define RATO_ABI_VERSION 4
 int rato_abi_version(void);
 
 /* ------------------------------------------------------------------ drone */
@@ -176,6 +183,10 @@ size_t rato_car_ego_scratch_floats(int32_t S);
 int rato_car_eval(const rato_car_params* p, const float* us, const float* dW,
                   const float* x0_ped, const float* w_speed, const float* w_rep,
                   float* ego_scratch, float* Z, float* xs, float* g, void* stream);
+
+/* Model.separation_distances_at_all_times on GIVEN trajectories (driving.py:223-236):
+ *   xs [S+1][8][M] -> dist [S][M] = ||p_ego(t+1) - p_ped(t+1)|| - d_min   (the constraint value is -dist). */
+int rato_car_separation_distances(const rato_car_params* p, const float* xs, float* dist, void* stream);
 
 /* Kernel variants of rato_car_linearize: cols_per_thread = -1 row-parallel adjoint kernel (default;
  * needs ~20*64*S bytes of LDS <= 160 KB), 4/8/16 forward column kernel.  Resolves 0 to a concrete
@@ -333,6 +344,30 @@ int rato_saa_tail_rows_batch(const float* G, const float* W /* NULL or factor */
 int rato_unpack_records(const void* all, int32_t world, int32_t n_sums, int64_t M_local, int64_t rec_bytes,
                         double* total, float* Z_all, void* stream);
 
+/*
+ * The collective itself (saa_comm_init / exchange / destroy).  The reference is one process
+ * (drone_risk.py:18); with the sample axis sharded over one process per GPU, the mean of drone_risk.py:294-296 and the
+ * statistics of :663-695 / drone_main_plot.py:640-652 need every rank's record.  RCCL (librccl, bound at run time)
+ * over xGMI; one communicator per (process, GPU); the caller selects the device (hipSetDevice) before rato_comm_init.
+ *   rato_comm_unique_id   rank 0 only: 128 opaque bytes (ncclUniqueId) that the host ships to the other ranks by
+ *                         any means it has (the Python facade: one torch.distributed broadcast)
+ *   rato_comm_init        collective over all `world` ranks; *comm is the opaque handle
+ *   rato_comm_allgather   stream-ordered all-gather of `bytes` bytes per rank into recv_all [world * bytes]
+ *   rato_comm_exchange    the whole exchange of an evaluation: all-gather of the record + rato_unpack_records
+ *   rato_comm_destroy     collective teardown
+ * Errors: RATO_ENOCOMM (no librccl), RATO_ERCCL - ncclResult_t.
+ */
+#define RATO_COMM_ID_BYTES 128
+typedef struct rato_comm rato_comm;
+int rato_comm_unique_id(void* id_out /* host, RATO_COMM_ID_BYTES */);
+int rato_comm_init(rato_comm** comm, const void* id_bytes /* host */, int32_t rank, int32_t world);
+int rato_comm_world(const rato_comm* comm);
+int rato_comm_rank(const rato_comm* comm);
+int rato_comm_allgather(rato_comm* comm, const void* send, void* recv_all, int64_t bytes, void* stream);
+int rato_comm_exchange(rato_comm* comm, const void* record, void* all, int64_t rec_bytes, int32_t n_sums,
+                       int64_t M_local, double* total, float* Z_all, void* stream);
+int rato_comm_destroy(rato_comm* comm);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,
@@ -344,6 +379,11 @@ int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double 
 /* Failure detection (the reference has none: an infeasible QP only prints, drone_risk.py:458-459):
  * counts the NaN/Inf entries of a device array into *count (device uint32). */
 int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, void* stream);
+
+/* Same scan ACCUMULATING into *count (no reset): chain several arrays (g_up, Z, partial sums ...) into one counter,
+ * zeroed by the caller (or by one rato_count_nonfinite), then read it once.  The facades' ``check_finite=True``
+ * turns a non-zero count into RATO_ENONFINITE / RatoNonFiniteError. */
+int rato_count_nonfinite_acc(const float* x, int64_t n, uint32_t* count, void* stream);
 
 /* Workspace bytes needed by rato_risk_stats for M samples. */
 size_t rato_risk_stats_workspace_bytes(int64_t M);

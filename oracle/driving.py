@@ -217,8 +217,9 @@ class Model:
 
     # -- Monte-Carlo validation: driving.py:623-638 --------------------------
     def monte_carlo_cost(self, us_mat):
-        # :623-629 multiplies by the MODULE dt (= T / 20)
-        return (T / S_DEFAULT) * float(np.sum(np.diag(R)[None, :] * us_mat * us_mat))
+        # :623-629 multiplies by the module's dt -- the ONE dt of driving.py (driving_params.py:14, dt = T / S), the
+        # same one the rollout uses; pinned by executing the reference at S = 40 (tests/test_reference_pin.py)
+        return self.dt * float(np.sum(np.diag(R)[None, :] * us_mat * us_mat))
 
     def monte_carlo_separation_constraints_verification(self, us_mat):
         xs = self.us_to_state_trajectories(us_mat)

@@ -15,6 +15,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "librato_saa.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"]
+LINK_FLAGS = ["-ldl"]          # comm.hip binds librccl at run time (dlopen); nothing links against torch or rccl
 
 
 def sources():
@@ -34,7 +35,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + sources()
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + sources() + LINK_FLAGS
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 3              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 4              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -42,6 +42,7 @@ SIGNATURES = {
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rato_car_eval": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 9 + [c_stream]),
+    "rato_car_separation_distances": (C.c_int, [C.POINTER(CarParams), c_float_p, c_float_p, c_stream]),
     "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
@@ -59,6 +60,15 @@ SIGNATURES = {
                                       c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
+    "rato_count_nonfinite_acc": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
+    "rato_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rato_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32]),
+    "rato_comm_world": (C.c_int, [C.c_void_p]),
+    "rato_comm_rank": (C.c_int, [C.c_void_p]),
+    "rato_comm_allgather": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, c_stream]),
+    "rato_comm_exchange": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int64, c_float_p,
+                                     c_float_p, c_stream]),
+    "rato_comm_destroy": (C.c_int, [C.c_void_p]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
@@ -67,6 +77,11 @@ SIGNATURES = {
 
 class RatoError(RuntimeError):
     pass
+
+
+class RatoNonFiniteError(RatoError):
+    """RATO_ENONFINITE: a checked device output holds NaN/Inf (the reference only prints, drone_risk.py:458-459)."""
+    status = -2
 
 
 def lib_path():

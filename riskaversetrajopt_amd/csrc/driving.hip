@@ -207,6 +207,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
   if (Z) Z[m] = zmax - P.tol;
 }
 
+// separation_distances_at_all_times on given trajectories (driving.py:223-236): xs [S+1][8][M] -> dist [S][M]
+__global__ __launch_bounds__(RATO_BLOCK) void car_distance_kernel(rato_car_params P, const float* __restrict__ xs,
+                                                                 float* __restrict__ dist) {
+  const size_t M = (size_t)P.M;
+  const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const int t = blockIdx.y;
+  if (m >= M) return;
+  const float* __restrict__ x = xs + (size_t)(t + 1) * 8 * M + m;
+  const float dx = x[0] - x[4 * M], dy = x[M] - x[5 * M];
+  dist[(size_t)t * M + m] = sqrtf(dx * dx + dy * dy) - P.d_min;
+}
+
 __device__ __forceinline__ int step_of(int k, int grp, int ngroups) {
   return k * ngroups + ((k & 1) ? (ngroups - 1 - grp) : grp);
 }
@@ -632,6 +644,15 @@ extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const fl
                      (float*)nullptr, (float*)nullptr, 0);
   hipLaunchKernelGGL(car_eval_kernel, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW, x0_ped,
                      w_speed, w_rep, ego_scratch, Z, xs, g);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_car_separation_distances(const rato_car_params* p, const float* xs, float* dist, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || !xs || !dist) return RATO_EINVAL;
+  hipLaunchKernelGGL(car_distance_kernel, dim3(rato::nblocks_for(p->M), p->S), dim3(RATO_BLOCK), 0,
+                     rato::as_stream(stream), *p, xs, dist);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

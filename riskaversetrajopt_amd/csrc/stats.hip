@@ -432,6 +432,17 @@ extern "C" int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, 
   return RATO_OK;
 }
 
+extern "C" int rato_count_nonfinite_acc(const float* x, int64_t n, uint32_t* count, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!x || !count || n <= 0) return RATO_EINVAL;
+  long nb = (n + RATO_BLOCK * 8 - 1) / (RATO_BLOCK * 8);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)nb), dim3(RATO_BLOCK), 0, rato::as_stream(stream), x,
+                     (long)n, count);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
 extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
   (void)M;
   return sizeof(Workspace);

@@ -1,5 +1,6 @@
-"""Sample-axis sharding across GPUs (one process per GPU, torch.distributed;
-backend "nccl" is RCCL over xGMI on ROCm).
+"""Sample-axis sharding across GPUs: one process per GPU; the data-path collective is RCCL behind the C ABI
+(``rato_comm_*`` of include/rato_saa.h, bound by ``device_comm``); torch.distributed is the control plane only
+(rendezvous, shipping the RCCL unique id, barriers) and the transport of the gloo CPU tests.
 
 Every ★ function of the hot path is independent per sample, so each rank owns a
 contiguous block of samples and all per-sample outputs (G, g_up, Z) stay
@@ -44,12 +45,87 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def shard_bounds(M_total, rank, world):
-    """Contiguous block of samples owned by ``rank`` (remainder spread over the
-    first ranks)."""
+def shard_bounds(M_total, rank, world, equal=False):
+    """Contiguous block of samples owned by ``rank`` (remainder spread over the first ranks).
+
+    The exchange (``exchange`` / ``exchange_record`` / ``gather_concat``) and the sharded SCP solve need EQUAL shards:
+    one all-gather of fixed-size records, ``M_total = M_local * world``.  ``equal=True`` refuses a batch that does
+    not divide (drop ``M_total % world`` samples or pad the batch first); ``check_equal_shards`` is what the
+    exchange itself calls, so that unequal shards fail on every rank instead of hanging RCCL."""
     base, rem = divmod(M_total, world)
+    if equal and rem:
+        raise ValueError(f"M_total={M_total} does not divide over {world} ranks: the sample-sharded path needs equal "
+                         f"shards (use {M_total - rem} or {M_total + world - rem} samples)")
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def check_equal_shards(M_local, group=None):
+    """Collective: every rank must hold the same number of samples.  One tiny all-gather, done once per Record /
+    Model.shard(); raises on EVERY rank when the counts differ (a mismatched RCCL all-gather would hang or corrupt
+    silently, gloo errors on one rank only)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(M_local)]
+    world = dist.get_world_size(group)
+    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    mine = torch.tensor([int(M_local)], dtype=torch.int64, device=dev)
+    every = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(every, mine, group=group)
+    counts = [int(v) for v in every.cpu()]
+    if len(set(counts)) != 1:
+        raise ValueError(f"sample shards differ across ranks: {counts}; the exchange needs equal M_local on every rank")
+    return counts
+
+
+# ---- the collective itself: RCCL behind the C ABI (include/rato_saa.h: rato_comm_*) -----------------------------
+_COMMS = {}
+
+
+def device_comm(group=None):
+    """The library's own RCCL communicator for ``group`` (created on first use; None when unavailable).
+
+    torch.distributed only ships the 128-byte unique id (one broadcast) and agrees on success; the data-path
+    collective is ``rato_comm_exchange`` / ``rato_comm_allgather`` on the caller's stream.  Used when every rank owns
+    its own GPU (backend "nccl").  ``RATO_COMM=torch`` keeps torch.distributed's own collective instead (A/B, debug);
+    gloo runs (CPU tests, ranks sharing one GPU) never get a communicator: RCCL refuses two ranks on one device."""
+    if group in _COMMS:
+        return _COMMS[group]
+    comm = None
+    if os.environ.get("RATO_COMM", "rccl") != "torch" and dist.get_backend(group) == "nccl":
+        import ctypes as C
+        import sys
+        from . import _lib
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_uint8 * 128)()
+        status = lib.rato_comm_unique_id(ident) if rank == 0 else 0
+        box = [bytes(ident) if (rank == 0 and status == 0) else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        handle = C.c_void_p()
+        if box[0] is not None:
+            status = lib.rato_comm_init(C.byref(handle), box[0], rank, world)
+        else:
+            status = -3
+        ok = torch.tensor([1 if status == 0 else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            comm = handle
+        else:
+            if status == 0:
+                lib.rato_comm_destroy(handle)
+            if rank == 0:
+                print(f"warning: rato_comm_init failed (status {status} on rank 0): falling back to torch.distributed's "
+                      "RCCL collective", file=sys.stderr)
+    _COMMS[group] = comm
+    return comm
+
+
+def destroy_comms():
+    from . import _lib
+    for comm in _COMMS.values():
+        if comm is not None:
+            _lib.load().rato_comm_destroy(comm)
+    _COMMS.clear()
 
 
 def pack_record(sums64, Z32):
@@ -118,7 +194,17 @@ def exchange_record(rec, group=None):
             (dist.get_world_size(group) == 1 and os.environ.get("RATO_FORCE_DIST") != "1"):
         return rec.sums, rec.Z
     world = dist.get_world_size(group)
+    if not getattr(rec, "_checked", False):
+        check_equal_shards(rec.M_local, group)           # once per record: unequal shards fail loudly on every rank
+        rec._checked = True
     all_, Z_all, total = rec._buffers(world)
+    comm = device_comm(group) if rec.buf.is_cuda else None
+    if comm is not None:                                 # RCCL all-gather + unpack behind the C ABI, caller's stream
+        from . import _lib
+        _lib.check(_lib.load().rato_comm_exchange(comm, _lib.ptr(rec.buf), _lib.ptr(all_), rec.rec_bytes, rec.n_sums,
+                                                  rec.M_local, _lib.ptr(total), _lib.ptr(Z_all),
+                                                  _lib.current_stream()), "rato_comm_exchange")
+        return total, Z_all
     if _staged(rec.buf, group):                          # gloo + device tensors: stage through the host
         host = torch.empty(all_.numel(), dtype=torch.uint8)
         dist.all_gather_into_tensor(host, rec.buf.cpu(), group=group)
@@ -154,6 +240,13 @@ def gather_concat(t, group=None):
     """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank)."""
     world = dist.get_world_size(group)
     src = t.contiguous()
+    comm = device_comm(group) if src.is_cuda else None
+    if comm is not None:
+        from . import _lib
+        out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+        _lib.check(_lib.load().rato_comm_allgather(comm, _lib.ptr(src), _lib.ptr(out), src.numel() * src.element_size(),
+                                                   _lib.current_stream()), "rato_comm_allgather")
+        return out
     if _staged(src, group):
         host = src.cpu()
         out = torch.empty(world * host.numel(), dtype=host.dtype)

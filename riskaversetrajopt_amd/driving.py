@@ -173,8 +173,27 @@ class Model:
         goal = np.concatenate((P.position_ego_goal, P.velocity_ego_goal))
         return np.asarray(xs)[..., -1, :4] - goal
 
-    def separation_distances_at_all_times(self, us_mat):
-        """Batched driving.py:232-236 at the model's samples -> (M, S)  (= -g)."""
+    def separation_distances_at_all_times(self, xs):
+        """driving.py:232-236: distances along GIVEN trajectories, xs (S+1, n_x) -> (S,); also batched
+        (M, S+1, n_x) -> (M, S).  (rato_car_separation_distances; the fused rollout+distance path of the hot loop is
+        ``separation_distances_of_samples(us_mat)`` / ``eval_device``.)"""
+        xs = np.asarray(xs)
+        if xs.shape[-1] != n_x or xs.shape[-2] != self.S + 1:
+            raise ValueError(f"xs must be (S+1, n_x) = ({self.S + 1}, {n_x}) or (M, S+1, n_x), got {xs.shape}")
+        single = xs.ndim == 2
+        if single:
+            xs = xs[None]
+        M = xs.shape[0]
+        xs_d = torch.as_tensor(xs, device=self.device).permute(1, 2, 0).float().contiguous()    # [S+1][8][M]
+        dist_d = self._empty(self.S, M)
+        p = self._params(M)
+        _lib.check(self._lib.rato_car_separation_distances(C.byref(p), _lib.ptr(xs_d), _lib.ptr(dist_d),
+                                                           _lib.current_stream()), "rato_car_separation_distances")
+        out = dist_d.t().double().cpu().numpy()
+        return out[0] if single else out
+
+    def separation_distances_of_samples(self, us_mat):
+        """Rollout of the model's samples under ``us_mat`` fused with driving.py:232-236 -> (M, S)  (= -g)."""
         _, _, g = self.eval_device(us_mat, want_g=True)
         return -g.t().double().cpu().numpy()
 
@@ -326,6 +345,8 @@ class Model:
         """This Model is one shard of a sample-sharded batch (see drone_risk.Model.shard): the cutting-plane oracle
         of ``solve_reduced`` then runs across the ranks.  (The final rows are sample independent: nothing else to merge.)"""
         import torch.distributed as tdist
+        from . import dist as rdist
+        rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
         self._group, self._world = group, tdist.get_world_size(group)
         self._cut_solver = None
         return self
@@ -351,8 +372,9 @@ class Model:
 
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------
     def monte_carlo_cost(self, us_mat):
+        # driving.py:623-629: the script has ONE dt (driving_params.py:14, dt = T / S), shared with the rollout
         us = np.asarray(us_mat)
-        return P.dt * float(np.sum(np.diag(P.R)[None, :] * us * us))
+        return self.dt * float(np.sum(np.diag(P.R)[None, :] * us * us))
 
     def monte_carlo_separation_constraints_verification(self, us_mat):
         Z, _, _ = self.eval_device(us_mat)

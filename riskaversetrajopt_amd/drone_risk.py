@@ -479,6 +479,8 @@ class Model:
         initialised, equal shard sizes): ``solve_reduced`` then merges the sample means and runs the cutting-plane
         oracle across the ranks (cvar_cuts.py); every rank returns the same iterate."""
         import torch.distributed as tdist
+        from . import dist as rdist
+        rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
         self._group, self._world = group, tdist.get_world_size(group)
         self._cut_solver = None
         return self

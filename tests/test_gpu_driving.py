@@ -40,8 +40,13 @@ def test_rollout_and_distances_vs_oracle(S, M):
     us = swerve(S)
     xs_o = o.us_to_state_trajectories(us)
     np.testing.assert_allclose(d.us_to_state_trajectories(us), xs_o, rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
-    np.testing.assert_allclose(d.separation_distances_at_all_times(us), o.separation_distances_at_all_times(xs_o),
+    np.testing.assert_allclose(d.separation_distances_of_samples(us), o.separation_distances_at_all_times(xs_o),
                                rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    # the reference's signature: distances along GIVEN trajectories (driving.py:232-236), batched and one sample
+    np.testing.assert_allclose(d.separation_distances_at_all_times(xs_o), o.separation_distances_at_all_times(xs_o),
+                               rtol=tol.G_RTOL, atol=tol.G_ATOL)
+    np.testing.assert_allclose(d.separation_distances_at_all_times(xs_o[0]),
+                               o.separation_distances_at_all_times(xs_o)[0], rtol=tol.G_RTOL, atol=tol.G_ATOL)
     np.testing.assert_allclose(
         d.us_to_state_trajectory(us, o.states_init[0], o.omegas_speed[0], o.omegas_repulsive[0], o.DWs[0]),
         xs_o[0], rtol=tol.STATE_RTOL, atol=tol.STATE_ATOL)
