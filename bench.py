@@ -40,16 +40,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="drone", choices=["drone", "driving", "hopper"])
+    ap.add_argument("--workload", default=None, choices=["drone", "driving", "hopper"])
     ap.add_argument("--mode", default="linearize", choices=["linearize", "eval"])
     ap.add_argument("--M", type=int, default=0, help="samples per GPU (default: 1e5 drone/driving, 5e4 hopper)")
     ap.add_argument("--S", type=int, default=0, help="steps (default: 50 drone, 40 driving, 60 hopper)")
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--cols-per-thread", type=int, default=0, help="0 auto; -1 row-parallel kernel (drone)")
     ap.add_argument("--samples-per-lane", type=int, default=0)
-    ap.add_argument("--packed-products", action="store_true",
-                    help="drone linearize: write the Jacobian as products (3S(S-1) numbers per sample, SURVEY 8d) "
-                         "instead of the default factored form W[j,t,a] * Phi[t,s,a] (S(S-1) + 6S numbers)")
+    ap.add_argument("--config", default="metric", choices=["metric", "C2", "C3", "C4", "C5"],
+                    help="BASELINE.json configuration: metric = drone M=1e5 S=50 (the one the metric is quoted on); "
+                         "C2 drone M=1e4 S=50; C3 driving M=1e4 S=40; C4 hopper M=5e4 S=60; C5 driving 125,000 "
+                         "samples per GPU, S=40 (M=1e6 over 8 GPUs).  --workload/--M/--S override.")
+    ap.add_argument("--jacobian", default="both", choices=["both", "products", "factored"],
+                    help="drone linearize: representation the kernel writes.  products = every structural nonzero, "
+                         "3S(S-1) numbers per sample (SURVEY 8d; this is what `value` and `roofline` are quoted on); "
+                         "factored = W[j,t,a] * Phi[t,s,a], S(S-1)+6S numbers (reported as *_factored); both = one "
+                         "timed region each, same samples")
+    ap.add_argument("--no-scp", action="store_true", help="skip the SCP wall-clock block (drone, N=1)")
+    ap.add_argument("--scp-iters", type=int, default=60)
+    ap.add_argument("--dry-run", action="store_true", help="rank start-up + barrier only (no GPU work)")
     ap.add_argument("--graph", action="store_true",
                     help="drone linearize, N=1: replay the step as ONE captured hipGraph (kernel time then comes "
                          "from an eager pre-pass with HIP events, since events cannot bracket a node inside a graph)")
@@ -59,7 +68,15 @@ def parse():
                          "is the dominant kernel + 7 us of partial sums + launch gaps; DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = {"metric": ("drone", 100000, 50), "C2": ("drone", 10000, 50), "C3": ("driving", 10000, 40),
+              "C4": ("hopper", 50000, 60), "C5": ("driving", 125000, 40)}[args.config]
+    if args.workload is None:
+        args.workload = preset[0]
+    if args.workload == preset[0]:
+        args.M = args.M or preset[1]
+        args.S = args.S or preset[2]
+    return args
 
 
 def graze_us(S, n_u):
@@ -80,7 +97,7 @@ class DroneWork:
         self.M = args.M or 100000
         self.mode = args.mode
         self.cpt, self.spl = args.cols_per_thread, args.samples_per_lane
-        self.fact = False if args.packed_products else None                   # None: the kernel's default
+        self.fact = False if args.packed_products else (True if getattr(args, "force_factored", False) else None)
         dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
         self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M)
         self.us = self.model._us_device(graze_us(self.S, 3))
@@ -283,34 +300,57 @@ CPU_SAMPLES = {"drone": 8000, "driving": 3000, "hopper": 50000}
 
 
 def pmc_traffic(workload, mode, M, S, jacobian=None):
-    """HBM bytes per launch from the committed PMC profile, if one matches (``jacobian``: the drone linearize
-    output representation the profile was taken with)."""
+    """HBM bytes per launch of the dominant kernel from the COMMITTED PMC profile, if one matches — measured in a
+    separate rocprofv3 --pmc run of this same command (profiles/README.md), not in this run; reported as
+    ``traffic_from_profile`` together with the file it came from."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        for rec in json.load(open(path)):
+        for rec in reversed(json.load(open(path))):          # later entries = later rounds
             if (rec["workload"], rec["mode"], rec["M"], rec["S"]) == (workload, mode, M, S) \
                     and rec.get("jacobian") == jacobian:
-                return rec["hbm_bytes_per_launch"]
+                return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "file": "profiles/pmc_traffic.json",
+                        "profile": rec.get("profile", rec.get("correction", ""))}
     except Exception:
         pass
     return None
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from riskaversetrajopt_amd import dist as rdist, stats
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    rank, world, local = rdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
 
-    work = WORKLOADS[args.workload](args, device, seed=1000 * rank + 7)
-    M, S = work.M, work.S
-    unit_steps = getattr(work, "C", S)        # hopper: the unit is a sample-contact
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves, as a CHILD process
+    (``python -m torch.distributed.run``), before anything in this process touches the GPU; the parent only relays
+    the exit code (a process that has initialised the GPU must never exec another program on this pool)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def roofline_block(work, kern_ms, workload, mode, M, S, jacobian):
+    alg = work.algorithmic_bytes()
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "frac_of_measured_copy_6290": achieved / 6290.0,
+            "algorithmic_bytes_per_launch": alg, "bytes_per_sample_step": alg / (M * S),
+            "kernel_ms": kern_ms, "kernel_ms_source": "HIP events around the launch, mean over the timed steps",
+            "traffic": None,
+            "traffic_from_profile": pmc_traffic(workload, mode, M, S, jacobian)}
+
+
+def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
+    """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; -> dict."""
+    M = work.M
     ws_bytes = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(M * world), dtype=torch.uint8, device=device)
     stats_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
     wss = [ws_bytes, torch.empty_like(ws_bytes)]
@@ -320,7 +360,6 @@ def main():
             dist.barrier()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
     use_graph = args.graph and args.workload == "drone" and args.mode == "linearize" and world == 1
     pipelined = args.overlap and not use_graph
     main_stream = torch.cuda.current_stream()
@@ -330,9 +369,9 @@ def main():
     counter = [0]
 
     def step(i=None):
-        """One pass of the hot path.  Pipelined (default): [exchange + VaR/CVaR of step n] on the side stream
-        overlap [linearize of step n+1] on the main stream; every step still does all of its work inside
-        the timed region (both streams are drained before the clock stops)."""
+        """One pass of the hot path: dominant kernel -> partial sums -> [one all-gather of the record when N > 1] ->
+        exact VaR / CVaR / fraction satisfied.  (--overlap: the exchange + statistics of step n run on a side
+        stream beside the hot kernel of step n+1; both streams are drained before the clock stops.)"""
         slot = counter[0] & 1
         counter[0] += 1
         if pipelined:
@@ -368,7 +407,8 @@ def main():
             step(i)
         torch.cuda.synchronize()
         kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        sg = work.model.capture_step(alpha=args.alpha, cols_per_thread=work.cpt, samples_per_lane=work.spl)
+        sg = work.model.capture_step(alpha=args.alpha, cols_per_thread=work.cpt, samples_per_lane=work.spl,
+                                     factored=work.fact)
         sg.us.copy_(work.us)
         for _ in range(args.warmup):
             sg.replay()
@@ -389,40 +429,122 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     kern_ms = kern_ms_eager if use_graph else float(np.mean([a.elapsed_time(b) for a, b in ev]))
     final_stats = (sg.stats if use_graph else stats_out[(counter[0] - 1) & 1]).cpu().numpy()
+    launch = "hipGraph replay of the whole step" if use_graph else (
+        "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
+        if pipelined else "eager, one stream, no overlap between steps")
+    return {"elapsed": elapsed, "kern_ms": kern_ms, "stats": final_stats, "launch": launch}
+
+
+def scp_block(work, args):
+    """The second half of the BASELINE metric: SCP wall-clock for the drone at the bench's M and S, with the
+    reference's timing protocol (drone_times.py:509-550 / drone_risk.py:510-532: a fixed 60 iterations from the
+    initial guess, per-iteration "define" and "solve" times, medians, cumulative).  Runs AFTER and OUTSIDE the timed
+    throughput region, on the same resident samples.  Every subproblem is the reference's QP reduced exactly to
+    (u, slack) and solved by device CVaR cuts + a host master QP: the reference's own 1.5e7-row QP at
+    M = 1e5 is out of reach of any host solver."""
+    import torch
+    from riskaversetrajopt_amd import scp
+    model = work.model
+    model.solve_reduced(model.initial_guess_us_mat(), 2)             # warm-up: allocations, first launches
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = scp.run_drone_reduced(model, num_scp_iters_max=args.scp_iters, verbose=False)
+    wall = time.perf_counter() - t0
+    st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)
+    return {"system": "drone_risk", "M": work.M, "S": work.S, "alpha": args.alpha, "iters": args.scp_iters,
+            "protocol": "drone_times.py:509-550: fixed iteration count from the initial guess, per-iteration define / "
+                        "solve wall-clock, medians + cumulative; run after the timed throughput region",
+            "subproblem": "reference QP reduced exactly to (u, slack): device CVaR cuts (Jacobian-free oracle) + host "
+                          "master QP (3S+1 variables); non-finite check on every linearization",
+            "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
+            "iteration_median_s": float(np.median(out["define_s"] + out["solve_s"])),
+            "cumulative_s": float(out["cumulative_s"][-1]), "wall_s": wall,
+            "cuts_median": float(np.median(out["cuts"])), "cuts_max": int(out["cuts"].max()),
+            "L2_error_last": float(out["L2_error"][-1]),
+            "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                      # before any GPU call in this process
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE={env_world} (launch with --nproc-per-node {args.gpus}, or "
+              f"let bench.py start the ranks itself: python bench.py --gpus {args.gpus})", file=sys.stderr)
+        sys.exit(2)
+    import torch
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, stats
+
+    rank, world, local = rdist.init_from_env()
+    if args.dry_run:                                     # launch plumbing only (CPU test of the spawn path)
+        if dist.is_initialized():
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "SAA constraint-eval throughput", "value": None, "n_gpus": world,
+                              "dry_run": True}))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    is_drone_lin = args.workload == "drone" and args.mode == "linearize"
+    variants = [None]
+    if is_drone_lin:
+        variants = {"products": ["products"], "factored": ["factored"], "both": ["products", "factored"]}[args.jacobian]
+    results = []
+    for var in variants:
+        args.packed_products = (var == "products")
+        args.force_factored = (var == "factored")
+        work = WORKLOADS[args.workload](args, device, seed=1000 * rank + 7)
+        res = timed_region(work, args, world, rank, device, stats, rdist, dist, torch)
+        res["work"], res["variant"] = work, var
+        results.append(res)
+        if var != variants[-1]:
+            del work.outs, work.records                  # free the 3 GB output slots before the next variant
+            torch.cuda.empty_cache()
+    head, work = results[0], results[0]["work"]
+    M, S = work.M, work.S
+    unit_steps = getattr(work, "C", S)        # hopper: the unit is a sample-contact
 
     if rank == 0:
-        value = world * M * unit_steps * args.steps / elapsed
-        alg = work.algorithmic_bytes()
-        jacobian = None
-        if args.workload == "drone" and args.mode == "linearize":
-            jacobian = "factored" if work.fact else "products"
-        achieved = alg / (kern_ms * 1e-3) / 1e9
+        value = world * M * unit_steps * args.steps / head["elapsed"]
+        jacobian = head["variant"]
         line = {
             "metric": "SAA constraint-eval throughput",
             "value": value,
             "unit": "samples*steps/s" if args.workload != "hopper" else "samples*contacts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * head["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{work.name} {args.mode}: rollout+Jacobian+mean+VaR/CVaR, "
-                                   f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}",
+                                   f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}"
+                                   + (f", Jacobian written as {jacobian}" if jacobian else ""),
+                       "baseline_config": args.config,
                        "M_per_gpu": M, "S": S, "M_total": world * M,
-                       "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step",
-                       "launch": "hipGraph replay of the whole step" if use_graph else (
-                           "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
-                           if pipelined else "eager, one stream, no overlap between steps")},
-            "roofline": {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "frac_of_measured_copy_6290": achieved / 6290.0,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
-                         "traffic": pmc_traffic(args.workload, args.mode, M, S, jacobian)},
-            "stats": {"VaR": final_stats[0], "CVaR": final_stats[1], "frac_satisfied": final_stats[2]},
+                       "value_is_for": ("the SURVEY 8(d) contract: every structural nonzero of the Jacobian written "
+                                        "(3S(S-1) numbers per sample)" if jacobian == "products" else
+                                        ("the factored Jacobian (Phi, W): S(S-1)+6S numbers per sample"
+                                         if jacobian == "factored" else "the whole step")),
+                       "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step "
+                                      f"(RCCL behind the C ABI: rato_comm_exchange)",
+                       "launch": head["launch"]},
+            "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian),
+            "stats": {"VaR": head["stats"][0], "CVaR": head["stats"][1], "frac_satisfied": head["stats"][2]},
         }
+        for res in results[1:]:                           # the other output representation, same run, same samples
+            w = res["work"]
+            line["roofline_" + res["variant"]] = roofline_block(w, res["kern_ms"], args.workload, args.mode, M, S,
+                                                               res["variant"])
+            line["value_" + res["variant"]] = world * M * unit_steps * args.steps / res["elapsed"]
+            line["ms_per_step_" + res["variant"]] = 1e3 * res["elapsed"] / args.steps
+        if world == 1 and is_drone_lin and not args.no_scp:
+            line["scp"] = scp_block(results[-1]["work"], args)
         if world == 1 and not args.no_cpu_baseline:
             n = args.cpu_samples or CPU_SAMPLES[args.workload]
             cpu_step = work.cpu_baseline(n, args.alpha)
@@ -458,6 +580,7 @@ def main():
                                   f"here); host reports {os.cpu_count()} cpus",
                 "gpu_over_cpu": value / cpu_val}
         print(json.dumps(line))
+    rdist.destroy_comms()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -73,7 +73,8 @@ def to_soa_inputs(states_init, omegas_speed, omegas_repulsive, DWs, device):
 
 class Model:
     def __init__(self, M, method='saa', alpha=0.05, S=P.S, device='cuda:0', rng=None,
-                 samples=None, verbose=False):
+                 samples=None, verbose=False, check_finite=False):
+        self.check_finite = check_finite        # scan every linearization for NaN/Inf -> RatoNonFiniteError (scp.py)
         if verbose:
             print("Initializing Model with")
             print("> method =", method)
@@ -220,6 +221,8 @@ class Model:
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
             _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
             _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
+        if self.check_finite:
+            stats.assert_finite("driving linearize", g_up, Z, final_du, final_rhs)
         return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M,
                 "cols_per_thread": cols_per_thread, "tile": tile}
 

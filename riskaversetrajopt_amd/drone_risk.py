@@ -67,8 +67,11 @@ def to_soa_inputs(DWs, masses, obs_Qs, device):
 
 class Model:
     def __init__(self, S, DWs, masses, obs_Qs, method='saa', alpha=0.1, device='cuda:0',
-                 verbose=False):
+                 verbose=False, check_finite=False):
         # drone_risk.py:71-93
+        # check_finite: scan g_up / Z / partial sums of every linearization for NaN/Inf and raise
+        # RatoNonFiniteError (the SCP drivers of scp.py switch it on; off in throughput runs: it costs a sync)
+        self.check_finite = check_finite
         if verbose:
             print("Initializing Model with")
             print("> method =", method)
@@ -256,6 +259,8 @@ class Model:
         if events is not None:
             events[1].record()
         sums = stats.sum_partials(part, out=o.get("sums"))           # [6S+6] fp64, one launch
+        if self.check_finite:
+            stats.assert_finite("drone linearize", g_up, Z, part)
         return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None),
                 "du_sum": sums[:6 * S].view(S, 6), "rhs_sum": sums[6 * S:], "sums": sums,
                 "part": part, "M": M, "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt,
@@ -283,6 +288,8 @@ class Model:
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(A22), _lib.ptr(Wf),
             _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()), "rato_drone_linearize_generators")
         sums = stats.sum_partials(part, out=o.get("sums"))
+        if self.check_finite:
+            stats.assert_finite("drone linearize (generators)", g_up, Z, part)
         return {"G": None, "g_up": g_up[..., :M], "Z": Z[:M], "du_sum": sums[:6 * S].view(S, 6),
                 "rhs_sum": sums[6 * S:], "sums": sums, "part": part, "M": M, "_g_up": g_up, "_Z": Z,
                 "tile": 64, "factored": True, "W": Wf[..., :M], "_W": Wf, "A22": A22[..., :M], "_A22": A22,
@@ -357,14 +364,15 @@ class Model:
         return g_obs_du, g_up
 
     # ---- hipGraph: one SCP-iteration's device work as a single replayable graph -------------
-    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0):
+    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None):
         """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
         only the capture/replay plumbing; the nodes are this library's kernels).  Returns a
         ``StepGraph``: write the controls into ``.us`` (device tensor, (S, n_u)), call ``.replay()``
         and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[10], rato_saa.h)."""
         alpha = self.alpha if alpha is None else alpha
         us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
-        out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane)
+        out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane,
+                                    factored=factored)
         ws = torch.empty(self._lib.rato_risk_stats_workspace_bytes(out["M"]), dtype=torch.uint8, device=self.device)
         st = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
         stats.risk_stats_device(out["Z"], alpha, workspace=ws, out=st)         # warm-up: uncaptured first call
@@ -372,7 +380,7 @@ class Model:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             res = self.linearize_device(us, cols_per_thread=out["cols_per_thread"],
-                                        samples_per_lane=out["samples_per_lane"], out=out)
+                                        samples_per_lane=out["samples_per_lane"], out=out, factored=out["factored"])
             stats.risk_stats_device(res["Z"], alpha, workspace=ws, out=st)
         return StepGraph(graph, us, res, st)
 

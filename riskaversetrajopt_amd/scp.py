@@ -24,10 +24,18 @@ def _sync():
         pass
 
 
-def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False):
+def _finite_guard(model, check_finite):
+    """Failure detection: every linearization of the run is scanned for NaN/Inf and a non-finite output raises
+    ``RatoNonFiniteError`` (RATO_ENONFINITE) instead of the reference's print-and-continue (drone_risk.py:458-459)."""
+    if check_finite is not None and hasattr(model, "check_finite"):
+        model.check_finite = bool(check_finite)
+
+
+def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False, check_finite=True):
     """drone_risk.py:503-532: define once (scp_iter=2 pattern), ``warmup_iters`` throw-away
     iterations, restart, then a fixed number of update_problem/solve iterations.
     -> dict(us, t_risk, define_s, solve_s, cumulative_s, L2_error)"""
+    _finite_guard(model, check_finite)
     us_prev = model.initial_guess_us_mat()
     model.define_problem(us_prev, verbose=False)
     for scp_iter in range(warmup_iters):
@@ -55,10 +63,11 @@ def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False):
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
 
 
-def run_drone_reduced(model, num_scp_iters_max=60, verbose=False):
+def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=True):
     """The SCP loop (drone_risk.py:519-532; also used for driving, driving.py:486-513) with every subproblem solved through
     ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
     "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop."""
+    _finite_guard(model, check_finite)
     us_prev = model.initial_guess_us_mat()
     define_s, solve_s, err, cuts, oracle_s = [], [], [], [], []
     t_risk = None
@@ -83,9 +92,10 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False):
             "oracle_s": np.array(oracle_s)}
 
 
-def run_driving(model, num_scp_iters_max=15, verbose=False):
+def run_driving(model, num_scp_iters_max=15, verbose=False, check_finite=True):
     """driving.py:474-513: two warm-up solves (scp_iter 0 and 1), restart, then a fixed number of
     define_problem/solve iterations (define re-sets the solver up at iterations 0 and 1)."""
+    _finite_guard(model, check_finite)
     us_prev = model.initial_guess_us_mat()
     model.define_problem(us_prev, verbose=False)
     us, _ = model.solve()
@@ -127,9 +137,9 @@ def load_results(path, n):
         return [np.load(f) for _ in range(n)]
 
 
-def run_driving_reduced(model, num_scp_iters_max=15, verbose=False):
+def run_driving_reduced(model, num_scp_iters_max=15, verbose=False, check_finite=True):
     """driving.py:486-513 with ``Model.solve_reduced`` subproblems (same loop as run_drone_reduced)."""
-    return run_drone_reduced(model, num_scp_iters_max=num_scp_iters_max, verbose=verbose)
+    return run_drone_reduced(model, num_scp_iters_max=num_scp_iters_max, verbose=verbose, check_finite=check_finite)
 
 
 def monte_carlo_report(mc_model, us_list, alpha, verbose=False):

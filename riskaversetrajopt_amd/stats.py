@@ -79,3 +79,23 @@ def count_nonfinite(x):
     _lib.check(lib.rato_count_nonfinite(_lib.ptr(x), x.numel(), _lib.ptr(cnt), _lib.current_stream()),
                "rato_count_nonfinite")
     return int(cnt.item())
+
+
+def assert_finite(what, *tensors):
+    """Failure detection for the hot path (a distinct status on non-finite output; the reference only
+    prints "[solve]: Problem infeasible.", drone_risk.py:458-459, and keeps iterating on NaNs): counts the NaN/Inf
+    entries of the given device fp32 tensors into ONE device counter (rato_count_nonfinite + _acc), reads it back
+    once and raises ``RatoNonFiniteError`` (status RATO_ENONFINITE) if it is not zero."""
+    lib = _lib.load()
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return
+    cnt = torch.empty(1, dtype=torch.int32, device=tensors[0].device)
+    st = _lib.current_stream()
+    for i, t in enumerate(tensors):
+        _lib.require_f32_device(t, what)
+        fn = lib.rato_count_nonfinite if i == 0 else lib.rato_count_nonfinite_acc
+        _lib.check(fn(_lib.ptr(t), t.numel(), _lib.ptr(cnt), st), "rato_count_nonfinite")
+    bad = int(cnt.item())
+    if bad:
+        raise _lib.RatoNonFiniteError(f"{what}: {bad} non-finite values in the device outputs (RATO_ENONFINITE)")
