@@ -108,8 +108,10 @@ def test_metric_config_linearize_vs_oracle(factored):
     assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.1)) < 2e-4 * max(1.0, abs(st["var"]))
     assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.1)) < 2e-4 * max(1.0, abs(st["cvar"]))
     # run-to-run bitwise determinism at this launch shape
+    from riskaversetrajopt_amd.drone_risk import untile
     r2 = d.linearize_device(us, factored=factored)
-    assert torch.equal(r["G"], r2["G"]) and torch.equal(r["g_up"], r2["g_up"]) and torch.equal(r["sums"], r2["sums"])
+    assert torch.equal(untile(r["G"], M), untile(r2["G"], M))      # (lanes >= M of the last tile are never written)
+    assert torch.equal(r["g_up"], r2["g_up"]) and torch.equal(r["sums"], r2["sums"]) and torch.equal(r["Z"], r2["Z"])
 
 
 def test_metric_config_products_equal_factored_products():
