@@ -333,6 +333,49 @@ int rato_saa_tail_rows_batch(const float* G, const float* W /* NULL or factor */
                              int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM, float* part,
                              void* stream);
 
+/* ------------------------------------------------------------ device sampler */
+
+/*
+ * Device-side sampler: Philox4x32-10 (Salmon et al., SC'11), counter = (sample m, step / row t, stream
+ * id), key = seed; 24-bit uniforms, Box-Muller normals (csrc/philox.h).  The value at (seed, stream, t, m) is a pure
+ * function of those numbers: the same batch can be MATERIALISED (rato_*_sample) or REGENERATED inside the rollout
+ * kernels (rato_*_eval_philox), bit for bit.  These replace, for synthetic / Monte-Carlo batches that never leave
+ * HBM, the host loops of drone_utils.py:61-93, driving.py:84-120, hopper.py:70-74 (same distributions; the host
+ * samplers of the Python facades replay the reference's MT19937 stream when identical draws are wanted).
+ *
+ * Generic fills, layout out[T][C][ld] (C <= 4 values per Philox call), used by the tests and as utilities:
+ *   rato_philox_u32      the raw 4 words            out[t][0..3][m]
+ *   rato_philox_normal   scale[k] * N(0,1) + mean[k]           (scale / mean: HOST float[C], NULL = 1 / 0)
+ *   rato_philox_uniform  low[k] + width[k] * U(0,1)
+ */
+int rato_philox_u32(uint32_t* out, int32_t T, int64_t M, int64_t ld, uint64_t seed, uint32_t stream_id, void* stream);
+int rato_philox_normal(float* out, int32_t T, int32_t C, int64_t M, int64_t ld, uint64_t seed, uint32_t stream_id,
+                       const float* scale, const float* mean, void* stream);
+int rato_philox_uniform(float* out, int32_t T, int32_t C, int64_t M, int64_t ld, uint64_t seed, uint32_t stream_id,
+                        const float* width, const float* low, void* stream);
+
+/* drone_utils.py:61-93: dW [S][3][ld] = sqrt(sampler_dt) N(0,1) (velocity rows), mass [ld] ~ U(nom -+ delta),
+ * Qsym [3][3][ld] from semi-axes obs_radii[j] + U(-+ obs_radii_delta) per dimension (HOST float[3]).  dW may be NULL
+ * (noise regenerated in rato_drone_eval_philox); mass and Qsym may both be NULL. */
+int rato_drone_sample(int64_t M, int64_t ld, int32_t S, float sampler_dt, uint64_t seed, float mass_nom,
+                      float mass_delta, const float* obs_radii, float obs_radii_delta, float* dW, float* mass,
+                      float* Qsym, void* stream);
+/* rato_drone_eval with the noise of rato_drone_sample(seed, sampler_dt) regenerated in the kernel (no dW array). */
+int rato_drone_eval_philox(const rato_drone_params* p, const float* us, uint64_t seed, float sampler_dt,
+                           const float* mass, const float* Qsym, float* Z, float* xs, float* g, void* stream);
+
+/* driving.py:84-120: dW [S][2][M], x0_ped [4][M] = x0_mean + x0_std * N(0,1) (HOST float[4] each), w_speed, w_rep [M]
+ * ~ U(nom -+ del).  dW may be NULL; the three parameter arrays may all be NULL. */
+int rato_car_sample(int64_t M, int32_t S, float sampler_dt, uint64_t seed, float w_speed_nom, float w_speed_del,
+                    float w_rep_nom, float w_rep_del, const float* x0_mean, const float* x0_std, float* dW,
+                    float* x0_ped, float* w_speed, float* w_rep, void* stream);
+int rato_car_eval_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
+                         const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch, float* Z,
+                         float* xs, float* g, void* stream);
+
+/* hopper.py:70-74: a = 0.025 sqrt(2/30) U(0,1), theta = pi U(0,1), tau = 2 pi U(0,1), each [30][M]. */
+int rato_hopper_sample(int64_t M, uint64_t seed, float* a, float* theta, float* tau, void* stream);
+
 /* ---------------------------------------------------------------- multi-GPU */
 
 /*

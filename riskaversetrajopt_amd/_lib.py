@@ -69,6 +69,20 @@ SIGNATURES = {
     "rato_comm_exchange": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int64, c_float_p,
                                      c_float_p, c_stream]),
     "rato_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rato_philox_u32": (C.c_int, [c_float_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, c_stream]),
+    "rato_philox_normal": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), c_stream]),
+    "rato_philox_uniform": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float), c_stream]),
+    "rato_drone_sample": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_float, C.c_float,
+                                    C.POINTER(C.c_float), C.c_float, c_float_p, c_float_p, c_float_p, c_stream]),
+    "rato_drone_eval_philox": (C.c_int, [C.POINTER(DroneParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 5 +
+                               [c_stream]),
+    "rato_car_sample": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64] + [C.c_float] * 4 +
+                        [C.POINTER(C.c_float), C.POINTER(C.c_float)] + [c_float_p] * 4 + [c_stream]),
+    "rato_car_eval_philox": (C.c_int, [C.POINTER(CarParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 7 +
+                             [c_stream]),
+    "rato_hopper_sample": (C.c_int, [C.c_int64, C.c_uint64, c_float_p, c_float_p, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),

@@ -14,6 +14,7 @@
 // share one slot because they share the activity window t > s).
 #include <atomic>
 
+#include "philox.h"
 #include "rato_common.h"
 
 namespace {
@@ -165,10 +166,13 @@ __device__ __forceinline__ void ped_step(const rato_car_params& P, const PedCons
   px = pxn; py = pyn; vx = vxn; vy = vyn;
 }
 
+// PHILOX: regenerate the two pedestrian noise components of step t in the kernel (philox.h; bit-identical to
+// rato_car_sample's dW) instead of reading 8 B per sample-step.
+template <bool PHILOX>
 __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
-    rato_car_params P, const float* __restrict__ dW, const float* __restrict__ x0_ped,
-    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const float* __restrict__ scratch,
-    float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ g) {
+    rato_car_params P, const float* __restrict__ dW, uint64_t seed, float noise_scale,
+    const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
+    const float* __restrict__ scratch, float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ g) {
   const size_t M = (size_t)P.M;
   const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
   if (m >= M) return;
@@ -185,10 +189,23 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
     xs[(size_t)4 * M + m] = px; xs[(size_t)5 * M + m] = py; xs[(size_t)6 * M + m] = vx; xs[(size_t)7 * M + m] = vy;
   }
   float zmax = -INFINITY;
-  float xi0 = dW[m], xi1 = dW[M + m];
+  float xi0 = 0.0f, xi1 = 0.0f;
+  if (!PHILOX) {
+    xi0 = dW[m];
+    xi1 = dW[M + m];
+  }
   for (int t = 0; t < S; ++t) {
-    const int tn = (t + 1 < S) ? t + 1 : t;
-    const float nx0 = dW[(size_t)(tn * 2 + 0) * M + m], nx1 = dW[(size_t)(tn * 2 + 1) * M + m];
+    float nx0 = 0.0f, nx1 = 0.0f;
+    if (PHILOX) {
+      const rato::u32x4 r = rato::philox_at(seed, rato::PHILOX_STREAM_DW, (uint32_t)t, (uint64_t)m);
+      rato::box_muller(r.x, r.y, xi0, xi1);
+      xi0 *= noise_scale;
+      xi1 *= noise_scale;
+    } else {
+      const int tn = (t + 1 < S) ? t + 1 : t;
+      nx0 = dW[(size_t)(tn * 2 + 0) * M + m];
+      nx1 = dW[(size_t)(tn * 2 + 1) * M + m];
+    }
     float n0, n1, rinv;
     ped_step(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy, n0, n1, rinv);
     const float dx = ego[(t + 1) * 4 + 0] - px, dy = ego[(t + 1) * 4 + 1] - py;
@@ -202,7 +219,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
       xs[((size_t)(t + 1) * 8 + 4) * M + m] = px; xs[((size_t)(t + 1) * 8 + 5) * M + m] = py;
       xs[((size_t)(t + 1) * 8 + 6) * M + m] = vx; xs[((size_t)(t + 1) * 8 + 7) * M + m] = vy;
     }
-    xi0 = nx0; xi1 = nx1;
+    if (!PHILOX) {
+      xi0 = nx0;
+      xi1 = nx1;
+    }
   }
   if (Z) Z[m] = zmax - P.tol;
 }
@@ -642,8 +662,23 @@ extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const fl
   hipStream_t st = rato::as_stream(stream);
   hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), ego_lds_bytes(p->S), st, *p, us, ego_scratch,
                      (float*)nullptr, (float*)nullptr, 0);
-  hipLaunchKernelGGL(car_eval_kernel, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW, x0_ped,
-                     w_speed, w_rep, ego_scratch, Z, xs, g);
+  hipLaunchKernelGGL(car_eval_kernel<false>, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW,
+                     (uint64_t)0, 0.0f, x0_ped, w_speed, w_rep, ego_scratch, Z, xs, g);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_car_eval_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
+                                    const float* x0_ped, const float* w_speed, const float* w_rep,
+                                    float* ego_scratch, float* Z, float* xs, float* g, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || !us || !x0_ped || !w_speed || !w_rep || !ego_scratch || !(sampler_dt >= 0.0f) || p->S > 65535)
+    return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), ego_lds_bytes(p->S), st, *p, us, ego_scratch,
+                     (float*)nullptr, (float*)nullptr, 0);
+  hipLaunchKernelGGL(car_eval_kernel<true>, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p,
+                     (const float*)nullptr, seed, sqrtf(sampler_dt), x0_ped, w_speed, w_rep, ego_scratch, Z, xs, g);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

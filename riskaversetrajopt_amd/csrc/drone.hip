@@ -11,6 +11,7 @@
 //   A_t = [[1, dt], [-kp dt/m, 1 - dt (kd + 2 c_d |v_t|)/m]],  B = [0, dt/m]^T.
 #include <atomic>
 
+#include "philox.h"
 #include "rato_common.h"
 
 namespace {
@@ -48,9 +49,13 @@ __device__ __forceinline__ void step_axis(const rato_drone_params& P, const Samp
   v = vn;
 }
 
+// PHILOX: the noise of step t is REGENERATED in the kernel (Philox4x32-10 at counter (m, t), philox.h) instead of
+// read from dW: bit-identical to rato_drone_sample's dW, no 12 B per sample-step of HBM reads, no 3 S floats per
+// sample of HBM capacity.  noise_scale = sqrt(sampler dt) (drone_utils.py:90).
+template <bool PHILOX>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
-    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
-    const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ Z,
+    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW, uint64_t seed,
+    float noise_scale, const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ Z,
     float* __restrict__ xs, float* __restrict__ g) {
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
@@ -72,13 +77,24 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
   }
   float zmax = -INFINITY;
   float xi[3];
+  if (!PHILOX) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
+    for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
+  }
   for (int t = 0; t < S; ++t) {
     float nxt[3];
-    const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
+    if (PHILOX) {
+      const rato::u32x4 r = rato::philox_at(seed, rato::PHILOX_STREAM_DW, (uint32_t)t, (uint64_t)m);
+      float n3;
+      rato::box_muller(r.x, r.y, xi[0], xi[1]);
+      rato::box_muller(r.z, r.w, xi[2], n3);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
+      for (int a = 0; a < 3; ++a) xi[a] *= noise_scale;
+    } else {
+      const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
+#pragma unroll
+      for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
     if (xs) {
@@ -95,8 +111,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
       zmax = fmaxf(zmax, gj);
       if (g) g[((size_t)j * S + t) * ld + m] = gj;
     }
+    if (!PHILOX) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
+      for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
+    }
   }
   if (Z) Z[m] = zmax - P.tol;
 }
@@ -853,7 +871,20 @@ extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, cons
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  hipLaunchKernelGGL(drone_eval_kernel, grid, block, 0, rato::as_stream(stream), *p, us, dW, mass, Qsym, Z, xs, g);
+  hipLaunchKernelGGL(drone_eval_kernel<false>, grid, block, 0, rato::as_stream(stream), *p, us, dW, (uint64_t)0, 0.0f,
+                     mass, Qsym, Z, xs, g);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_drone_eval_philox(const rato_drone_params* p, const float* us, uint64_t seed, float sampler_dt,
+                                      const float* mass, const float* Qsym, float* Z, float* xs, float* g,
+                                      void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || !us || !mass || !Qsym || !(sampler_dt >= 0.0f) || p->S > 65535) return RATO_EINVAL;
+  dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  hipLaunchKernelGGL(drone_eval_kernel<true>, grid, block, 0, rato::as_stream(stream), *p, us, (const float*)nullptr,
+                     seed, sqrtf(sampler_dt), mass, Qsym, Z, xs, g);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

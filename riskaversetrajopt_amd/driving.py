@@ -43,20 +43,23 @@ def sample_uncertain_parameters(M, method='saa', S=P.S, rng=None):
     return states_init, omegas_speed, omegas_repulsive, DWs
 
 
-def sample_uncertain_parameters_device(M, S, seed=0, device='cuda:0'):
-    """Synthetic batch drawn in HBM in kernel layout: dW [S][2][M], x0_ped [4][M],
-    w_speed [M], w_rep [M] (fp32)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    dt = P.T / S
-    dW = torch.randn((S, 2, M), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(dt))
-    u = lambda: 2 * torch.rand(M, generator=g, device=device, dtype=torch.float32) - 1
-    w_speed = P.omega_speed_nom + P.omega_speed_del * u()
-    w_rep = P.omega_repulsive_nom + P.omega_repulsive_del * u()
-    std = torch.tensor([1e-1, 1e-1, 1e-4, 1e-4], device=device)[:, None]
-    x0 = torch.tensor(P.state_init[4:], dtype=torch.float32, device=device)[:, None] + \
-        std * torch.randn((4, M), generator=g, device=device, dtype=torch.float32)
-    return dW, x0.contiguous(), w_speed, w_rep
+def sample_uncertain_parameters_device(M, S, seed=0, device='cuda:0', want_dW=True):
+    """Synthetic batch (driving.py:84-120 distributions) drawn in HBM by the library's Philox sampler
+    (rato_car_sample), in kernel layout: dW [S][2][M], x0_ped [4][M], w_speed [M], w_rep [M] (fp32).
+    ``want_dW=False``: no noise array (``Model.from_device(..., noise_seed=seed)`` regenerates it in the kernel)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    dW = e(S, 2, M) if want_dW else None
+    x0, w_speed, w_rep = e(4, M), e(M), e(M)
+    mean = (C.c_float * 4)(*[float(v) for v in P.state_init[4:]])
+    std = (C.c_float * 4)(*[float(v) for v in np.diag(std_matrix_ped_initial_state)])
+    with torch.cuda.device(dev):
+        _lib.check(lib.rato_car_sample(M, S, float(P.T / S), int(seed), float(P.omega_speed_nom),
+                                       float(P.omega_speed_del), float(P.omega_repulsive_nom),
+                                       float(P.omega_repulsive_del), mean, std, _lib.ptr(dW), _lib.ptr(x0),
+                                       _lib.ptr(w_speed), _lib.ptr(w_rep), _lib.current_stream()), "rato_car_sample")
+    return dW, x0, w_speed, w_rep
 
 
 def to_soa_inputs(states_init, omegas_speed, omegas_repulsive, DWs, device):
@@ -100,11 +103,18 @@ class Model:
                                     device=self.device)
 
     @classmethod
-    def from_device(cls, S, dW, x0_ped, w_speed, w_rep, method='saa', alpha=0.05):
-        self = cls(w_speed.numel(), method, alpha, S=S, device=dW.device, samples='device')
+    def from_device(cls, S, dW, x0_ped, w_speed, w_rep, method='saa', alpha=0.05, noise_seed=None):
+        """Batch resident in HBM in kernel layout.  ``dW=None`` with ``noise_seed``: the pedestrian noise of
+        ``sample_uncertain_parameters_device(seed=noise_seed)`` is regenerated inside the rollout kernel
+        (rato_car_eval_philox); the linearization kernels still need a materialised dW."""
+        self = cls(w_speed.numel(), method, alpha, S=S, device=w_speed.device, samples='device')
         self._ego_init = P.state_init[:4].astype(np.float64)
-        self._dW, self._x0, self._ws, self._wr = (_lib.require_f32_device(t, n) for t, n in
-                                                  ((dW, "dW"), (x0_ped, "x0_ped"), (w_speed, "w_speed"), (w_rep, "w_rep")))
+        self._x0, self._ws, self._wr = (_lib.require_f32_device(t, n) for t, n in
+                                        ((x0_ped, "x0_ped"), (w_speed, "w_speed"), (w_rep, "w_rep")))
+        self._dW = _lib.require_f32_device(dW, "dW") if dW is not None else None
+        if dW is None and noise_seed is None:
+            raise ValueError("from_device needs dW or a noise_seed to regenerate it from")
+        self._noise_seed = None if noise_seed is None else int(noise_seed)
         return self
 
     # ---- layout helpers (driving.py:122-143) -------------------------------
@@ -151,6 +161,12 @@ class Model:
         xs = self._empty(self.S + 1, n_x, M) if want_xs else None
         g = self._empty(self.S, M) if want_g else None
         p = self._params(M)
+        if dW is None:                                   # noise regenerated in the kernel (Philox, csrc/philox.h)
+            _lib.check(self._lib.rato_car_eval_philox(C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt),
+                                                      _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                                                      _lib.ptr(self._scratch), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
+                                                      _lib.current_stream()), "rato_car_eval_philox")
+            return Z, xs, g
         _lib.check(self._lib.rato_car_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws),
                                            _lib.ptr(wr), _lib.ptr(self._scratch), _lib.ptr(Z), _lib.ptr(xs),
                                            _lib.ptr(g), _lib.current_stream()), "rato_car_eval")
@@ -203,6 +219,8 @@ class Model:
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
+        if dW is None:
+            raise _lib.RatoError("the linearization kernels read a materialised dW (this Model regenerates its noise)")
         M, S = ws.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}

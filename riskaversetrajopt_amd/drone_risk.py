@@ -94,13 +94,21 @@ class Model:
                 raise ValueError(f"DWs has {self._dW.shape[0]} steps, Model has S={S}")
 
     @classmethod
-    def from_device(cls, S, dW, mass, Qsym, method='saa', alpha=0.1, M=None):
+    def from_device(cls, S, dW, mass, Qsym, method='saa', alpha=0.1, M=None, noise_seed=None, sampler_dt=None):
         """Batch already resident in HBM in kernel layout (throughput runs):
-        dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld]; M <= ld samples are used."""
-        self = cls(S, None, None, None, method, alpha, device=dW.device)
+        dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld]; M <= ld samples are used.
+        ``dW=None`` with ``noise_seed``: the Brownian increments of ``drone_utils.sample_uncertain_parameters_device(
+        seed=noise_seed, dt=sampler_dt)`` are REGENERATED inside the rollout kernel (rato_drone_eval_philox) instead
+        of being stored: Monte-Carlo validation batches (drone_risk.py:647-662) then cost 40 B per sample of HBM
+        instead of 12 S + 40; the linearization kernels still need a materialised dW."""
+        self = cls(S, None, None, None, method, alpha, device=mass.device)
         self.DWs = self.masses = self.obs_Qs = None
-        self._dW, self._mass, self._Qsym = (_lib.require_f32_device(t, n) for t, n in
-                                            ((dW, "dW"), (mass, "mass"), (Qsym, "Qsym")))
+        self._mass, self._Qsym = (_lib.require_f32_device(t, n) for t, n in ((mass, "mass"), (Qsym, "Qsym")))
+        self._dW = _lib.require_f32_device(dW, "dW") if dW is not None else None
+        if dW is None and noise_seed is None:
+            raise ValueError("from_device needs dW or a noise_seed to regenerate it from")
+        self._noise_seed = None if noise_seed is None else int(noise_seed)
+        self._sampler_dt = P.T / S if sampler_dt is None else float(sampler_dt)
         self.M = mass.numel() if M is None else M
         return self
 
@@ -157,6 +165,11 @@ class Model:
         xs = self._empty(self.S + 1, n_x, ld) if want_xs else None
         g = self._empty(n_obs, self.S, ld) if want_g else None
         p = self._params(M, ld)
+        if dW is None:                                   # noise regenerated in the kernel (Philox, csrc/philox.h)
+            _lib.check(self._lib.rato_drone_eval_philox(C.byref(p), _lib.ptr(us), self._noise_seed, self._sampler_dt,
+                                                        _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs),
+                                                        _lib.ptr(g), _lib.current_stream()), "rato_drone_eval_philox")
+            return Z[:M], (xs[..., :M] if want_xs else None), (g[..., :M] if want_g else None)
         _lib.check(self._lib.rato_drone_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass),
                                              _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
                                              _lib.current_stream()), "rato_drone_eval")
@@ -226,6 +239,8 @@ class Model:
         linearize launch on the launch stream (bench.py's roofline timing).
         """
         dW, mass, Qsym, M = self._inputs(inputs)
+        if dW is None:
+            raise _lib.RatoError("the linearization kernels read a materialised dW (this Model regenerates its noise)")
         ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
         nblk, cpt, spl, tile = self.linearize_plan(M, ld, cols_per_thread, samples_per_lane)

@@ -33,19 +33,26 @@ def sample_uncertain_parameters(method='saa', M=100, S=P.S, dt=P.dt, rng=None):
     return DWs, masses, obs_Qs
 
 
-def sample_uncertain_parameters_device(M, S, dt=P.dt, seed=0, device='cuda:0'):
-    """Synthetic batch with the reference's distributions drawn on the device,
-    already in kernel layout with row stride ld = M rounded up to a multiple of 4:
-    dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld] (fp32; the ld-M padding samples are
-    ordinary draws that the kernels ignore)."""
+def sample_uncertain_parameters_device(M, S, dt=None, seed=0, device='cuda:0', want_dW=True):
+    """Synthetic batch with the reference's distributions (drone_utils.py:61-93) drawn ON THE DEVICE by the library's
+    Philox4x32-10 sampler (rato_drone_sample), already in kernel layout with row stride ld = M rounded up to a
+    multiple of 4: dW [S][3][ld], mass [ld], Qsym [n_obs][3][ld] (fp32; the ld-M padding samples are ordinary draws
+    that the kernels ignore).  ``dt``: the sampler's dt, default T/S — the dt of the Model the batch is for (the
+    reference's own default is its module-level dt = T/S with ITS S, drone_utils.py:61).  ``want_dW=False``: no
+    noise array at all — ``Model.from_device(..., noise_seed=seed)`` regenerates it inside the rollout kernel."""
+    import ctypes as C
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    from . import _lib
+    lib = _lib.load()
+    dt = P.T / S if dt is None else dt
     ld = (M + 3) // 4 * 4
-    dW = torch.randn((S, 3, ld), generator=g, device=device, dtype=torch.float32) * float(np.sqrt(dt))
-    mass = P.mass_nom + P.mass_delta * (2 * torch.rand(ld, generator=g, device=device, dtype=torch.float32) - 1)
-    r = torch.as_tensor(P.obs_radii, dtype=torch.float32, device=device)[:, None, None] + \
-        P.obs_radii_deltas * (2 * torch.rand((P.n_obs, 3, ld), generator=g, device=device, dtype=torch.float32) - 1)
-    q = 1.0 / (r * r)                      # diag entries (x, y, z) per obstacle
-    Qsym = torch.stack([q[:, 0], torch.zeros_like(q[:, 0]), q[:, 1]], dim=1).contiguous()
+    dev = torch.device(device)
+    dW = torch.empty((S, 3, ld), dtype=torch.float32, device=dev) if want_dW else None
+    mass = torch.empty(ld, dtype=torch.float32, device=dev)
+    Qsym = torch.empty((P.n_obs, 3, ld), dtype=torch.float32, device=dev)
+    radii = (C.c_float * 3)(*[float(r) for r in P.obs_radii])
+    with torch.cuda.device(dev):
+        _lib.check(lib.rato_drone_sample(ld, ld, S, float(dt), int(seed), float(P.mass_nom), float(P.mass_delta), radii,
+                                         float(P.obs_radii_deltas), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
+                                         _lib.current_stream()), "rato_drone_sample")
     return dW, mass, Qsym

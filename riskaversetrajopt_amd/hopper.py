@@ -34,11 +34,15 @@ def sample_friction_fields(M, rng=None):
 
 
 def sample_friction_fields_device(M, seed=1, device='cuda:0'):
-    """Synthetic fields drawn in HBM in kernel layout [30][M] (fp32)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    r = lambda: torch.rand((num_mu_features, M), generator=g, device=device, dtype=torch.float32)
-    return (0.025 * float(np.sqrt(2 / num_mu_features))) * r(), float(np.pi) * r(), float(2 * np.pi) * r()
+    """Synthetic fields (hopper.py:70-74 distributions) drawn in HBM by the library's Philox sampler
+    (rato_hopper_sample), kernel layout [30][M] (fp32)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    a, th, tau = (torch.empty((num_mu_features, M), dtype=torch.float32, device=dev) for _ in range(3))
+    with torch.cuda.device(dev):
+        _lib.check(lib.rato_hopper_sample(M, int(seed), _lib.ptr(a), _lib.ptr(th), _lib.ptr(tau),
+                                          _lib.current_stream()), "rato_hopper_sample")
+    return a, th, tau
 
 
 class Model:
