@@ -124,11 +124,12 @@ class DroneWork:
         else:
             self.kernel = "drone_eval_kernel"
 
-    def hot_kernel(self, events=None, slot=0):
-        """One pass; ``events`` bracket ONLY the dominant kernel's launch."""
+    def hot_kernel(self, events=None, slot=0, reduce=True):
+        """One pass; ``events`` bracket ONLY the dominant kernel's launch.  ``reduce=False``: the partial sums stay
+        unreduced (the single-GPU step folds their reduction into the launch of the risk statistics)."""
         if self.mode == "linearize":
             return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
-                                               out=self.outs[slot], events=events, factored=self.fact)
+                                               out=self.outs[slot], events=events, factored=self.fact, reduce=reduce)
         if events is not None:
             events[0].record()
         Z, _, _ = self.model.eval_device(self.us)
@@ -351,9 +352,8 @@ def roofline_block(work, kern_ms, workload, mode, M, S, jacobian):
 def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
     """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; -> dict."""
     M = work.M
-    ws_bytes = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(M * world), dtype=torch.uint8, device=device)
     stats_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
-    wss = [ws_bytes, torch.empty_like(ws_bytes)]
+    wss = [stats.new_workspace(M * world, device), stats.new_workspace(M * world, device)]
 
     def barrier():
         if dist.is_initialized():
@@ -376,6 +376,12 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         counter[0] += 1
         if pipelined:
             main_stream.wait_event(ev_free[slot])
+        fold = world == 1 and isinstance(work, DroneWork) and work.mode == "linearize" and not pipelined
+        if fold:       # single GPU: linearize, then ONE launch for the sample sums + VaR / CVaR (2 launches per step)
+            r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot, reduce=False)
+            stats.sums_and_risk_stats_device(r["part"], r["Z"], args.alpha, workspace=wss[slot], sums_out=r["sums"],
+                                             out=stats_out[slot])
+            return r["sums"]
         r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot)
         if pipelined:
             ev_lin[slot].record(main_stream)

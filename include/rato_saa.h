@@ -308,7 +308,7 @@ int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass,
  * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =
  * sum over the block's samples of w_i * G_i[arg_i, (s,g)], with w_i = 1 if
  * m_vals[i] > tstar, lambda if == tstar, 0 otherwise.  Reduce with rato_sum_partials.
- * If stats_dev != NULL (the device double[10] written by rato_risk_stats on m_vals), tstar and
+ * If stats_dev != NULL (the device double[RATO_N_STATS] written by rato_risk_stats on m_vals), tstar (slot 10) and
  * lambda = clamp((alphaM - #{m > t}) / #{m == t}, 0, 1) are taken from it on the device instead
  * of from the arguments (no host round trip between the two calls).
  */
@@ -428,8 +428,12 @@ int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, void* strea
  * turns a non-zero count into RATO_ENONFINITE / RatoNonFiniteError. */
 int rato_count_nonfinite_acc(const float* x, int64_t n, uint32_t* count, void* stream);
 
-/* Workspace bytes needed by rato_risk_stats for M samples. */
+/* Workspace of rato_risk_stats for M samples: caller-owned device memory of this many bytes, set up ONCE with
+ * rato_risk_stats_init (zero fill + a tag) before its first use; one workspace per stream that computes statistics
+ * concurrently.  Every call leaves it ready for the next one.  A workspace that was never initialised makes the
+ * single-launch path write NaN into all of `out` instead of computing from garbage. */
 size_t rato_risk_stats_workspace_bytes(int64_t M);
+int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Replaces the Monte-Carlo statistics: fraction satisfied (drone_risk.py:661,719),
@@ -437,12 +441,25 @@ size_t rato_risk_stats_workspace_bytes(int64_t M);
  * and AVaR/CVaR (drone_risk.py:663-695; the OSQP LP there is replaced by exact
  * selection of the Rockafellar-Uryasev minimiser followed by the closed form :694).
  *   Z [M]; thr = 1e-6 (the B_satisfied threshold)
- *   out: double[10] = { VaR, CVaR, fraction(Z<=thr), mean(Z), max(Z),
+ *   out: double[RATO_N_STATS] = { VaR, CVaR, fraction(Z<=thr), mean(Z), max(Z),
  *                       count(Z<=thr), sum(max(Z-t,0)), k (selected ascending rank),
- *                       #{Z > t}, #{Z == t} }   (t = the Rockafellar-Uryasev minimiser = VaR)
+ *                       #{Z > t}, #{Z == t}, t }
+ *        t = the Rockafellar-Uryasev minimiser = sort(Z)[k]; VaR = t except when floor(alpha M) == M, where the
+ *        reference's index -1 wraps to max(Z) (NumPy negative index, drone_main_plot.py:651) while CVaR, the counts
+ *        and every consumer of the threshold (rato_saa_tail_rows*) keep using t = out[10].
+ * Launches: 1 for M <= 131,072 (one workgroup below 8,192; above it histogram workgroups + a ticket, the last
+ * workgroup finishes: csrc/stats.hip rs_fused), 6 beyond.  Exact selection, deterministic sums.
  */
+#define RATO_N_STATS 11
 int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
                     void* workspace, size_t workspace_bytes, double* out, void* stream);
+
+/* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
+ * M <= 131,072 (the partial-sum workgroups ride along with the histogram workgroups; two stream-ordered calls
+ * otherwise): the whole reduction stage of a single-GPU SAA step. */
+int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
+                             const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                             size_t workspace_bytes, double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,9 @@ SIGNATURES = {
                              [c_stream]),
     "rato_hopper_sample": (C.c_int, [C.c_int64, C.c_uint64, c_float_p, c_float_p, c_float_p, c_stream]),
     "rato_risk_stats_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "rato_risk_stats_init": (C.c_int, [C.c_void_p, C.c_size_t, c_stream]),
+    "rato_sums_and_risk_stats": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_float_p, C.c_int64,
+                                           C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
                                                                double alphaM, float* __restrict__ part) {
   extern __shared__ float tr_lds[];   // [4 waves][2*(S-1)]
   if (stats_dev) {  // threshold and tie weight straight from rato_risk_stats' device output (no host round trip)
-    tstar = (float)stats_dev[0];
+    tstar = (float)stats_dev[10];   // the Rockafellar-Uryasev minimiser (slot 0 = VaR wraps to max(Z) when floor(alpha M) = M)
     const double n_gt = stats_dev[8], n_eq = stats_dev[9];
     double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
     lambda = (float)fmin(fmax(l, 0.0), 1.0);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
   const float* __restrict__ mvals = m_base + slot * M;
   const int* __restrict__ arg = arg_base + slot * M;
   const double* __restrict__ st = stats_base + slot * stats_stride;
-  const float tstar = (float)st[0];
+  const float tstar = (float)st[10];
   const double n_gt = st[8], n_eq = st[9];
   const double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
   const float lambda = (float)fmin(fmax(l, 0.0), 1.0);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
   const float* __restrict__ mvals = m_base + slot * M;
   const int* __restrict__ arg = arg_base + slot * M;
   const double* __restrict__ st = stats_base + slot * stats_stride;
-  const float tstar = (float)st[0];
+  const float tstar = (float)st[10];
   const double n_gt = st[8], n_eq = st[9];
   const double lq = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
   const float lambda = (float)fmin(fmax(lq, 0.0), 1.0);

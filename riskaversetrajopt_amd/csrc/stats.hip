@@ -17,12 +17,11 @@ namespace {
 // bandwidth-bound), then a fixed-order LDS tree gives a run-to-run identical fp64 sum.
 constexpr int SP_COLS = 16, SP_ROWS = 64;
 
-__global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const float* __restrict__ part, int nblocks,
-                                                                       int ncols, double scale,
-                                                                       double* __restrict__ out) {
+__device__ __forceinline__ void sum_partials_block(int col_block, const float* __restrict__ part, int nblocks,
+                                                   int ncols, double scale, double* __restrict__ out) {
   __shared__ double red[SP_ROWS][SP_COLS + 1];
   const int cx = threadIdx.x % SP_COLS, ry = threadIdx.x / SP_COLS;
-  const int c = blockIdx.x * SP_COLS + cx;
+  const int c = col_block * SP_COLS + cx;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (c < ncols) {
     int b = ry;
@@ -48,6 +47,12 @@ __global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const fl
   if (ry == 0 && c < ncols) out[c] = red[0][cx] * scale;
 }
 
+__global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const float* __restrict__ part, int nblocks,
+                                                                       int ncols, double scale,
+                                                                       double* __restrict__ out) {
+  sum_partials_block(blockIdx.x, part, nblocks, ncols, scale, out);
+}
+
 // ------------------------------------------------------------ non-finite check
 __global__ __launch_bounds__(RATO_BLOCK) void count_nonfinite_kernel(const float* __restrict__ x, long n,
                                                                      unsigned* __restrict__ count) {
@@ -71,7 +76,12 @@ struct Workspace {
   double blockpart[RS_MAX_BLOCKS][6];  // sum Z, count(Z<=thr), max Z, tail sum, count(Z>t), count(Z==t)
   float tstar;
   unsigned nblocks;
+  // single-launch path (rs_fused): self-cleaning state -- zero between calls, set up once by rato_risk_stats_init
+  unsigned fhist[B1];
+  unsigned fticket;
+  unsigned magic;
 };
+constexpr unsigned RS_MAGIC = 0x52A70517u;
 
 // order-preserving map float -> uint32 (ascending)
 __device__ __forceinline__ unsigned key_of(float f) {
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
   out[7] = (double)k;
   out[8] = ngt;                                // #{Z > t}
   out[9] = neq;                                // #{Z == t}
+  out[10] = t;                                 // the Rockafellar-Uryasev minimiser itself (== out[0] unless var_is_max)
 }
 
 // ---- single-workgroup form for small M (<= RS_SINGLE_MAX): the whole selection in ONE launch (Z is a few tens of
@@ -367,7 +378,219 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
     out[7] = (double)k;
     out[8] = NG;
     out[9] = NE;
+    out[10] = (double)t;
   }
+}
+
+
+// ---- ONE launch for 8192 < M <= RS_FUSED_MAX (the BASELINE configs C2-C4 and the metric's M = 1e5), optionally with
+// the second stage of the sample mean riding along in extra workgroups (what used to be rs_zero + 3 passes + tail +
+// final + sum_partials = 7 launches, ~25-35 us of launch-bound time per step, as long as a whole linearize kernel at
+// M = 1e4).
+//   stage 1, g_hist workgroups: LDS histogram of the top 11 key bits of a slice of Z, flushed with RETURNING integer
+//            atomics into ws->fhist; every wave waits for its atomics, the workgroup takes a ticket (one returning
+//            atomic).  No spinning anywhere: a workgroup that is not last simply exits.
+//   stage 2, the workgroup whose ticket is last: reads AND re-zeroes ws->fhist with atomic exchanges (the same
+//            coherence point as the adds: no cache has to be trusted), finds the bin b1 of the wanted rank, then makes
+//            ONE pass over Z (16-byte loads): sum, count(Z <= thr), max, the part of the tail that lies in bins above
+//            b1 (accumulated against the lower edge of bin b1 + 1, all terms >= 0), and the keys of bin b1 compacted
+//            into LDS (wave-aggregated append).  The remaining 21 key bits are selected inside LDS (2 histogram passes
+//            over the candidates only).  The candidates' share of the tail is EXACT integer arithmetic: inside a bin
+//            the exponent is fixed, so z = v0 + low21 * ulp and sum_{z > t}(z - t) = ulp * (sum low21 - n * low21(t)).
+//            If bin b1 holds more than RSF_CAP keys (heavily tied / clustered data) the same steps re-read Z instead.
+// Deterministic: integer atomics commute, every floating-point sum has a fixed order.
+constexpr long RS_FUSED_MAX = 1 << 17;
+constexpr int RSF_CAP = 10240;
+
+__device__ __forceinline__ double block_max_1024(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, RATO_WAVE));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double m = -INFINITY;
+  for (int w = 0; w < RS1_T / RATO_WAVE; ++w) m = fmax(m, red[w]);
+  return m;
+}
+
+__global__ __launch_bounds__(RS1_T) void rs_fused(const float* __restrict__ Z, long M, double alpha, unsigned k,
+                                                  int var_is_max, float thr, Workspace* __restrict__ ws,
+                                                  double* __restrict__ out, int g_hist,
+                                                  const float* __restrict__ part, int nblocks, int ncols,
+                                                  double scale, double* __restrict__ sums_out) {
+  if ((int)blockIdx.x >= g_hist) {   // the sample-mean second stage rides along (independent workgroups)
+    sum_partials_block(blockIdx.x - g_hist, part, nblocks, ncols, scale, sums_out);
+    return;
+  }
+  __shared__ unsigned h[B1];
+  __shared__ unsigned cand[RSF_CAP];
+  __shared__ double red[RS1_T / RATO_WAVE];
+  __shared__ unsigned sh[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (ws->magic != RS_MAGIC) {       // workspace never initialised (rato_risk_stats_init): fail loudly, touch nothing
+    if (blockIdx.x == 0 && tid < 11) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  // ---- stage 1
+  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * RS1_T + tid; i < M; i += (long)g_hist * RS1_T) atomicAdd(&h[key_of(Z[i]) >> 21], 1u);
+  __syncthreads();
+  unsigned keep = 0;
+  for (int i = tid; i < B1; i += RS1_T) {
+    const unsigned c = h[i];
+    if (c) keep += __hip_atomic_fetch_add(&ws->fhist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::"v"(keep) : "memory");   // this wave's adds have been performed (values returned)
+  __syncthreads();
+  if (tid == 0) sh[0] = __hip_atomic_fetch_add(&ws->fticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (sh[0] != (unsigned)(g_hist - 1)) return;
+  // ---- stage 2: this workgroup's ticket is the last one: every other workgroup's adds precede it
+  for (int i = tid; i < B1; i += RS1_T)
+    h[i] = __hip_atomic_exchange(&ws->fhist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __hip_atomic_exchange(&ws->fticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[1] = 0;                         // candidate cursor
+  }
+  __syncthreads();
+  unsigned b1, k1, b2, k2, b3, k3;
+  find_bin<B1, RS1_T>(h, k, b1, k1);
+  const double r_hi = (b1 + 1 < (unsigned)B1) ? (double)value_of((b1 + 1) << 21) : 0.0;   // lower edge of bin b1 + 1
+  double sum = 0.0, s_hi = 0.0;
+  unsigned cnt_le = 0, n_hi = 0;
+  float mx = -INFINITY;
+  auto visit = [&](float z, bool live) {
+    const unsigned key = key_of(z), bin = key >> 21;
+    const bool is_c = live && bin == b1;
+    if (live) {
+      sum += (double)z;
+      cnt_le += (z <= thr) ? 1u : 0u;
+      mx = fmaxf(mx, z);
+      if (bin > b1) {
+        s_hi += (double)z - r_hi;
+        ++n_hi;
+      }
+    }
+    const unsigned long long mask = __ballot(is_c);   // wave-aggregated append of the candidates
+    if (mask) {
+      unsigned base = 0;
+      const int leader = __ffsll((long long)mask) - 1;
+      if (lane == leader) base = atomicAdd(&sh[1], (unsigned)__popcll(mask));
+      base = __shfl(base, leader, RATO_WAVE);
+      if (is_c) {
+        const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < (unsigned)RSF_CAP) cand[pos] = key;
+      }
+    }
+  };
+  {
+    // 16-byte loads over the aligned body, scalar head / tail
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(Z);
+    long head = (long)(((16 - (addr & 15)) & 15) >> 2);
+    if (head > M) head = M;
+    const long nvec = (M - head) >> 2;
+    const float4* __restrict__ Zv = reinterpret_cast<const float4*>(Z + head);
+    const long rounds = (nvec + RS1_T - 1) / RS1_T;     // every wave runs the same trip count (ballots inside)
+    for (long rnd = 0; rnd < rounds; rnd += 4) {
+      float4 v[4];
+      bool lv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = (rnd + u) * RS1_T + tid;
+        lv[u] = (rnd + u) < rounds && i < nvec;
+        v[u] = lv[u] ? Zv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if ((rnd + u) < rounds) {
+          visit(v[u].x, lv[u]);
+          visit(v[u].y, lv[u]);
+          visit(v[u].z, lv[u]);
+          visit(v[u].w, lv[u]);
+        }
+      }
+    }
+    const long rest0 = head + (nvec << 2);
+    {   // head [0, head) and tail [rest0, M): at most 3 + 3 elements, one round
+      const long i = (tid < head) ? tid : (rest0 + (tid - head));
+      const bool live = i < M && (tid < head || (tid - head) < (M - rest0));
+      visit(live ? Z[i] : 0.f, live);
+    }
+  }
+  __syncthreads();
+  const unsigned ncand = sh[1];
+  const bool in_lds = ncand <= (unsigned)RSF_CAP;
+  auto for_each_cand = [&](auto&& f) {
+    if (in_lds) {
+      for (unsigned i = tid; i < ncand; i += RS1_T) f(cand[i]);
+    } else {
+      for (long i = tid; i < M; i += RS1_T) {
+        const unsigned key = key_of(Z[i]);
+        if ((key >> 21) == b1) f(key);
+      }
+    }
+  };
+  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  for_each_cand([&](unsigned key) { atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u); });
+  __syncthreads();
+  find_bin<B2, RS1_T>(h, k1, b2, k2);
+  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  const unsigned prefix = (b1 << 11) | b2;
+  for_each_cand([&](unsigned key) {
+    if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
+  });
+  __syncthreads();
+  find_bin<B3, RS1_T>(h, k2, b3, k3);
+  const unsigned n_eq = h[b3];
+  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
+  const float t = value_of(tkey);
+  // candidates above t: count and exact integer sum of the low 21 key bits
+  unsigned long long low_sum = 0;
+  unsigned c_gt = 0;
+  for_each_cand([&](unsigned key) {
+    if (key > tkey) {
+      low_sum += key & 0x1fffffu;
+      ++c_gt;
+    }
+  });
+  const double S = block_sum_1024(sum, red);
+  const double SH = block_sum_1024(s_hi, red);
+  const double C = block_sum_1024((double)cnt_le, red);
+  const double NH = block_sum_1024((double)n_hi, red);
+  const double CG = block_sum_1024((double)c_gt, red);
+  const double LS = block_sum_1024((double)low_sum, red);     // per-thread sums < 2^53: exact in fp64, so is the total
+  const double MX = block_max_1024((double)mx, red);
+  if (tid == 0) {
+    const double td = (double)t;
+    const double v0 = (double)value_of(b1 << 21);
+    const double ulp = (double)value_of((b1 << 21) | 1u) - v0;   // spacing of the floats inside bin b1 (exact)
+    const double tail_c = ulp * (LS - CG * (double)(tkey & 0x1fffffu));
+    const double tail_h = (NH > 0.0) ? (SH + NH * (r_hi - td)) : 0.0;
+    const double T = tail_c + tail_h;
+    out[0] = var_is_max ? MX : td;
+    out[1] = td + (T / (double)M) / alpha;
+    out[2] = C / (double)M;
+    out[3] = S / (double)M;
+    out[4] = MX;
+    out[5] = C;
+    out[6] = T;
+    out[7] = (double)k;
+    out[8] = NH + CG;
+    out[9] = (double)n_eq;
+    out[10] = td;
+  }
+}
+
+// one workgroup: zero the whole workspace, then tag it
+__global__ __launch_bounds__(RATO_BLOCK) void rs_init_kernel(Workspace* __restrict__ ws) {
+  unsigned* w = reinterpret_cast<unsigned*>(ws);
+  const int n = (int)(sizeof(Workspace) / sizeof(unsigned));
+  for (int i = blockIdx.x * RATO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RATO_BLOCK) w[i] = 0;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws->magic = RS_MAGIC;
 }
 
 // ------------------------------------------------------------ gathered records
@@ -448,24 +671,44 @@ extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
   return sizeof(Workspace);
 }
 
-extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
-                               size_t workspace_bytes, double* out, void* stream) {
+namespace {
+int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
+                    double* out, const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
+                    void* stream) {
   RATO_CLEAR_ERROR();
   if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
     return RATO_EINVAL;
   if (workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
+  if (part && (!sums_out || nblocks <= 0 || ncols <= 0)) return RATO_EINVAL;
   // ascending 0-based rank of sort(Z)[M - floor(alpha*M) - 1]  (drone_main_plot.py:649-651)
   long xth = (long)floor(alpha * (double)M);
-  long kk = (long)M - xth - 1;
-  const int var_is_max = kk < 0;
-  if (kk < 0) kk = 0;  // the Rockafellar-Uryasev minimiser is then min(Z)
+  long kk = M - xth - 1;
+  int var_is_max = 0;
+  if (kk < 0) {  // alpha*M == M: the reference's index -1 wraps to the maximum
+    kk = 0;
+    var_is_max = 1;
+  }
   const unsigned k = (unsigned)kk;
-  Workspace* ws = static_cast<Workspace*>(workspace);
   hipStream_t st = rato::as_stream(stream);
-  if (M <= RS_SINGLE_MAX) {
+  Workspace* ws = static_cast<Workspace*>(workspace);
+  const int sp_blocks = part ? (ncols + SP_COLS - 1) / SP_COLS : 0;
+  if (M <= RS_SINGLE_MAX && !part) {
     hipLaunchKernelGGL(rs_single, dim3(1), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
+  }
+  if (M <= RS_FUSED_MAX) {   // ONE launch: histogram workgroups + (optionally) the partial-sum workgroups
+    int g_hist = (int)((M + 4 * RS1_T - 1) / (4 * RS1_T));
+    if (g_hist > 32) g_hist = 32;
+    if (g_hist < 1) g_hist = 1;
+    hipLaunchKernelGGL(rs_fused, dim3(g_hist + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, ws,
+                       out, g_hist, part, (int)nblocks, (int)ncols, scale, sums_out);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
+  }
+  if (part) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(sp_blocks), dim3(SP_COLS * SP_ROWS), 0, st, part, (int)nblocks,
+                       (int)ncols, scale, sums_out);
   }
   // Grid: 4 elements per thread up to 256 workgroups, then more elements per thread (every workgroup flushes its
   // LDS histogram with global atomics: at M ~ 1e6 of CLUSTERED values 1000 workgroups hammering the same few bins
@@ -486,4 +729,27 @@ extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float th
   hipLaunchKernelGGL(rs_final, dim3(1), dim3(RATO_WAVE), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
+}
+}  // namespace
+
+extern "C" int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!workspace || workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
+  hipLaunchKernelGGL(rs_init_kernel, dim3(1), dim3(RATO_BLOCK), 0, rato::as_stream(stream),
+                     static_cast<Workspace*>(workspace));
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                               size_t workspace_bytes, double* out, void* stream) {
+  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream);
+}
+
+extern "C" int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int32_t ncols, double scale,
+                                        double* sums_out, const float* Z, int64_t M, double alpha, float thr,
+                                        void* workspace, size_t workspace_bytes, double* out, void* stream) {
+  if (!part) return RATO_EINVAL;
+  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, part, nblocks, ncols, scale, sums_out,
+                         stream);
 }

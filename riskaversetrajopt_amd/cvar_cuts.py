@@ -91,7 +91,7 @@ class CvarCutSolver:
         self.sums_b_host = torch.zeros(self.keep_max * self.nc, dtype=torch.float64).pin_memory()
         self.slots_dev = torch.zeros(self.keep_max, dtype=torch.int32, device=device)
         self.slots_host = torch.zeros(self.keep_max, dtype=torch.int32).pin_memory()
-        self.ws = torch.empty(lib.rato_risk_stats_workspace_bytes(self.M_total), dtype=torch.uint8, device=device)
+        self.ws = stats.new_workspace(self.M_total, device)
         self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
         self.u_host = torch.zeros((S, n_u), dtype=torch.float32).pin_memory()
         self.us_dev = e(S, n_u)

@@ -221,7 +221,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None, factored=None, want_A22=False):
+                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -237,6 +237,8 @@ class Model:
         ``out``: a dict returned by an earlier call (same shapes) whose buffers are reused.
         ``events``: optional (start, end) torch.cuda.Event pair recorded tightly around the
         linearize launch on the launch stream (bench.py's roofline timing).
+        ``reduce=False``: leave the per-block partial sums unreduced (``part``); ``step_device`` folds their
+        reduction into the single launch of the risk statistics.
         """
         dW, mass, Qsym, M = self._inputs(inputs)
         if dW is None:
@@ -273,7 +275,11 @@ class Model:
             "rato_drone_linearize")
         if events is not None:
             events[1].record()
-        sums = stats.sum_partials(part, out=o.get("sums"))           # [6S+6] fp64, one launch
+        if reduce:
+            sums = stats.sum_partials(part, out=o.get("sums"))       # [6S+6] fp64, one launch
+        else:
+            sums = o["sums"] if o.get("sums") is not None else torch.empty(6 * S + 6, dtype=torch.float64,
+                                                                            device=self.device)
         if self.check_finite:
             stats.assert_finite("drone linearize", g_up, Z, part)
         return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None),
@@ -378,6 +384,15 @@ class Model:
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
+    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, **kw):
+        """One single-GPU SAA step in TWO launches: the linearize kernel, then ONE launch that reduces the sample
+        sums (drone_risk.py:294-296) and computes fraction satisfied / VaR / CVaR of Z (:661, :663-695,
+        drone_main_plot.py:640-652) -- rato_sums_and_risk_stats.  -> (linearize result dict, stats double[N_STATS])."""
+        r = self.linearize_device(us_mat, out=out, events=events, reduce=False, **kw)
+        _, st = stats.sums_and_risk_stats_device(r["part"], r["Z"], self.alpha if alpha is None else alpha,
+                                                 workspace=workspace, sums_out=r["sums"], out=stats_out)
+        return r, st
+
     # ---- hipGraph: one SCP-iteration's device work as a single replayable graph -------------
     def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None):
         """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
@@ -388,15 +403,15 @@ class Model:
         us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
         out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane,
                                     factored=factored)
-        ws = torch.empty(self._lib.rato_risk_stats_workspace_bytes(out["M"]), dtype=torch.uint8, device=self.device)
+        ws = stats.new_workspace(out["M"], self.device)
         st = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
-        stats.risk_stats_device(out["Z"], alpha, workspace=ws, out=st)         # warm-up: uncaptured first call
+        kw = dict(cols_per_thread=out["cols_per_thread"], samples_per_lane=out["samples_per_lane"],
+                  factored=out["factored"])
+        self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, **kw)      # warm-up: uncaptured first call
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            res = self.linearize_device(us, cols_per_thread=out["cols_per_thread"],
-                                        samples_per_lane=out["samples_per_lane"], out=out, factored=out["factored"])
-            stats.risk_stats_device(res["Z"], alpha, workspace=ws, out=st)
+            res, _ = self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, **kw)
         return StepGraph(graph, us, res, st)
 
     # ---- L3: sparse QP assembly (drone_risk.py:221-237, 282-423) -----------

@@ -11,7 +11,7 @@ from . import _lib
 SATISFIED_THRESHOLD = 1e-6   # ``B_satisfied = max_constraint <= 1e-6`` (drone_risk.py:661)
 
 _STAT_NAMES = ("var", "cvar", "frac_satisfied", "mean", "max", "count_satisfied", "tail_sum", "rank",
-               "count_above_var", "count_at_var")
+               "count_above_var", "count_at_var", "t_star")
 N_STATS = len(_STAT_NAMES)
 
 
@@ -23,15 +23,46 @@ def _as_device_f32(Z, device=None):
     return torch.as_tensor(np.asarray(Z, dtype=np.float32), device=device or 'cuda:0')
 
 
+def new_workspace(M, device):
+    """A rato_risk_stats workspace (device bytes), initialised once (rato_risk_stats_init); reusable for any number of
+    stream-ordered calls on ONE stream at a time."""
+    lib = _lib.load()
+    ws = torch.empty(lib.rato_risk_stats_workspace_bytes(M), dtype=torch.uint8, device=device)
+    with torch.cuda.device(ws.device):
+        _lib.check(lib.rato_risk_stats_init(_lib.ptr(ws), ws.numel(), _lib.current_stream()), "rato_risk_stats_init")
+    return ws
+
+
+def sums_and_risk_stats_device(part, Z, alpha, thr=SATISFIED_THRESHOLD, scale=1.0, workspace=None, sums_out=None,
+                               out=None, stream=None):
+    """sum_partials(part) and risk_stats_device(Z) as ONE launch for M <= 131,072 (rato_sums_and_risk_stats)
+    -> (sums fp64 (part.shape[1:]), stats fp64 [N_STATS])."""
+    lib = _lib.load()
+    _lib.require_f32_device(part, "part")
+    Z = _as_device_f32(Z)
+    M = Z.numel()
+    if workspace is None:
+        workspace = new_workspace(M, Z.device)
+    if sums_out is None:
+        sums_out = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
+    if out is None:
+        out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
+    _lib.check(lib.rato_sums_and_risk_stats(_lib.ptr(part), part.shape[0], part[0].numel(), float(scale),
+                                            _lib.ptr(sums_out), _lib.ptr(Z), M, float(alpha), float(thr),
+                                            _lib.ptr(workspace), workspace.numel(), _lib.ptr(out),
+                                            _lib.current_stream() if stream is None else stream),
+               "rato_sums_and_risk_stats")
+    return sums_out, out
+
+
 def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):
     """Z: device tensor (M,) fp32 -> device tensor double[10] (see rato_saa.h).
     Asynchronous on the current stream (``stream``: an already looked-up ``_lib.current_stream()``)."""
     lib = _lib.load()
     Z = _as_device_f32(Z)
     M = Z.numel()
-    nbytes = lib.rato_risk_stats_workspace_bytes(M)
     if workspace is None:
-        workspace = torch.empty(nbytes, dtype=torch.uint8, device=Z.device)
+        workspace = new_workspace(M, Z.device)
     if out is None:
         out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
     _lib.check(lib.rato_risk_stats(_lib.ptr(Z), M, float(alpha), float(thr), _lib.ptr(workspace),

@@ -29,9 +29,9 @@ def test_risk_stats_exact(M, alpha):
     assert st["max"] == ref["max"]
 
 
-def test_risk_stats_edge_distributions():
+@pytest.mark.parametrize("M", [5000, 20000, 100000])       # one workgroup / single-launch ticket path (LDS and re-read forms)
+def test_risk_stats_edge_distributions(M):
     from riskaversetrajopt_amd import stats
-    M = 5000
     cases = {
         "constant": np.full(M, -1.25, np.float32),
         "ties": np.repeat(np.float32([-3.0, -1.0, 0.0, 2.5]), M // 4),
@@ -40,6 +40,9 @@ def test_risk_stats_edge_distributions():
         "tiny": (np.random.RandomState(2).randn(M) * 1e-30).astype(np.float32),
         "clustered": (1.0 + 1e-6 * np.random.RandomState(3).rand(M)).astype(np.float32),
         "sorted_desc": np.linspace(5, -5, M).astype(np.float32),
+        "two_bins": (1.25 + 1e-4 * (np.random.RandomState(5).rand(M) - 0.5)).astype(np.float32),
+        "one_outlier": np.concatenate([np.full(M - 1, 0.5, np.float32), np.float32([1e6])]),
+        "negative_cluster": (-2.0 - 1e-5 * np.random.RandomState(6).rand(M)).astype(np.float32),
     }
     for name, Z in cases.items():
         for alpha in (0.05, 0.5):
@@ -121,3 +124,46 @@ def test_unpack_records_matches_host_layout():
             for r in recs[1:]:
                 ref += r.sums
             assert torch.equal(total[:n_sums], ref)
+
+
+@pytest.mark.parametrize("M", [1000, 10000, 50000, 100000, 300000])
+def test_sums_and_risk_stats_single_launch_equals_the_two_calls(M):
+    """rato_sums_and_risk_stats (ONE launch for M <= 131,072) == rato_sum_partials + rato_risk_stats, bit for bit"""
+    import torch
+    from riskaversetrajopt_amd import stats
+    rng = np.random.RandomState(M % 97)
+    Z = torch.as_tensor((rng.randn(M) * 0.5 - 0.2).astype(np.float32), device="cuda")
+    part = torch.as_tensor(rng.randn((M + 63) // 64, 306).astype(np.float32), device="cuda")
+    sums_a = stats.sum_partials(part)
+    st_a = stats.risk_stats_device(Z, 0.1)
+    ws = stats.new_workspace(M, Z.device)
+    for _ in range(3):                                           # the workspace cleans itself for the next call
+        sums_b, st_b = stats.sums_and_risk_stats_device(part, Z, 0.1, workspace=ws)
+        assert torch.equal(sums_a, sums_b) and torch.equal(st_a, st_b)
+    Zs = np.sort(Z.cpu().numpy())
+    assert st_b[0].item() == float(Zs[M - int(np.floor(0.1 * M)) - 1]) == st_b[10].item()
+
+
+def test_uninitialised_workspace_fails_loudly():
+    import torch
+    from riskaversetrajopt_amd import stats, _lib
+    lib = _lib.load()
+    M = 20000
+    Z = torch.randn(M, device="cuda")
+    ws = torch.full((lib.rato_risk_stats_workspace_bytes(M),), 0x5A, dtype=torch.uint8, device="cuda")   # never initialised
+    out = stats.risk_stats_device(Z, 0.1, workspace=ws)
+    assert torch.isnan(out).all()
+    good = stats.risk_stats_device(Z, 0.1)
+    assert torch.isfinite(good).all()
+
+
+def test_alpha_one_keeps_the_minimiser_separate_from_the_wrapped_var():
+    """floor(alpha M) == M: VaR wraps to max(Z) like the reference's index -1 (drone_main_plot.py:651), while the
+    Rockafellar-Uryasev minimiser t (slot 10), CVaR and the counts are those of t = min(Z)"""
+    from riskaversetrajopt_amd import stats
+    for M in (7, 5000, 20000, 200000):
+        Z = (np.random.RandomState(M).randn(M)).astype(np.float32)
+        st = stats.risk_stats(Z, 1.0)
+        assert st["var"] == float(Z.max()) and st["t_star"] == float(Z.min())
+        assert st["count_above_var"] + st["count_at_var"] == M
+        np.testing.assert_allclose(st["cvar"], Z.astype(np.float64).mean(), rtol=1e-12, atol=1e-12)

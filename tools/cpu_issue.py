@@ -7,7 +7,7 @@ sys.argv = ["bench.py"]
 args = bench.parse()
 dev = torch.device("cuda:0")
 work = bench.DroneWork(args, dev, 7)
-ws = torch.empty(stats._lib.load().rato_risk_stats_workspace_bytes(work.M), dtype=torch.uint8, device=dev)
+ws = stats.new_workspace(work.M, dev)
 out = torch.empty(stats.N_STATS, dtype=torch.float64, device=dev)
 for _ in range(5):
     r = work.hot_kernel(); stats.risk_stats_device(r["Z"], 0.1, workspace=ws, out=out)

@@ -7,7 +7,7 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 for M in (1000, 4096, 10000, 16384, 100000, 800000, 1000000, 8000000):
     for name, Z in (("clustered", 0.9 + 0.05 * torch.randn(M, generator=g, device=dev)),
                     ("spread", torch.randn(M, generator=g, device=dev) * torch.exp(8 * torch.rand(M, generator=g, device=dev)))):
-        ws = torch.zeros(stats._lib.load().rato_risk_stats_workspace_bytes(M), dtype=torch.uint8, device=dev)
+        ws = stats.new_workspace(M, dev)
         out = torch.empty(stats.N_STATS, dtype=torch.float64, device=dev)
         for _ in range(5):
             stats.risk_stats_device(Z, 0.1, workspace=ws, out=out)
