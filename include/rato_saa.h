@@ -430,8 +430,9 @@ int rato_count_nonfinite_acc(const float* x, int64_t n, uint32_t* count, void* s
 
 /* Workspace of rato_risk_stats for M samples: caller-owned device memory of this many bytes, set up ONCE with
  * rato_risk_stats_init (zero fill + a tag) before its first use; one workspace per stream that computes statistics
- * concurrently.  Every call leaves it ready for the next one.  A workspace that was never initialised makes the
- * single-launch path write NaN into all of `out` instead of computing from garbage. */
+ * concurrently.  Every call leaves it ready for the next one (the histograms are re-zeroed by the last launch).  A
+ * workspace that was never initialised makes the multi-launch path write NaN into all of `out` instead of numbers
+ * computed from garbage. */
 size_t rato_risk_stats_workspace_bytes(int64_t M);
 int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream);
 
@@ -447,15 +448,15 @@ int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream);
  *        t = the Rockafellar-Uryasev minimiser = sort(Z)[k]; VaR = t except when floor(alpha M) == M, where the
  *        reference's index -1 wraps to max(Z) (NumPy negative index, drone_main_plot.py:651) while CVaR, the counts
  *        and every consumer of the threshold (rato_saa_tail_rows*) keep using t = out[10].
- * Launches: 1 for M <= 131,072 (one workgroup below 8,192; above it histogram workgroups + a ticket, the last
- * workgroup finishes: csrc/stats.hip rs_fused), 6 beyond.  Exact selection, deterministic sums.
+ * Launches: 1 for M <= 32,768 (one workgroup, Z read once, keys resident in LDS: csrc/stats.hip rs_small), 5 beyond
+ * (3 histogram passes, tail, final).  Exact selection, deterministic sums.
  */
 #define RATO_N_STATS 11
 int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
                     void* workspace, size_t workspace_bytes, double* out, void* stream);
 
 /* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
- * M <= 131,072 (the partial-sum workgroups ride along with the histogram workgroups; two stream-ordered calls
+ * M <= 32,768 (the partial-sum workgroups ride along with the selection workgroup; two stream-ordered calls
  * otherwise): the whole reduction stage of a single-GPU SAA step. */
 int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
                              const float* Z, int64_t M, double alpha, float thr, void* workspace,

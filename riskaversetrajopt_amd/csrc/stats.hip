@@ -7,6 +7,10 @@
 // Everything is deterministic: no floating-point atomics; integer histogram
 // atomics commute.  Passes are separate launches on the caller's stream, so the
 // kernel boundary provides inter-workgroup visibility (no in-launch hand-off).
+#include <stdlib.h>
+
+#include <atomic>
+
 #include "rato_common.h"
 
 namespace {
@@ -76,10 +80,7 @@ struct Workspace {
   double blockpart[RS_MAX_BLOCKS][6];  // sum Z, count(Z<=thr), max Z, tail sum, count(Z>t), count(Z==t)
   float tstar;
   unsigned nblocks;
-  // single-launch path (rs_fused): self-cleaning state -- zero between calls, set up once by rato_risk_stats_init
-  unsigned fhist[B1];
-  unsigned fticket;
-  unsigned magic;
+  unsigned magic;   // set by rato_risk_stats_init: the histograms start zeroed and every call leaves them zeroed
 };
 constexpr unsigned RS_MAGIC = 0x52A70517u;
 
@@ -143,13 +144,6 @@ __device__ void flush_hist(unsigned* lds_hist, unsigned* __restrict__ ghist) {
     const unsigned c = lds_hist[i];
     if (c) atomicAdd(&ghist[i], c);
   }
-}
-
-// zeroes the three histograms (a kernel rather than hipMemsetAsync: memset nodes of this size did not
-// replay correctly inside a captured hipGraph on ROCm 7.2)
-__global__ __launch_bounds__(RATO_BLOCK) void rs_zero(Workspace* __restrict__ ws) {
-  unsigned* h = ws->hist1;  // hist1, hist2, hist3 are contiguous
-  for (int i = blockIdx.x * RATO_BLOCK + threadIdx.x; i < B1 + B2 + B3; i += gridDim.x * RATO_BLOCK) h[i] = 0;
 }
 
 __global__ __launch_bounds__(RATO_BLOCK) void rs_pass1(const float* __restrict__ Z, long M, float thr,
@@ -257,8 +251,19 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_tail(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsigned k, int var_is_max, int nblocks,
-                                                       const Workspace* __restrict__ ws, double* __restrict__ out) {
+__global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, unsigned k, int var_is_max, int nblocks,
+                                                        Workspace* __restrict__ ws, double* __restrict__ out) {
+  // leaves the three histograms zeroed for the next call (the workspace starts zeroed: rato_risk_stats_init), so a
+  // call is 5 launches instead of 6
+  // (zeroed by a kernel rather than hipMemsetAsync: memset nodes of this size did not replay correctly inside a
+  // captured hipGraph on ROCm 7.2)
+  const bool ok = ws->magic == RS_MAGIC;
+  for (int i = threadIdx.x; i < B1 + B2 + B3; i += RATO_BLOCK) ws->hist1[i] = 0;   // hist1..3 are contiguous
+  if (!ok) {   // never initialised: the histograms held garbage -> fail loudly instead of returning numbers
+    if (threadIdx.x < RATO_N_STATS) out[threadIdx.x] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  if (threadIdx.x >= RATO_WAVE) return;
   // one wave: lane i folds blocks i, i+64, ... in order, then a fixed shuffle tree (deterministic)
   const int lane = threadIdx.x;
   double s = 0, c = 0, m = -INFINITY, tail = 0, ngt = 0, neq = 0;
@@ -294,47 +299,63 @@ __global__ __launch_bounds__(RATO_WAVE) void rs_final(long M, double alpha, unsi
   out[10] = t;                                 // the Rockafellar-Uryasev minimiser itself (== out[0] unless var_is_max)
 }
 
-// ---- single-workgroup form for small M (<= RS_SINGLE_MAX): the whole selection in ONE launch (Z is a few tens of
-// KB and L2-resident; five ~5 us launches become one ~10 us launch).  Same arithmetic, fixed reduction order.
+// ---- ONE workgroup, ONE launch for M <= RS_SMALL_MAX (BASELINE configs C2 / C3: M = 1e4): Z is read from memory
+// ONCE, its order-preserving keys stay in LDS (4 M bytes, up to 128 KB of the CU's 160 KB) and the three radix passes
+// and the tail sum run out of LDS -- a pass costs a few hundred cycles instead of a memory round trip, and there is no
+// launch boundary between passes.  The second stage of the sample mean (sum_partials) rides along in extra workgroups of
+// the same launch.  Same arithmetic as the multi-launch form: exact selection, fixed-order fp64 sums.
+// Measured per call, host issue excluded (tools/stats_time.py, hipGraph replay): see DESIGN.md 4.5.
+// (A single-launch form for larger M -- histogram workgroups + an atomic ticket, the last workgroup finishing alone --
+//  was built and measured at 25-108 us for M = 1e4-1e5 against 20 us for six launches: one CU needs 11-23 us of issue
+//  time for 1e5 elements, and constraint values cluster in 4 key bins per binade, so almost nothing is filtered by the
+//  first pass.  Removed; git history has it.)
 constexpr int RS1_T = 1024;
-// Measured per call (tools/stats_time.py): one workgroup 15 / 19 / 24 / 36 us at M = 1e3 / 4e3 / 1e4 / 1.6e4 against
-// ~25 us for the six launches at any M <= 1e5 (launch-bound); and 8 us instead of 46 us of HOST issue time.  (Wave-level
-// aggregation of the LDS histogram updates was tried and bought nothing: the cost is passes and barriers, not conflicts.)
-constexpr long RS_SINGLE_MAX = 1 << 13;
+constexpr long RS_SMALL_MAX = 1 << 15;
 
-__device__ __forceinline__ double block_sum_1024(double v, double* red) {
-  v = rato::wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double s = 0;
-  for (int w = 0; w < RS1_T / RATO_WAVE; ++w) s += red[w];   // fixed order, every thread computes the same
-  return s;
-}
-
-__global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, long M, double alpha, unsigned k,
-                                                   int var_is_max, float thr, double* __restrict__ out) {
+__global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
+                                                  int var_is_max, float thr, double* __restrict__ out,
+                                                  const float* __restrict__ part, int nblocks, int ncols,
+                                                  double scale, double* __restrict__ sums_out) {
+  if (blockIdx.x > 0) {   // the sample-mean second stage rides along (independent workgroups)
+    sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
+    return;
+  }
+  extern __shared__ unsigned keys[];                     // [M]
   __shared__ unsigned h[B1];
-  __shared__ double red[RS1_T / RATO_WAVE];
+  __shared__ double red[6][RS1_T / RATO_WAVE];
   const int tid = threadIdx.x;
+  const int n = (int)M;
   for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
   __syncthreads();
   double sum = 0.0, cnt = 0.0;
   float mx = -INFINITY;
-  for (long i = tid; i < M; i += RS1_T) {
-    const float z = Z[i];
-    atomicAdd(&h[key_of(z) >> 21], 1u);
-    sum += (double)z;
-    cnt += (z <= thr) ? 1.0 : 0.0;
-    mx = fmaxf(mx, z);
+  for (int i0 = tid; i0 < n; i0 += 8 * RS1_T) {          // 8 loads in flight per thread
+    float z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * RS1_T;
+      z[u] = (i < n) ? Z[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * RS1_T;
+      if (i < n) {
+        const unsigned key = key_of(z[u]);
+        keys[i] = key;
+        atomicAdd(&h[key >> 21], 1u);
+        sum += (double)z[u];
+        cnt += (z[u] <= thr) ? 1.0 : 0.0;
+        mx = fmaxf(mx, z[u]);
+      }
+    }
   }
   __syncthreads();
   unsigned b1, k1, b2, k2, b3, k3;
   find_bin<B1, RS1_T>(h, k, b1, k1);
   for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
   __syncthreads();
-  for (long i = tid; i < M; i += RS1_T) {
-    const unsigned key = key_of(Z[i]);
+  for (int i = tid; i < n; i += RS1_T) {
+    const unsigned key = keys[i];
     if ((key >> 21) == b1) atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u);
   }
   __syncthreads();
@@ -342,32 +363,40 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
   for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
   __syncthreads();
   const unsigned prefix = (b1 << 11) | b2;
-  for (long i = tid; i < M; i += RS1_T) {
-    const unsigned key = key_of(Z[i]);
+  for (int i = tid; i < n; i += RS1_T) {
+    const unsigned key = keys[i];
     if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
   }
   __syncthreads();
   find_bin<B3, RS1_T>(h, k2, b3, k3);
-  const float t = value_of((b1 << 21) | (b2 << 10) | b3);
+  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
+  const float t = value_of(tkey);
   double tail = 0.0, ngt = 0.0, neq = 0.0;
-  for (long i = tid; i < M; i += RS1_T) {
-    const float z = Z[i];
-    tail += (z > t) ? ((double)z - (double)t) : 0.0;
-    ngt += (z > t) ? 1.0 : 0.0;
-    neq += (z == t) ? 1.0 : 0.0;
+  for (int i = tid; i < n; i += RS1_T) {
+    const unsigned key = keys[i];
+    const float z = value_of(key);
+    tail += (key > tkey) ? ((double)z - (double)t) : 0.0;
+    ngt += (key > tkey) ? 1.0 : 0.0;
+    neq += (key == tkey) ? 1.0 : 0.0;
   }
-  const double S = block_sum_1024(sum, red);
-  const double C = block_sum_1024(cnt, red);
-  const double T = block_sum_1024(tail, red);
-  const double NG = block_sum_1024(ngt, red);
-  const double NE = block_sum_1024(neq, red);
+  // one barrier for all six block reductions (fixed order: wave tree, then waves 0..15 in order)
+  sum = rato::wave_sum(sum);
+  cnt = rato::wave_sum(cnt);
+  tail = rato::wave_sum(tail);
+  ngt = rato::wave_sum(ngt);
+  neq = rato::wave_sum(neq);
   mx = rato::wave_max(mx);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = (double)mx;
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    red[0][w] = sum; red[1][w] = cnt; red[2][w] = tail; red[3][w] = ngt; red[4][w] = neq; red[5][w] = (double)mx;
+  }
   __syncthreads();
   if (tid == 0) {
-    double m = -INFINITY;
-    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) m = fmax(m, red[w]);
+    double S = 0, C = 0, T = 0, NG = 0, NE = 0, m = -INFINITY;
+    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) {
+      S += red[0][w]; C += red[1][w]; T += red[2][w]; NG += red[3][w]; NE += red[4][w];
+      m = fmax(m, red[5][w]);
+    }
     out[0] = var_is_max ? m : (double)t;
     out[1] = (double)t + (T / (double)M) / alpha;
     out[2] = C / (double)M;
@@ -379,208 +408,6 @@ __global__ __launch_bounds__(RS1_T) void rs_single(const float* __restrict__ Z, 
     out[8] = NG;
     out[9] = NE;
     out[10] = (double)t;
-  }
-}
-
-
-// ---- ONE launch for 8192 < M <= RS_FUSED_MAX (the BASELINE configs C2-C4 and the metric's M = 1e5), optionally with
-// the second stage of the sample mean riding along in extra workgroups (what used to be rs_zero + 3 passes + tail +
-// final + sum_partials = 7 launches, ~25-35 us of launch-bound time per step, as long as a whole linearize kernel at
-// M = 1e4).
-//   stage 1, g_hist workgroups: LDS histogram of the top 11 key bits of a slice of Z, flushed with RETURNING integer
-//            atomics into ws->fhist; every wave waits for its atomics, the workgroup takes a ticket (one returning
-//            atomic).  No spinning anywhere: a workgroup that is not last simply exits.
-//   stage 2, the workgroup whose ticket is last: reads AND re-zeroes ws->fhist with atomic exchanges (the same
-//            coherence point as the adds: no cache has to be trusted), finds the bin b1 of the wanted rank, then makes
-//            ONE pass over Z (16-byte loads): sum, count(Z <= thr), max, the part of the tail that lies in bins above
-//            b1 (accumulated against the lower edge of bin b1 + 1, all terms >= 0), and the keys of bin b1 compacted
-//            into LDS (wave-aggregated append).  The remaining 21 key bits are selected inside LDS (2 histogram passes
-//            over the candidates only).  The candidates' share of the tail is EXACT integer arithmetic: inside a bin
-//            the exponent is fixed, so z = v0 + low21 * ulp and sum_{z > t}(z - t) = ulp * (sum low21 - n * low21(t)).
-//            If bin b1 holds more than RSF_CAP keys (heavily tied / clustered data) the same steps re-read Z instead.
-// Deterministic: integer atomics commute, every floating-point sum has a fixed order.
-constexpr long RS_FUSED_MAX = 1 << 17;
-constexpr int RSF_CAP = 10240;
-
-__device__ __forceinline__ double block_max_1024(double v, double* red) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, RATO_WAVE));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double m = -INFINITY;
-  for (int w = 0; w < RS1_T / RATO_WAVE; ++w) m = fmax(m, red[w]);
-  return m;
-}
-
-__global__ __launch_bounds__(RS1_T) void rs_fused(const float* __restrict__ Z, long M, double alpha, unsigned k,
-                                                  int var_is_max, float thr, Workspace* __restrict__ ws,
-                                                  double* __restrict__ out, int g_hist,
-                                                  const float* __restrict__ part, int nblocks, int ncols,
-                                                  double scale, double* __restrict__ sums_out) {
-  if ((int)blockIdx.x >= g_hist) {   // the sample-mean second stage rides along (independent workgroups)
-    sum_partials_block(blockIdx.x - g_hist, part, nblocks, ncols, scale, sums_out);
-    return;
-  }
-  __shared__ unsigned h[B1];
-  __shared__ unsigned cand[RSF_CAP];
-  __shared__ double red[RS1_T / RATO_WAVE];
-  __shared__ unsigned sh[2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (ws->magic != RS_MAGIC) {       // workspace never initialised (rato_risk_stats_init): fail loudly, touch nothing
-    if (blockIdx.x == 0 && tid < 11) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
-    return;
-  }
-  // ---- stage 1
-  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  for (long i = (long)blockIdx.x * RS1_T + tid; i < M; i += (long)g_hist * RS1_T) atomicAdd(&h[key_of(Z[i]) >> 21], 1u);
-  __syncthreads();
-  unsigned keep = 0;
-  for (int i = tid; i < B1; i += RS1_T) {
-    const unsigned c = h[i];
-    if (c) keep += __hip_atomic_fetch_add(&ws->fhist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::"v"(keep) : "memory");   // this wave's adds have been performed (values returned)
-  __syncthreads();
-  if (tid == 0) sh[0] = __hip_atomic_fetch_add(&ws->fticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (sh[0] != (unsigned)(g_hist - 1)) return;
-  // ---- stage 2: this workgroup's ticket is the last one: every other workgroup's adds precede it
-  for (int i = tid; i < B1; i += RS1_T)
-    h[i] = __hip_atomic_exchange(&ws->fhist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 0) {
-    __hip_atomic_exchange(&ws->fticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh[1] = 0;                         // candidate cursor
-  }
-  __syncthreads();
-  unsigned b1, k1, b2, k2, b3, k3;
-  find_bin<B1, RS1_T>(h, k, b1, k1);
-  const double r_hi = (b1 + 1 < (unsigned)B1) ? (double)value_of((b1 + 1) << 21) : 0.0;   // lower edge of bin b1 + 1
-  double sum = 0.0, s_hi = 0.0;
-  unsigned cnt_le = 0, n_hi = 0;
-  float mx = -INFINITY;
-  auto visit = [&](float z, bool live) {
-    const unsigned key = key_of(z), bin = key >> 21;
-    const bool is_c = live && bin == b1;
-    if (live) {
-      sum += (double)z;
-      cnt_le += (z <= thr) ? 1u : 0u;
-      mx = fmaxf(mx, z);
-      if (bin > b1) {
-        s_hi += (double)z - r_hi;
-        ++n_hi;
-      }
-    }
-    const unsigned long long mask = __ballot(is_c);   // wave-aggregated append of the candidates
-    if (mask) {
-      unsigned base = 0;
-      const int leader = __ffsll((long long)mask) - 1;
-      if (lane == leader) base = atomicAdd(&sh[1], (unsigned)__popcll(mask));
-      base = __shfl(base, leader, RATO_WAVE);
-      if (is_c) {
-        const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < (unsigned)RSF_CAP) cand[pos] = key;
-      }
-    }
-  };
-  {
-    // 16-byte loads over the aligned body, scalar head / tail
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(Z);
-    long head = (long)(((16 - (addr & 15)) & 15) >> 2);
-    if (head > M) head = M;
-    const long nvec = (M - head) >> 2;
-    const float4* __restrict__ Zv = reinterpret_cast<const float4*>(Z + head);
-    const long rounds = (nvec + RS1_T - 1) / RS1_T;     // every wave runs the same trip count (ballots inside)
-    for (long rnd = 0; rnd < rounds; rnd += 4) {
-      float4 v[4];
-      bool lv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long i = (rnd + u) * RS1_T + tid;
-        lv[u] = (rnd + u) < rounds && i < nvec;
-        v[u] = lv[u] ? Zv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if ((rnd + u) < rounds) {
-          visit(v[u].x, lv[u]);
-          visit(v[u].y, lv[u]);
-          visit(v[u].z, lv[u]);
-          visit(v[u].w, lv[u]);
-        }
-      }
-    }
-    const long rest0 = head + (nvec << 2);
-    {   // head [0, head) and tail [rest0, M): at most 3 + 3 elements, one round
-      const long i = (tid < head) ? tid : (rest0 + (tid - head));
-      const bool live = i < M && (tid < head || (tid - head) < (M - rest0));
-      visit(live ? Z[i] : 0.f, live);
-    }
-  }
-  __syncthreads();
-  const unsigned ncand = sh[1];
-  const bool in_lds = ncand <= (unsigned)RSF_CAP;
-  auto for_each_cand = [&](auto&& f) {
-    if (in_lds) {
-      for (unsigned i = tid; i < ncand; i += RS1_T) f(cand[i]);
-    } else {
-      for (long i = tid; i < M; i += RS1_T) {
-        const unsigned key = key_of(Z[i]);
-        if ((key >> 21) == b1) f(key);
-      }
-    }
-  };
-  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  for_each_cand([&](unsigned key) { atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u); });
-  __syncthreads();
-  find_bin<B2, RS1_T>(h, k1, b2, k2);
-  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  const unsigned prefix = (b1 << 11) | b2;
-  for_each_cand([&](unsigned key) {
-    if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
-  });
-  __syncthreads();
-  find_bin<B3, RS1_T>(h, k2, b3, k3);
-  const unsigned n_eq = h[b3];
-  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
-  const float t = value_of(tkey);
-  // candidates above t: count and exact integer sum of the low 21 key bits
-  unsigned long long low_sum = 0;
-  unsigned c_gt = 0;
-  for_each_cand([&](unsigned key) {
-    if (key > tkey) {
-      low_sum += key & 0x1fffffu;
-      ++c_gt;
-    }
-  });
-  const double S = block_sum_1024(sum, red);
-  const double SH = block_sum_1024(s_hi, red);
-  const double C = block_sum_1024((double)cnt_le, red);
-  const double NH = block_sum_1024((double)n_hi, red);
-  const double CG = block_sum_1024((double)c_gt, red);
-  const double LS = block_sum_1024((double)low_sum, red);     // per-thread sums < 2^53: exact in fp64, so is the total
-  const double MX = block_max_1024((double)mx, red);
-  if (tid == 0) {
-    const double td = (double)t;
-    const double v0 = (double)value_of(b1 << 21);
-    const double ulp = (double)value_of((b1 << 21) | 1u) - v0;   // spacing of the floats inside bin b1 (exact)
-    const double tail_c = ulp * (LS - CG * (double)(tkey & 0x1fffffu));
-    const double tail_h = (NH > 0.0) ? (SH + NH * (r_hi - td)) : 0.0;
-    const double T = tail_c + tail_h;
-    out[0] = var_is_max ? MX : td;
-    out[1] = td + (T / (double)M) / alpha;
-    out[2] = C / (double)M;
-    out[3] = S / (double)M;
-    out[4] = MX;
-    out[5] = C;
-    out[6] = T;
-    out[7] = (double)k;
-    out[8] = NH + CG;
-    out[9] = (double)n_eq;
-    out[10] = td;
   }
 }
 
@@ -692,17 +519,19 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   hipStream_t st = rato::as_stream(stream);
   Workspace* ws = static_cast<Workspace*>(workspace);
   const int sp_blocks = part ? (ncols + SP_COLS - 1) / SP_COLS : 0;
-  if (M <= RS_SINGLE_MAX && !part) {
-    hipLaunchKernelGGL(rs_single, dim3(1), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out);
-    RATO_LAUNCH_CHECK();
-    return RATO_OK;
-  }
-  if (M <= RS_FUSED_MAX) {   // ONE launch: histogram workgroups + (optionally) the partial-sum workgroups
-    int g_hist = (int)((M + 4 * RS1_T - 1) / (4 * RS1_T));
-    if (g_hist > 32) g_hist = 32;
-    if (g_hist < 1) g_hist = 1;
-    hipLaunchKernelGGL(rs_fused, dim3(g_hist + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, ws,
-                       out, g_hist, part, (int)nblocks, (int)ncols, scale, sums_out);
+  // RATO_RS_PATH=multi: diagnostic override (A/B timing of the launch structure; tools/stats_time.py)
+  static const int force_multi = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'm') ? 1 : 0; }();
+  if (M <= RS_SMALL_MAX && !force_multi) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
+    const size_t lds = (size_t)M * sizeof(unsigned);
+    static std::atomic<size_t> lds_attr_set{32 * 1024};
+    if (lds > lds_attr_set.load()) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rs_small),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RS_SMALL_MAX * sizeof(unsigned)));
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
+      lds_attr_set.store(RS_SMALL_MAX * sizeof(unsigned));
+    }
+    hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), lds, st, Z, (long)M, alpha, k, var_is_max, thr, out,
+                       part, (int)nblocks, (int)ncols, scale, sums_out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
@@ -721,12 +550,11 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb), block(RATO_BLOCK);
-  hipLaunchKernelGGL(rs_zero, dim3(4), block, 0, st, ws);
   hipLaunchKernelGGL(rs_pass1, grid, block, 0, st, Z, (long)M, thr, ws);
   hipLaunchKernelGGL(rs_pass2, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_pass3, grid, block, 0, st, Z, (long)M, k, ws);
   hipLaunchKernelGGL(rs_tail, grid, block, 0, st, Z, (long)M, k, ws);
-  hipLaunchKernelGGL(rs_final, dim3(1), dim3(RATO_WAVE), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
+  hipLaunchKernelGGL(rs_final, dim3(1), dim3(RATO_BLOCK), 0, st, (long)M, alpha, k, var_is_max, (int)nb, ws, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

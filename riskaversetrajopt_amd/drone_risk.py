@@ -154,6 +154,11 @@ class Model:
     def _empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
+    def _rows(self, *shape, M):
+        """[..][ld] output rows: the kernels never write the ld - M padding lanes, so they are zeroed once here
+        (whole-buffer consumers such as the non-finite scan then see defined values)."""
+        return self._empty(*shape) if shape[-1] == M else torch.zeros(shape, dtype=torch.float32, device=self.device)
+
     # ---- rollout + constraint values (K1) ----------------------------------
     def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
         """-> (Z [M], xs [S+1][6][M] or None, g [n_obs][S][M] or None): device tensors
@@ -262,8 +267,8 @@ class Model:
             if not factored:
                 raise _lib.RatoError("A22 goes with the factored output (row-parallel kernel)")
             A22 = o["_A22"] if o.get("_A22") is not None else self._empty(S, 2, ld)
-        g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
-        Z = (o["_Z"] if "_Z" in o else self._empty(ld)) if want_Z else None
+        g_up = o["_g_up"] if "_g_up" in o else self._rows(n_obs, S, ld, M=M)
+        Z = (o["_Z"] if "_Z" in o else self._rows(ld, M=M)) if want_Z else None
         part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) \
             else self._empty(nblk, 6 * S + 6)
         p = self._params(M, ld)
@@ -300,8 +305,8 @@ class Model:
         o = out if out is not None else {}
         A22 = o["_A22"] if (o.get("_A22") is not None and o["_A22"].shape[1] == 3) else self._empty(S, 3, ld)
         Wf = o["_W"] if o.get("_W") is not None else self._empty(n_obs, S, 2, ld)
-        g_up = o["_g_up"] if "_g_up" in o else self._empty(n_obs, S, ld)
-        Z = o["_Z"] if o.get("_Z") is not None else self._empty(ld)
+        g_up = o["_g_up"] if "_g_up" in o else self._rows(n_obs, S, ld, M=M)
+        Z = o["_Z"] if o.get("_Z") is not None else self._rows(ld, M=M)
         nblk = (M + 255) // 256
         part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) else self._empty(nblk, 6 * S + 6)
         p = self._params(M, ld)

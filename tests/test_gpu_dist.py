@@ -124,7 +124,7 @@ def test_sharded_step_record_exchange_equals_single_process(tmp_path):
     us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
     r = model.linearize_device(us)
     n = 6 * S + 6
-    np.testing.assert_array_equal(a[n + 10:], r["Z"].double().cpu().numpy())         # Z: same kernel, rank order
+    np.testing.assert_array_equal(a[n + stats.N_STATS:], r["Z"].double().cpu().numpy())         # Z: same kernel, rank order
     st = stats.risk_stats_device(r["Z"], 0.1).cpu().numpy()
-    np.testing.assert_array_equal(a[n:n + 10], st)                                   # exact selection on the same Z
+    np.testing.assert_array_equal(a[n:n + stats.N_STATS], st)                                   # exact selection on the same Z
     np.testing.assert_allclose(a[:n], r["sums"].cpu().numpy(), rtol=1e-6, atol=1e-4)  # fp32 block partials differ
