@@ -13,7 +13,7 @@ def _np_stats(Z32, alpha, thr=1e-6):
                 frac=np.mean(Z32 <= np.float32(thr)), mean=Z.mean(), max=Z.max())
 
 
-@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 1 << 15, (1 << 15) + 1, 123457, 1 << 20])
+@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 20 * 1024, 20 * 1024 + 1, 1 << 15, 123457, 1 << 20])
 @pytest.mark.parametrize("alpha", [0.01, 0.05, 0.3, 1.0])
 def test_risk_stats_exact(M, alpha):
     from riskaversetrajopt_amd import stats
@@ -29,7 +29,7 @@ def test_risk_stats_exact(M, alpha):
     assert st["max"] == ref["max"]
 
 
-@pytest.mark.parametrize("M", [5000, 32768, 100000])       # one workgroup with LDS-resident keys / multi-launch path
+@pytest.mark.parametrize("M", [5000, 20480, 100000])       # one workgroup with LDS-resident keys / multi-launch path
 def test_risk_stats_edge_distributions(M):
     from riskaversetrajopt_amd import stats
     cases = {
@@ -128,7 +128,7 @@ def test_unpack_records_matches_host_layout():
 
 @pytest.mark.parametrize("M", [1000, 10000, 50000, 100000, 300000])
 def test_sums_and_risk_stats_single_launch_equals_the_two_calls(M):
-    """rato_sums_and_risk_stats (ONE launch for M <= 32,768) == rato_sum_partials + rato_risk_stats, bit for bit"""
+    """rato_sums_and_risk_stats (ONE launch for M <= 20,480) == rato_sum_partials + rato_risk_stats, bit for bit"""
     import torch
     from riskaversetrajopt_amd import stats
     rng = np.random.RandomState(M % 97)
@@ -148,7 +148,7 @@ def test_uninitialised_workspace_fails_loudly():
     import torch
     from riskaversetrajopt_amd import stats, _lib
     lib = _lib.load()
-    M = 50000                                    # the multi-launch path (M > 32,768) is the one that uses the workspace
+    M = 50000                                    # the multi-launch path (M > 20,480) is the one that uses the workspace
     Z = torch.randn(M, device="cuda")
     ws = torch.full((lib.rato_risk_stats_workspace_bytes(M),), 0x5A, dtype=torch.uint8, device="cuda")   # never initialised
     out = stats.risk_stats_device(Z, 0.1, workspace=ws)
