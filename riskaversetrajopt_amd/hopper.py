@@ -133,16 +133,18 @@ class Model:
                   torch.empty((3, Cn), dtype=torch.float32, device=dev))
             self._stage = st
         host, devbuf = st
+        capturing = torch.cuda.is_current_stream_capturing()   # inside a hipGraph capture: no host-side waits
         self._stage_event = getattr(self, "_stage_event", None)
-        if self._stage_event is not None:
+        if self._stage_event is not None and not capturing:
             self._stage_event.synchronize()          # the previous upload has left the pinned buffer
         host[0].copy_(torch.from_numpy(px))
         host[1].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 0])))
         host[2].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 1])))
         devbuf.copy_(host, non_blocking=True)
-        if self._stage_event is None:
-            self._stage_event = torch.cuda.Event()
-        self._stage_event.record()
+        if not capturing:
+            if self._stage_event is None:
+                self._stage_event = torch.cuda.Event()
+            self._stage_event.record()
         pxd, fxd, fzd = devbuf[0], devbuf[1], devbuf[2]
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         Z = e(M) if want_Z else None
