@@ -9,6 +9,8 @@
 // the trajectory is known, and each thread re-rolls the (cheap) trajectory while
 // it propagates CPT columns held in registers.  Axes decouple:
 //   A_t = [[1, dt], [-kp dt/m, 1 - dt (kd + 2 c_d |v_t|)/m]],  B = [0, dt/m]^T.
+#include <stdlib.h>
+
 #include <atomic>
 
 #include "philox.h"
@@ -589,15 +591,19 @@ __host__ __device__ inline size_t rows_lds_floats(int S) {
   return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 4;
 }
 
-// grid = (tiles, row_split): blockIdx.y > 0 only for the tiles of an incomplete last "round" (and for
-// small batches), whose row tasks are dealt out to row_split workgroups that each rebuild the LDS tables.
+// 1-D grid: workgroups [0, n_whole) own one whole tile each; after them every remaining tile is dealt out to `split`
+// workgroups that each rebuild the LDS tables (noise staging + rollout: latency, almost no bandwidth) and take the row
+// tasks congruent to their part (mod split).  Small batches (fewer tiles than workgroup slots) split every tile to
+// fill the chip.  (Large batches CAN split the tiles of the last round into smaller work units to shorten the drain
+// at the end of the launch -- RATO_TAIL_SPLIT / RATO_TAIL_PCT -- but that was measured to cost more than it returns,
+// see the launch code; off by default.)
 // FACT: factored output.  d g[j,t] / d u[s,a] = W[j,t,a] * Phi[t,s,a] with W = -(Q+Q^T)(p_{t+1} - o_j) (the
 // gradient of g wrt position) and Phi = d p_{t+1,a} / d u_{s,a} SHARED by the three obstacles, so the same
 // information is S(S-1) + 6S numbers per sample instead of 3S(S-1): 2.67x less HBM traffic at S = 50, for
 // this kernel and for every consumer that reads the Jacobian (rowmax / tail-rows oracle, CSC emission).
 template <bool FACT>
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
-    rato_drone_params P, int tile_base, const float* __restrict__ us, const float* __restrict__ dW,
+    rato_drone_params P, int n_whole, int split, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
     float* __restrict__ part) {
@@ -616,8 +622,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   float* UZ = reinterpret_cast<float*>(US + S);                     // [S]
   int* head = reinterpret_cast<int*>(UZ + S);                       // [0] task queue, [1..2] rollout progress x, y
 
-  const int tile = tile_base + blockIdx.x;
-  const int part_id = blockIdx.y, row_split = gridDim.y;
+  const int bid = blockIdx.x;
+  const bool whole = bid < n_whole;
+  const int tile = whole ? bid : n_whole + (bid - n_whole) / split;
+  const int part_id = whole ? 0 : (bid - n_whole) % split, row_split = whole ? 1 : split;
 #if RATO_DIAG == 4
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
 #endif
@@ -1006,18 +1014,37 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
     if (per_cu < 1) per_cu = 1;
     const int slots = cus * per_cu;
     const int n_tiles = (p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
-    int split = 1;
-    if (n_tiles < slots) {
+    const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;   // keep >= 4 row tasks per workgroup
+    int split = 1, n_whole = n_tiles;
+    if (n_tiles < slots) {   // small batch: every tile split so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us)
       split = slots / n_tiles;
-      if (split > (p->S + 3) / 4) split = (p->S + 3) / 4;  // keep >= 4 tasks per workgroup
+      if (split > max_split) split = max_split;
       if (split < 1) split = 1;
+      n_whole = split > 1 ? 0 : n_tiles;
+    } else {                 // large batch: the last round's tiles as quarter-size work units (shorter drain)
+      // Measured (tools/tail_sweep.sh, M = 1e5, S = 50, same box, alternating): split 1 / 2 / 4 / 8 over the last round
+      // = 0.557-0.583 / 0.565-0.597 / 0.582-0.607 / 0.625-0.633 ms (products) and 0.237 / 0.231-0.238 / 0.261-0.268 /
+      // 0.342-0.348 ms (factored): every extra work unit spends ~15-25 us staging and rolling out in one of only 512
+      // LDS-limited slots, which costs more slot time than the shorter drain returns.  Off by default; the knobs stay
+      // for A/B runs.
+      static const int tail_split = [] { const char* e = getenv("RATO_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
+      static const int tail_pct = [] { const char* e = getenv("RATO_TAIL_PCT"); return e ? atoi(e) : 100; }();
+      split = tail_split > max_split ? max_split : tail_split;
+      if (split > 1) {
+        long tail_tiles = (long)slots * tail_pct / 100;
+        if (tail_tiles > n_tiles) tail_tiles = n_tiles;
+        n_whole = n_tiles - (int)tail_tiles;
+      } else {
+        split = 1;
+      }
     }
+    const int grid = n_whole + (n_tiles - n_whole) * split;
     if (W)
-      hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(n_tiles, split), dim3(ROWS_NW * RATO_WAVE), lds, st,
-                         *p, 0, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+      hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole,
+                         split, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     else
-      hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(n_tiles, split), dim3(ROWS_NW * RATO_WAVE), lds, st,
-                         *p, 0, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+      hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p,
+                         n_whole, split, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

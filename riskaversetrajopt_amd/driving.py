@@ -228,12 +228,18 @@ class Model:
         if self._lib.rato_car_linearize_plan(M, S, C.byref(cpt), C.byref(tile)) < 0:
             raise _lib.RatoError(f"no car linearize variant for cols_per_thread={cols_per_thread}, S={S}")
         cols_per_thread, tile = cpt.value, tile.value
-        G = o["G"] if ("G" in o and o["G"].shape[-1] == tile) else \
-            self._empty(num_tiles(M, tile), max(num_pairs(S), 1), 2, tile)
-        g_up = o.get("g_up") if "g_up" in o else self._empty(S, M)
-        Z = (o.get("Z") if "Z" in o else self._empty(M)) if want_Z else None
-        final_du = o.get("final_du") if "final_du" in o else self._empty(4, n_u * S)
-        final_rhs = o.get("final_rhs") if "final_rhs" in o else self._empty(4)
+        def reuse(key, shape):
+            """a buffer of an earlier call is reused only if it has exactly the shape this launch writes"""
+            t = o.get(key)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t
+            return self._empty(*shape)
+
+        G = reuse("G", (num_tiles(M, tile), max(num_pairs(S), 1), 2, tile))
+        g_up = reuse("g_up", (S, M))
+        Z = reuse("Z", (M,)) if want_Z else None
+        final_du = reuse("final_du", (4, n_u * S))
+        final_rhs = reuse("final_rhs", (4,))
         p = self._params(M)
         _lib.check(self._lib.rato_car_linearize(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),

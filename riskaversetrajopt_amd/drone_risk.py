@@ -258,19 +258,29 @@ class Model:
         o = out if out is not None else {}
         g_shape = (num_tiles(M, tile), max(num_pairs(S), 1), 2, tile) if factored else \
             (num_tiles(M, tile), max(num_pairs(S), 1), 2, n_obs, tile)
-        G = o["G"] if ("G" in o and tuple(o["G"].shape) == g_shape) else self._empty(*g_shape)
+
+        def reuse(key, shape, alloc):
+            """a buffer of an earlier call is reused only if it has exactly the shape this launch writes (``out`` may
+            come from another batch size or S: the kernels would write past a smaller buffer)"""
+            t = o.get(key)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t
+            return alloc()
+
+        G = reuse("G", g_shape, lambda: self._empty(*g_shape))
         Wf = None
         if factored:
-            Wf = o["_W"] if (o.get("_W") is not None and o["_W"].shape[-1] == ld) else self._empty(n_obs, S, 2, ld)
+            Wf = reuse("_W", (n_obs, S, 2, ld), lambda: self._empty(n_obs, S, 2, ld))
         A22 = None
         if want_A22:
             if not factored:
                 raise _lib.RatoError("A22 goes with the factored output (row-parallel kernel)")
-            A22 = o["_A22"] if o.get("_A22") is not None else self._empty(S, 2, ld)
-        g_up = o["_g_up"] if "_g_up" in o else self._rows(n_obs, S, ld, M=M)
-        Z = (o["_Z"] if "_Z" in o else self._rows(ld, M=M)) if want_Z else None
-        part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) \
-            else self._empty(nblk, 6 * S + 6)
+            A22 = reuse("_A22", (S, 2, ld), lambda: self._empty(S, 2, ld))
+        g_up = reuse("_g_up", (n_obs, S, ld), lambda: self._rows(n_obs, S, ld, M=M))
+        Z = reuse("_Z", (ld,), lambda: self._rows(ld, M=M)) if want_Z else None
+        part = reuse("part", (nblk, 6 * S + 6), lambda: self._empty(nblk, 6 * S + 6))
+        if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
+            o = dict(o, sums=None)
         p = self._params(M, ld)
         if events is not None:
             events[0].record()
@@ -303,12 +313,21 @@ class Model:
         ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}
-        A22 = o["_A22"] if (o.get("_A22") is not None and o["_A22"].shape[1] == 3) else self._empty(S, 3, ld)
-        Wf = o["_W"] if o.get("_W") is not None else self._empty(n_obs, S, 2, ld)
-        g_up = o["_g_up"] if "_g_up" in o else self._rows(n_obs, S, ld, M=M)
-        Z = o["_Z"] if o.get("_Z") is not None else self._rows(ld, M=M)
+
+        def reuse(key, shape, alloc):
+            t = o.get(key)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t
+            return alloc()
+
+        A22 = reuse("_A22", (S, 3, ld), lambda: self._empty(S, 3, ld))
+        Wf = reuse("_W", (n_obs, S, 2, ld), lambda: self._empty(n_obs, S, 2, ld))
+        g_up = reuse("_g_up", (n_obs, S, ld), lambda: self._rows(n_obs, S, ld, M=M))
+        Z = reuse("_Z", (ld,), lambda: self._rows(ld, M=M))
         nblk = (M + 255) // 256
-        part = o["part"] if (o.get("part") is not None and o["part"].shape[0] == nblk) else self._empty(nblk, 6 * S + 6)
+        part = reuse("part", (nblk, 6 * S + 6), lambda: self._empty(nblk, 6 * S + 6))
+        if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
+            o = dict(o, sums=None)
         p = self._params(M, ld)
         _lib.check(self._lib.rato_drone_linearize_generators(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(A22), _lib.ptr(Wf),
