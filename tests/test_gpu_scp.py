@@ -73,10 +73,14 @@ def test_drone_scp_iterates_match_oracle_path():
     o, d = _drone(M, S, alpha=0.2)
     ref = scp.run_drone(DroneOracleQP(o), num_scp_iters_max=25, warmup_iters=1)
     out = scp.run_drone(d, num_scp_iters_max=25, warmup_iters=1)
-    assert ref["L2_error"][-1] < 1e-5 and out["L2_error"][-1] < 1e-4          # both converge
-    # converged iterates agree to the fp32 linearization error (stated tolerance 1e-5 on |u| <= 10: 1e-4 abs)
-    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=1e-4)
-    assert abs(out["t_risk"] - ref["t_risk"]) < 1e-4
+    assert ref["L2_error"][-1] < 1e-5 and out["L2_error"][-1] < 1e-5          # both converge
+    # North star: "SCP iterates matching reference to 1e-5".  Converged iterates agree to 1e-5 ABSOLUTE on controls
+    # bounded by u_max = 10 (measured on MI355X, tools/scp_tol.py: 1e-7 .. 6e-7 over the last five iterations for
+    # M = 30 and M = 50; both legs polished).  Along the path the difference is below 1e-6 except at the one iteration
+    # where the CVaR rows are switched on (scp_iter = 2, drone_risk.py:413-417): there the subproblem's optimiser is
+    # ill-conditioned in the linearization and one step differs by up to 1.2e-2 before contracting again.
+    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=1e-5)
+    assert abs(out["t_risk"] - ref["t_risk"]) < 1e-5
     # Monte-Carlo validation on fresh samples through the device path (drone_risk.py:643-725)
     from oracle import drone as od
     from riskaversetrajopt_amd import drone_risk
@@ -94,7 +98,10 @@ def test_driving_scp_iterates_match_oracle_path():
     o, d = _car(M, S, alpha=0.1)
     ref = scp.run_driving(DrivingOracleQP(o), num_scp_iters_max=10)
     out = scp.run_driving(d, num_scp_iters_max=10)
-    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=2e-3)
+    # 1e-5 absolute on controls bounded by u_max = 100 (measured: 6e-8 at the last iteration, <= 1.4e-6 along the
+    # whole path for M = 16; tools/scp_tol.py)
+    np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=1e-5)
+    assert abs(out["t_risk"] - ref["t_risk"]) < 1e-5
     assert np.all(np.isfinite(out["define_s"])) and out["cumulative_s"][-1] > 0
 
 
