@@ -603,7 +603,8 @@ __host__ __device__ inline size_t rows_lds_floats(int S) {
 // this kernel and for every consumer that reads the Jacobian (rowmax / tail-rows oracle, CSC emission).
 template <bool FACT>
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
-    rato_drone_params P, int n_whole, int split, const float* __restrict__ us, const float* __restrict__ dW,
+    rato_drone_params P, int n_whole, int split, int tile_stride, int n_tiles_total, const float* __restrict__ us,
+    const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
     float* __restrict__ part) {
@@ -624,8 +625,13 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 
   const int bid = blockIdx.x;
   const bool whole = bid < n_whole;
-  const int tile = whole ? bid : n_whole + (bid - n_whole) / split;
+  const int tile0 = whole ? bid : n_whole + (bid - n_whole) / split;
   const int part_id = whole ? 0 : (bid - n_whole) % split, row_split = whole ? 1 : split;
+  // tile_stride > 0: a BALANCED grid -- this workgroup runs tiles tile0, tile0 + stride, ... one after the other, so
+  // that every workgroup of the launch does the same number of tiles and all of them finish together (no last round
+  // of a few workgroups running one more tile alone)
+  for (int tile = tile0; tile < n_tiles_total; tile += (tile_stride > 0 ? tile_stride : n_tiles_total)) {
+  if (tile != tile0) __syncthreads();   // the previous tile's tables are dead
 #if RATO_DIAG == 4
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
 #endif
@@ -866,7 +872,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
   }
 #endif
+  }  // tile loop
 }
+
+#include "drone_rows_persistent.h"
 
 bool params_ok(const rato_drone_params* p) {
   return p && p->M > 0 && p->ld >= p->M && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
@@ -1014,6 +1023,39 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
     if (per_cu < 1) per_cu = 1;
     const int slots = cus * per_cu;
     const int n_tiles = (p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
+    // Resident workgroups with double-buffered tables (drone_rows_persistent.h): built to hide the staging + rollout of
+    // every tile behind the previous tile's sweeps; measured SLOWER than one tile per workgroup on every box (M = 1e5,
+    // S = 50, alternating: products 0.559-0.608 -> 0.569-0.617 ms, factored 0.224-0.255 -> 0.246-0.269 ms; balanced
+    // grids of 224 / 196 workgroups no better) -- profiles/r02_ab_rows.txt.  Off by default, kept for A/B runs and
+    // covered by a bit-identity test against the default kernel (RATO_ROWS_PERSISTENT=1).
+    static const int persistent = [] { const char* e = getenv("RATO_ROWS_PERSISTENT"); return e ? atoi(e) : 0; }();
+    const size_t lds_p = rowsp_lds_floats(p->S) * sizeof(float);
+    if (persistent && lds_p <= ROWS_LDS_MAX && n_tiles >= 2 * cus) {
+      static std::atomic<size_t> lds_attr_set_p{64 * 1024};
+      if (lds_p > lds_attr_set_p.load()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_persistent_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_persistent_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        if (e != hipSuccess) return RATO_EHIP - (int)e;
+        lds_attr_set_p.store(lds_p);
+      }
+      // balanced grid: every workgroup gets the same number of tiles (the last one possibly one fewer), so that all
+      // of them finish together instead of a few running one more tile alone
+      static const int g_env = [] { const char* e = getenv("RATO_ROWS_G"); return e ? atoi(e) : 0; }();
+      const int per_wg = (n_tiles + cus - 1) / cus;
+      int gp = g_env > 0 ? g_env : (n_tiles + per_wg - 1) / per_wg;
+      if (gp > cus) gp = cus;
+      if (W)
+        hipLaunchKernelGGL(drone_linearize_rows_persistent_kernel<true>, dim3(gp), dim3(PR_NW * RATO_WAVE), lds_p, st, *p,
+                           n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+      else
+        hipLaunchKernelGGL(drone_linearize_rows_persistent_kernel<false>, dim3(gp), dim3(PR_NW * RATO_WAVE), lds_p, st,
+                           *p, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+      RATO_LAUNCH_CHECK();
+      return RATO_OK;
+    }
     const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;   // keep >= 4 row tasks per workgroup
     int split = 1, n_whole = n_tiles;
     if (n_tiles < slots) {   // small batch: every tile split so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us)
@@ -1038,13 +1080,29 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         split = 1;
       }
     }
-    const int grid = n_whole + (n_tiles - n_whole) * split;
+    int grid = n_whole + (n_tiles - n_whole) * split, stride = 0;
+    // Balanced grid.  One tile per workgroup leaves n_tiles mod slots tiles for a last, almost empty round: M = 1e5 is
+    // 1563 tiles on 512 slots = 3 rounds + 27 tiles that run one more tile time nearly alone (~35 us of a 0.58 ms
+    // launch; splitting those tiles was measured to cost more, see above).  With ceil(n_tiles / rounds) workgroups
+    // that each loop over `rounds` tiles every workgroup finishes at the same time: 391 x 4 tiles at M = 1e5.
+    // Measured (tools/ab_rows.sh, same box, alternating, M = 1e5, S = 50): products 0.596 / 0.591 / 0.583 ->
+    // 0.584 / 0.563 / 0.562 ms; factored 0.238 / 0.241 / 0.243 -> 0.267 / 0.260 / 0.259 ms (its tiles are 2.7x
+    // shorter, so the staging + rollout latency of the 121 CUs that hold one workgroup instead of two is exposed).
+    // Hence: products output only, and only when the last round would be less than a quarter full.
+    // RATO_ROWS_BALANCED = 0 / 1 forces it off / on (A/B runs).
+    static const int balanced_env = [] { const char* e = getenv("RATO_ROWS_BALANCED"); return e ? atoi(e) : -1; }();
+    const bool auto_bal = !W && (n_tiles % slots) * 4 < slots && n_tiles <= 8 * slots;
+    if ((balanced_env == 1 || (balanced_env < 0 && auto_bal)) && split == 1 && n_tiles > slots) {
+      const int per_wg = (n_tiles + slots - 1) / slots;
+      grid = (n_tiles + per_wg - 1) / per_wg;   // <= slots: every workgroup is resident from the start
+      stride = grid;
+    }
     if (W)
       hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole,
-                         split, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+                         split, stride, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     else
       hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p,
-                         n_whole, split, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+                         n_whole, split, stride, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

@@ -1,0 +1,56 @@
+"""GPU: the launch-structure variants of the drone row kernel are the SAME arithmetic: balanced grid (several tiles per
+workgroup, default for the products output at M = 1e5) and the persistent double-buffered kernel (off by default)
+must reproduce the one-tile-per-workgroup kernel bit for bit.  The variant is chosen by an environment variable
+that the library reads once, hence one subprocess per variant."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from riskaversetrajopt_amd import drone_risk, drone_utils
+from riskaversetrajopt_amd.drone_risk import untile
+S, M = %(S)d, %(M)d
+dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(M, S, seed=3)
+d = drone_risk.Model.from_device(S, dW, mass, Qsym, 'saa', 0.1, M=M)
+t = np.arange(S)[:, None]
+us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+out = {}
+for fact in (False, True):
+    r = d.linearize_device(us, factored=fact)
+    G = untile(r["G"], M)
+    out["G%%d" %% fact] = np.frombuffer(G.cpu().numpy().tobytes(), dtype=np.uint8)[::97].copy()   # strided byte sample
+    out["Gsum%%d" %% fact] = G.double().sum().item()
+    out["gup%%d" %% fact] = r["g_up"].cpu().numpy()
+    out["Z%%d" %% fact] = r["Z"].cpu().numpy()
+    out["part%%d" %% fact] = r["part"].cpu().numpy()
+np.savez(%(path)r, **out)
+'''
+
+
+def run_variant(tmp_path, name, env, S, M):
+    path = str(tmp_path / (name + ".npz"))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, S=S, M=M, path=path)], env=e,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return np.load(path)
+
+
+@pytest.mark.parametrize("S,M", [(50, 100000), (20, 70000)])
+def test_launch_structure_variants_are_bit_identical(tmp_path, S, M):
+    base = run_variant(tmp_path, "base", {"RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0"}, S, M)
+    for name, env in (("balanced", {"RATO_ROWS_BALANCED": "1", "RATO_ROWS_PERSISTENT": "0"}),
+                      ("persistent", {"RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "1"}),
+                      ("default", {})):
+        v = run_variant(tmp_path, name, env, S, M)
+        for k in base.files:
+            assert np.array_equal(base[k], v[k]), (name, k)
