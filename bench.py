@@ -56,6 +56,10 @@ def parse():
                          "3S(S-1) numbers per sample (SURVEY 8d; this is what `value` and `roofline` are quoted on); "
                          "factored = W[j,t,a] * Phi[t,s,a], S(S-1)+6S numbers (reported as *_factored); both = one "
                          "timed region each, same samples")
+    ap.add_argument("--philox", action="store_true",
+                    help="--mode eval (drone, driving): no noise array in HBM, the Brownian increments are regenerated "
+                         "inside the rollout kernel (Philox4x32-10, rato_*_eval_philox); the algorithmic bytes drop from "
+                         "12 + 56/S (8 + 28/S) to 56/S (28/S) per sample-step")
     ap.add_argument("--no-scp", action="store_true", help="skip the SCP wall-clock block (drone, N=1)")
     ap.add_argument("--scp-iters", type=int, default=60)
     ap.add_argument("--dry-run", action="store_true", help="rank start-up + barrier only (no GPU work)")
@@ -99,8 +103,11 @@ class DroneWork:
         self.mode = args.mode
         self.cpt, self.spl = args.cols_per_thread, args.samples_per_lane
         self.fact = False if args.packed_products else (True if getattr(args, "force_factored", False) else None)
-        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
-        self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M)
+        self.philox = bool(getattr(args, "philox", False)) and args.mode == "eval"
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device,
+                                                                        want_dW=not self.philox)
+        self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M,
+                                                  noise_seed=seed if self.philox else None)
         self.us = self.model._us_device(graze_us(self.S, 3))
         self.out = None
         if self.mode == "linearize":
@@ -123,7 +130,7 @@ class DroneWork:
                 o["_Z"], o["sums"] = rec.Z_row[:ld], rec.sums
                 self.records.append(rec)
         else:
-            self.kernel = "drone_eval_kernel"
+            self.kernel = "drone_eval_kernel<philox>" if self.philox else "drone_eval_kernel"
 
     def hot_kernel(self, events=None, slot=0, reduce=True):
         """One pass; ``events`` bracket ONLY the dominant kernel's launch.  ``reduce=False``: the partial sums stay
@@ -148,7 +155,7 @@ class DroneWork:
         M, S = self.M, self.S
         eval_in = M * B * (3 * S + 1 + 9 + 1) + 3 * S * B          # dW, mass, Qsym, Z | us
         if self.mode == "eval":
-            return eval_in
+            return eval_in - (M * B * 3 * S if self.philox else 0)
         nblk = (M + 255) // 256
         # Jacobian as written: products (3S(S-1) numbers per sample) or its two factors
         # Phi[t,s,a] (S(S-1)) and W[j,t,a] (6S) -- the bytes the launch really has to move
@@ -185,8 +192,11 @@ class DrivingWork:
         self.M = args.M or 100000
         self.mode = args.mode
         self.cpt = args.cols_per_thread
-        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device)
-        self.model = driving.Model.from_device(self.S, dW, x0, ws, wr, 'saa', args.alpha)
+        self.philox = bool(getattr(args, "philox", False)) and args.mode == "eval"
+        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device,
+                                                                    want_dW=not self.philox)
+        self.model = driving.Model.from_device(self.S, dW, x0, ws, wr, 'saa', args.alpha,
+                                               noise_seed=seed if self.philox else None)
         self.us = self.model._us_device(graze_us(self.S, 2))
         self.out = None
         if self.mode == "linearize":
@@ -203,7 +213,7 @@ class DrivingWork:
             self.variant = "cols_per_thread=%d" % r["cols_per_thread"]
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
-            self.kernel = "car_eval_kernel"
+            self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_kernel"
 
     def hot_kernel(self, events=None, slot=0):
         if events is not None:
@@ -224,7 +234,7 @@ class DrivingWork:
         M, S = self.M, self.S
         eval_in = M * B * (2 * S + 6 + 1) + 2 * S * B
         if self.mode == "eval":
-            return eval_in
+            return eval_in - (M * B * 2 * S if self.philox else 0)
         return eval_in + M * B * (S + S * (S - 1))
 
     def cpu_baseline(self, n, alpha):
