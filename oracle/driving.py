@@ -3,7 +3,7 @@ NumPy fp64.
 
 Restates, vectorised over the sample axis, the arithmetic of
 ``/root/reference/car/driving.py`` (+ ``driving_params.py``).
-PARITY UNPINNED — see ``oracle/__init__.py``.
+Pinned by executing the reference's own text — see ``oracle/__init__.py``.
 
 The control-Jacobian (reference: ``jax.jacfwd``, driving.py:267-276) is the
 analytic forward-sensitivity recursion X_{t+1} = J_t X_t + B_t with the full

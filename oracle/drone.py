@@ -2,7 +2,7 @@
 
 Restates, vectorised over the sample axis, the arithmetic of
 ``/root/reference/drone/drone_risk.py`` (+ ``drone_params.py``,
-``drone_utils.py``).  PARITY UNPINNED — see ``oracle/__init__.py``.
+``drone_utils.py``).  Pinned by executing the reference's own text — see ``oracle/__init__.py``.
 
 The reference differentiates with ``jax.jacfwd`` (drone_risk.py:255-258); here
 the control-Jacobian is the analytic forward-sensitivity recursion of the same

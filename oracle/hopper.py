@@ -5,7 +5,7 @@ Restates the sample-dependent part of ``/root/reference/hopper/hopper.py``:
 the random-Fourier friction field (:68-81), the slip-risk rows (:300-367), the
 slices of the IPOPT Jacobian / Lagrangian-Hessian that depend on the samples
 (reference: ``jacrev(g)`` :569, ``hessian(lambda.g)`` :577-580) and the
-Monte-Carlo check (:901-925).  PARITY UNPINNED — see ``oracle/__init__.py``.
+Monte-Carlo check (:901-925).  Pinned by executing the reference's own text — see ``oracle/__init__.py``.
 The sample-independent NLP rows (RK4 defects, contact equalities, bounds) are
 out of scope.
 """

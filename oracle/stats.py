@@ -1,6 +1,6 @@
 """Oracle (test infrastructure) — Monte-Carlo risk statistics, NumPy fp64.
 
-PARITY UNPINNED — see ``oracle/__init__.py``.
+Pinned by executing the reference's own text — see ``oracle/__init__.py``.
 """
 import numpy as np
 
