@@ -4,7 +4,7 @@ linearization baseline, ``/root/reference/drone/drone_gaussian.py:135-227`` (Num
 Only used for BASELINE config C1 ("plumbing": M=100, S=30, CPU only): the recursion is checked
 against the sample moments of SAA rollouts.  The baseline itself (IPOPT NLP with risk-allocation
 variables, :238-535) has no sample axis and is out of scope.
-PARITY UNPINNED — see oracle/__init__.py.
+Pinned by executing the reference's own text (tests/golden/ref_gaussian_S30.npz, tests/test_reference_pin.py).
 """
 import numpy as np
 
@@ -25,8 +25,14 @@ def mean_trajectory(us_mat, S):
     return xs
 
 
-def covariance_trajectory(us_mat, S, mass_variance=MASS_VARIANCE):
-    """drone_gaussian.py:176-227:  Sig+ = A Sig A^T + dt sigma sigma^T + var_m b_dm b_dm^T."""
+def covariance_trajectory(us_mat, S, mass_variance=MASS_VARIANCE, outer_product=False):
+    """drone_gaussian.py:176-227:  Sig+ = A Sig A^T + dt sigma sigma^T + var_m * (b_dm @ b_dm.T).
+
+    Reference quirk, reproduced by default (found by executing the reference's text): ``b_dm = dt * jacfwd(b, mass)``
+    is a 1-D array of shape (6,), so ``b_dm @ b_dm.T`` (:207) is the INNER product — a scalar — and
+    ``Sig_next += Sigma_due_to_mass`` (:212) adds that scalar to ALL 36 entries of the covariance.
+    ``outer_product=True`` gives the rank-one term b_dm b_dm^T the comment at :190-191 describes (used only for
+    the sample-moment sanity check of config C1)."""
     dt, m = od.T / S, od.mass_nom
     xs = mean_trajectory(us_mat, S)
     Sig = np.zeros((S + 1, od.n_x, od.n_x))
@@ -42,5 +48,6 @@ def covariance_trajectory(us_mat, S, mass_variance=MASS_VARIANCE):
         Sigma_w = dt * sig @ sig.T                                           # :203-204
         b_dm = np.zeros(6)
         b_dm[3:] = dt * (-(us_mat[t] + od.FEEDBACK_GAIN @ x) / m**2 + od.drag_coefficient * np.abs(v) * v / m**2)
-        Sig[t + 1] = A @ Sig[t] @ A.T + Sigma_w + mass_variance * np.outer(b_dm, b_dm)   # :206-213
+        mass_term = np.outer(b_dm, b_dm) if outer_product else float(b_dm @ b_dm)          # :207 (see docstring)
+        Sig[t + 1] = A @ Sig[t] @ A.T + Sigma_w + mass_variance * mass_term               # :206-213
     return Sig

@@ -3,7 +3,8 @@
  * drone SAA inner loop of /root/reference/drone/drone_risk.py, one sample per loop iteration,
  * OpenMP over the sample axis.  Used (i) to cross-check the NumPy oracle and (ii) as the
  * multi-core CPU baseline of bench.py ("port": the reference's own JAX/XLA-CPU path cannot be
- * installed here).  PARITY UNPINNED by the reference (no tests / golden vectors there).
+ * installed here).  Checked against the NumPy oracle (tests/test_oracle_c.py), which is pinned by executing the
+ * reference's own text (oracle/__init__.py).
  *
  * Outputs use the reference's dense shapes (C order):
  *   xs          (M, S+1, 6)     us_to_state_trajectories        drone_risk.py:139-162

@@ -167,11 +167,26 @@ def vmap(fn):
 
 
 def _wrt0(transform):
-    def outer(fn):
-        def run(x, *rest):
-            return transform(lambda z: fn(z, *rest))(_t(x))
+    def outer(fn, argnums=0):
+        def run(*args):
+            args = list(args)
+            x = _t(args[argnums])
+
+            def only(z):
+                a = list(args)
+                a[argnums] = z
+                return fn(*a)
+            return transform(only)(x)
         return run
     return outer
+
+
+def fori_loop(lower, upper, body, init):
+    """jax.lax.fori_loop: a plain loop (the carried arrays are immutable, so this is the same computation)."""
+    val = init
+    for i in range(lower, upper):
+        val = body(i, val)
+    return val
 
 
 jacfwd = _wrt0(torch.func.jacfwd)
@@ -202,6 +217,9 @@ def install():
     jstats.norm = scipy.stats.norm
     jscipy.stats = jstats
     jax.scipy = jscipy
+    lax = types.ModuleType("jax.lax")
+    lax.fori_loop = fori_loop
+    jax.lax = lax
     sys.modules.update({"jax": jax, "jax.numpy": jax.numpy, "jax.config": cfg_mod, "jax.scipy": jscipy,
-                        "jax.scipy.stats": jstats})
+                        "jax.scipy.stats": jstats, "jax.lax": lax})
     return jax

@@ -1,9 +1,8 @@
 """Generates the golden fixtures under tests/golden/ from the fp64 oracle.
 
-The reference ships no golden vectors and cannot be imported here (jax / osqp /
-ipyopt absent, no network) — so these vectors come from ``oracle/`` (PARITY
-UNPINNED, see oracle/__init__.py), which is itself pinned against independent
-autodiff and finite differences by tests/test_oracle_*.py.  Inputs replay the
+Regression vectors of the oracle itself (``oracle/`` is pinned by executing the
+reference's own text: make_reference_golden.py -> ref_*.npz, tests/test_reference_pin.py;
+and checked against independent autodiff and finite differences by tests/test_oracle_*.py).  Inputs replay the
 reference's RNG draw order (np.random.RandomState(seed)).
 
     python tests/golden/make_golden.py

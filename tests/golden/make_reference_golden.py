@@ -296,21 +296,45 @@ def make_hopper(jax, S, M, alpha=0.2):
     np.savez_compressed(os.path.join(HERE, f"ref_hopper_S{S}_M{M}.npz"), **out)
 
 
-CASES = {"drone": ((20, 16), (50, 8)), "driving": ((20, 16), (40, 8)), "hopper": ((30, 30), (60, 24))}
+# ---------------------------------------------------------------- drone, Gaussian-linearization baseline (config C1)
+def make_gaussian(jax, S, M_unused, alpha=0.1):
+    """drone_gaussian.py:161-227: the mean trajectory and the covariance recursion (no sample axis)."""
+    jnp = jax.numpy
+    sys.path.insert(0, os.path.join(REF, "drone"))
+    drone_params = importlib.import_module("drone_params")
+    drone_utils = importlib.import_module("drone_utils")
+    ns = base_namespace(jax)
+    ns.update(drone_params=drone_params, fori_loop=jax.lax.fori_loop,
+              p_th_quantile_cdf_normal=drone_utils.p_th_quantile_cdf_normal)
+    load_reference(os.path.join(REF, "drone", "drone_gaussian.py"), ns, overrides={"S": S})
+    model = ns["Model"](S, 'gaussian', alpha)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.25 * np.cos(0.2 * t) + 0.1, 0.05 * np.sin(0.3 * t), 0.02 * np.cos(t)])
+    out = dict(S=S, alpha=alpha, us=us, mass_variance=float(model.mass_variance),
+               xs=npy(model.us_to_state_trajectory(jnp.array(us))),
+               Sigmas=npy(model.us_to_covariance_trajectory(jnp.array(us))),
+               b_dx=npy(model.b_dx(jnp.array(drone_params.x_init) + 0.3, jnp.array(us[3]))),
+               b_dmass=npy(model.b_dmass(jnp.array(drone_params.x_init) + 0.3, jnp.array(us[3]))))
+    np.savez_compressed(os.path.join(HERE, f"ref_gaussian_S{S}.npz"), **out)
+    sys.path.pop(0)
+
+
+CASES = {"drone": ((20, 16), (50, 8)), "driving": ((20, 16), (40, 8)), "hopper": ((30, 30), (60, 24)),
+         "gaussian": ((30, 0),)}
 
 
 def main(which=None):
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not found: this generator only runs in the build container")
     jax = jax_standin.install()
-    makers = {"drone": make_drone, "driving": make_driving, "hopper": make_hopper}
+    makers = {"drone": make_drone, "driving": make_driving, "hopper": make_hopper, "gaussian": make_gaussian}
     for name, mk in makers.items():
         if which and name not in which:
             continue
         for S, M in CASES[name]:
             t0 = time.time()
             mk(jax, S, M)
-            print(f"ref_{name}_S{S}_M{M}.npz  {time.time() - t0:.1f} s", flush=True)
+            print(f"ref_{name}_S{S}" + (f"_M{M}" if M else "") + f".npz  {time.time() - t0:.1f} s", flush=True)
 
 
 if __name__ == "__main__":

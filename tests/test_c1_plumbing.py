@@ -49,6 +49,7 @@ def test_gaussian_recursion_matches_sample_moments():
     # C1-sized batch: same check at M = 100 with the looser statistical tolerance
     emp100 = np.cov(xs[:M, -1, :].T)
     assert np.all(np.diag(emp100) < 2.0 * np.diag(Sig[-1])) and np.all(np.diag(emp100) > 0.5 * np.diag(Sig[-1]))
-    # with the mass term the propagated variance can only grow
-    Sig_m = og.covariance_trajectory(us, S)
-    assert np.all(np.diag(Sig_m[-1]) >= np.diag(Sig[-1]) - 1e-15)
+    # with the mass term the propagated variance can only grow (rank-one form and the reference's scalar form alike)
+    for outer in (True, False):
+        Sig_m = og.covariance_trajectory(us, S, outer_product=outer)
+        assert np.all(np.diag(Sig_m[-1]) >= np.diag(Sig[-1]) - 1e-15)

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from oracle import drone as od, driving as ocar, hopper as oh, stats as ostats
+from oracle import drone as od, driving as ocar, gaussian as og, hopper as oh, stats as ostats
 from _oracle_qp import DroneOracleQP, DrivingOracleQP
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -218,3 +218,17 @@ def test_hopper_oracle_matches_reference_execution(name):
             H[fzcol, ia] += D1[c] * Jee[c, a_]
     Href = csc(f, "H").toarray()
     np.testing.assert_allclose(H, Href, rtol=1e-9, atol=1e-11 * np.abs(Href).max())
+
+
+# --------------------------------------------------- drone, Gaussian-linearization recursion (BASELINE config C1)
+def test_gaussian_recursion_matches_reference_execution():
+    """drone_gaussian.py:161-227 executed: mean trajectory and covariance recursion, including the reference's
+    ``b_dm @ b_dm.T`` on a 1-D array (an inner product: the mass term is a SCALAR added to every entry)."""
+    f = np.load(os.path.join(G, "ref_gaussian_S30.npz"))
+    S, us = int(f["S"]), f["us"]
+    assert float(f["mass_variance"]) == og.MASS_VARIANCE
+    np.testing.assert_allclose(og.mean_trajectory(us, S), f["xs"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(og.covariance_trajectory(us, S), f["Sigmas"], rtol=1e-11, atol=1e-16)
+    assert f["b_dmass"].shape == (6,)                                  # 1-D: hence the inner product
+    rank_one = og.covariance_trajectory(us, S, outer_product=True)
+    assert np.abs(rank_one - f["Sigmas"]).max() > 0.1 * np.abs(f["Sigmas"]).max()      # the two forms really differ
