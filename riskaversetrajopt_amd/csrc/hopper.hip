@@ -32,7 +32,7 @@ typedef float hfloat2 __attribute__((ext_vector_type(2)));
 // reduced per wave with DPP into an LDS table and combined once per workgroup at the end (no barrier per
 // contact); lambda for a contact is fetched before that contact's trig block so that its latency is covered.
 template <bool DERIV>
-__global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
+__global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     int M_, int C, int cpg, const float* __restrict__ px, const float* __restrict__ fx,
     const float* __restrict__ fz, const float* __restrict__ a, const float* __restrict__ theta,
     const float* __restrict__ tau, const float* __restrict__ lam, float* __restrict__ Z, int z_atomic,
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
   hfloat2 fa[NP], rth[NP], rtau[NP];   // amplitude | theta / 2 pi | tau / 2 pi
-  hfloat2 ath[DERIV ? NP : 1], ath2[DERIV ? NP : 1];   // a theta | a theta^2
+
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     hfloat2 th, ta;
@@ -58,10 +58,6 @@ __global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
     ta.y = tau[(size_t)(2 * k + 1) * M + m];
     rth[k] = th * INV_2PI;
     rtau[k] = ta * INV_2PI;
-    if (DERIV) {
-      ath[k] = fa[k] * th;
-      ath2[k] = ath[k] * th;
-    }
   }
   const int c0 = blockIdx.y * cpg;
   const int c1 = min(C, c0 + cpg);
@@ -83,14 +79,25 @@ __global__ __launch_bounds__(RATO_BLOCK) void hopper_slip_kernel(
       hfloat2 cs;
       cs.x = __builtin_amdgcn_cosf(r.x);
       cs.y = __builtin_amdgcn_cosf(r.y);
-      s0 += fa[k] * cs;
-      if (DERIV) {
+      if (!DERIV) {
+        s0 += fa[k] * cs;
+      } else {
+        // a theta and a theta^2 are NOT kept in registers (60 VGPRs: 194-202 -> 2 waves per SIMD).  Every product
+        // starts from a trig value, so nothing is loop invariant and nothing can be hoisted back into registers:
+        //   u = a cos,  s0 += u,  s2 += (u r) r;   v = a sin,  s1 += v r      (r = theta / 2 pi; the factors 2 pi and
+        //   (2 pi)^2 are applied once per contact to the sums): 7 packed ops per feature pair instead of 4.
         hfloat2 sn;
         sn.x = __builtin_amdgcn_sinf(r.x);
         sn.y = __builtin_amdgcn_sinf(r.y);
-        s1 += ath[k] * sn;
-        s2 += ath2[k] * cs;
+        const hfloat2 u = fa[k] * cs;
+        s0 += u;
+        s2 += (u * rth[k]) * rth[k];
+        s1 += (fa[k] * sn) * rth[k];
       }
+    }
+    if (DERIV) {
+      s1 *= 6.28318530717958647692f;
+      s2 *= 39.4784176043574344753f;
     }
     const float mu = MU_NOM + (s0.x + s0.y);
     const float hv = f_x - mu * f_z;  // hopper.py:322
