@@ -69,7 +69,8 @@ int rato_abi_version(void);
 
 /* Constants of drone_params.py:1-45 / Model.__init__ drone_risk.py:71-93. */
 typedef struct rato_drone_params {
-  int32_t M;            /* samples in this shard */
+  int32_t M;            /* samples in this shard (< 2^31: one GPU holds ~2e7 drone samples at S = 50; every offset
+                           derived from it is computed in 64 bits) */
   int32_t ld;           /* row stride (floats) of every [..][M] array, ld >= M; a multiple
                            of samples_per_lane (use a multiple of 4) */
   int32_t S;            /* control intervals; dt = T/S (drone_risk.py:82) */
@@ -244,6 +245,9 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
  * tile-blocked Jacobian of the linearize calls (tile = its TILE, n_g = 2,
  * R = 3 drone / 1 driving).  scale = the reference's MULTIPLIER (0.01 drone, 1
  * driving), times 1e-7 while scp_iter < 2 (drone_risk.py:413-415).
+ * The transposition is staged through 64 (R (S-1) + 1) floats of LDS: RATO_EINVAL when that exceeds 160 KB
+ * (S > 213 for the drone, S > 639 for driving) -- the facades then assemble on the host from the untiled Jacobian
+ * (Model.get_constraints_coeffs_host), same pattern and values.
  */
 int rato_emit_csc_values(const float* G, const float* W /* NULL, or the factor of a factored G */,
                          int64_t ld /* row stride of W */, int32_t tile, int32_t n_g, int32_t R, int32_t S,

@@ -319,7 +319,7 @@ class Model:
             fast = assemble.FastAssembler(A0, l0, u0, n_c=4, n_u=n_u, n_g=2, R=1, S=self.S, M=self.M,
                                           saa=self.method == 'saa')
             self._fast = fast
-        if not fast.ok or self.S < 2:
+        if not fast.ok or self.S < 2 or 64 * (1 * (self.S - 1) + 1) * 4 > 160 * 1024:   # rato_emit_csc_values' LDS limit
             return self._assemble(us_mat, None)
         r = self.linearize_device(us_mat)
         M, S = r["M"], self.S

@@ -481,7 +481,7 @@ class Model:
             saa = self.method == 'saa'
             fast = assemble.FastAssembler(A0, l0, u0, n_c=n_x, n_u=n_u, n_g=2, R=n_obs, S=self.S, M=self.M, saa=saa)
             self._fast = fast
-        if not fast.ok or self.S < 2:
+        if not fast.ok or self.S < 2 or 64 * (n_obs * (self.S - 1) + 1) * 4 > 160 * 1024:   # rato_emit_csc_values' LDS limit
             return self._assemble(us_mat, relax)
         r = self.linearize_device(us_mat)
         M, S = r["M"], self.S
