@@ -582,6 +582,10 @@ constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// tile queues of the row-parallel kernel's dynamic form: {next tile, workgroups gone}; zero at load, every launch
+// leaves its queue zeroed again
+__device__ unsigned g_tile_queues[64 * 2];
+
 #ifndef RATO_DIAG
 #define RATO_DIAG 0  // diagnostic builds only (tools/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores,
 #endif               // 4 = timeline: part[tile][0..7] <- wall_clock64 at block start / after phase 0 / after phase 1 / end
@@ -603,8 +607,8 @@ __host__ __device__ inline size_t rows_lds_floats(int S) {
 // this kernel and for every consumer that reads the Jacobian (rowmax / tail-rows oracle, CSC emission).
 template <bool FACT>
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
-    rato_drone_params P, int n_whole, int split, int tile_stride, int n_tiles_total, const float* __restrict__ us,
-    const float* __restrict__ dW,
+    rato_drone_params P, int n_whole, int split, int tile_stride, int n_tiles_total, unsigned* __restrict__ tile_queue,
+    const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
     float* __restrict__ part) {
@@ -627,11 +631,16 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   const bool whole = bid < n_whole;
   const int tile0 = whole ? bid : n_whole + (bid - n_whole) / split;
   const int part_id = whole ? 0 : (bid - n_whole) % split, row_split = whole ? 1 : split;
-  // tile_stride > 0: a BALANCED grid -- this workgroup runs tiles tile0, tile0 + stride, ... one after the other, so
-  // that every workgroup of the launch does the same number of tiles and all of them finish together (no last round
-  // of a few workgroups running one more tile alone)
-  for (int tile = tile0; tile < n_tiles_total; tile += (tile_stride > 0 ? tile_stride : n_tiles_total)) {
-  if (tile != tile0) __syncthreads();   // the previous tile's tables are dead
+  // Several tiles per workgroup (large batches):
+  //   tile_queue != NULL  DYNAMIC: the grid fills every workgroup slot once; a workgroup that has finished a tile
+  //                       takes the next one from a global counter (one returning atomic per tile).  Workgroups on
+  //                       XCDs / CUs that happen to run faster simply take more tiles, so the whole chip finishes
+  //                       together (with one tile per workgroup the hardware deals the grid out to the XCDs up front
+  //                       and four of them sat idle for the last ~13 % of the launch: DESIGN.md 4.1).
+  //   tile_stride > 0     static: tiles tile0, tile0 + stride, ... (A/B only)
+  int* next_tile = head + 3;   // LDS word: the tile thread 0 has fetched for this workgroup
+  for (int tile = tile0; tile < n_tiles_total;) {
+  if (tile != tile0 && !tile_queue) __syncthreads();   // the previous tile's tables are dead (dynamic: synced below)
 #if RATO_DIAG == 4
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
 #endif
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   {
     float* PPf = reinterpret_cast<float*>(PP);
     const int nrows = 3 * S;
-    constexpr int MAXR = 20;  // rows per wave per batch: S = 50 needs 150/8 = 19 -> one batch, all loads in flight
+    constexpr int MAXR = (160 + ROWS_NW - 1) / ROWS_NW;  // rows per wave per batch: S = 50 needs 150 / 8 = 19 -> one batch, all loads in flight
     for (int r0 = wave; r0 < nrows; r0 += ROWS_NW * MAXR) {
       float tmp[MAXR];
 #pragma unroll
@@ -872,7 +881,28 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
   }
 #endif
+  // ---- next tile
+  if (tile_queue) {
+    __syncthreads();   // every wave has finished this tile's rows: the tables are dead, head[] may be rewritten
+    if (threadIdx.x == 0)
+      next_tile[0] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    tile = next_tile[0];
+  } else if (tile_stride > 0) {
+    tile += tile_stride;
+  } else {
+    break;
+  }
   }  // tile loop
+  if (tile_queue && threadIdx.x == 0) {
+    // the queue cleans up after itself: the workgroup that leaves last (its own final fetch came back empty, like
+    // everybody's before it) resets both words for the next launch
+    const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1) {
+      __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 #include "drone_rows_persistent.h"
@@ -1081,28 +1111,41 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
       }
     }
     int grid = n_whole + (n_tiles - n_whole) * split, stride = 0;
-    // Balanced grid.  One tile per workgroup leaves n_tiles mod slots tiles for a last, almost empty round: M = 1e5 is
-    // 1563 tiles on 512 slots = 3 rounds + 27 tiles that run one more tile time nearly alone (~35 us of a 0.58 ms
-    // launch; splitting those tiles was measured to cost more, see above).  With ceil(n_tiles / rounds) workgroups
-    // that each loop over `rounds` tiles every workgroup finishes at the same time: 391 x 4 tiles at M = 1e5.
-    // Measured (tools/ab_rows.sh, same box, alternating, M = 1e5, S = 50): products 0.596 / 0.591 / 0.583 ->
-    // 0.584 / 0.563 / 0.562 ms; factored 0.238 / 0.241 / 0.243 -> 0.267 / 0.260 / 0.259 ms (its tiles are 2.7x
-    // shorter, so the staging + rollout latency of the 121 CUs that hold one workgroup instead of two is exposed).
-    // Hence: products output only, and only when the last round would be less than a quarter full.
-    // RATO_ROWS_BALANCED = 0 / 1 forces it off / on (A/B runs).
-    static const int balanced_env = [] { const char* e = getenv("RATO_ROWS_BALANCED"); return e ? atoi(e) : -1; }();
-    const bool auto_bal = !W && (n_tiles % slots) * 4 < slots && n_tiles <= 8 * slots;
-    if ((balanced_env == 1 || (balanced_env < 0 && auto_bal)) && split == 1 && n_tiles > slots) {
-      const int per_wg = (n_tiles + slots - 1) / slots;
-      grid = (n_tiles + per_wg - 1) / per_wg;   // <= slots: every workgroup is resident from the start
-      stride = grid;
+    unsigned* queue = nullptr;
+    // Large batches: a grid that fills every slot once + a global tile counter (see the kernel).  Why: with one tile
+    // per workgroup the timeline (tools/timeline.py, -DRATO_DIAG=4, M = 1e5) shows the workgroups with an even block
+    // index -- every other XCD -- running their tiles in 145-151 us and the odd ones in 174-176 us, the hardware
+    // having dealt the grid out to the XCDs in advance: the fast half of the chip is done at 500-518 us and idles
+    // until the slow half finishes at 585-590 us.  RATO_ROWS_DYNAMIC=0 switches it off (A/B);
+    // RATO_ROWS_BALANCED=1 selects the static several-tiles-per-workgroup form instead (391 x 4 at M = 1e5), which
+    // only removes the 27-tile last round (-3.5 % for the products output, +8 % for the factored one).
+    static const int dynamic_env = [] { const char* e = getenv("RATO_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
+    static const int balanced_env = [] { const char* e = getenv("RATO_ROWS_BALANCED"); return e ? atoi(e) : 0; }();
+    if (split == 1 && n_tiles > slots) {
+      if (balanced_env == 1) {
+        const int per_wg = (n_tiles + slots - 1) / slots;
+        grid = (n_tiles + per_wg - 1) / per_wg;   // <= slots: every workgroup is resident from the start
+        stride = grid;
+      } else if (dynamic_env) {
+        // 64 two-word queues in device memory, handed out round robin: launches that overlap on different streams get
+        // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
+        static unsigned* queues = nullptr;
+        static std::atomic<unsigned> next_queue{0};
+        if (!queues) {
+          void* sym = nullptr;
+          if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) != hipSuccess) return RATO_EHIP;
+          queues = static_cast<unsigned*>(sym);
+        }
+        queue = queues + 2 * (next_queue.fetch_add(1) % 64);
+        grid = slots;
+      }
     }
     if (W)
       hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole,
-                         split, stride, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+                         split, stride, n_tiles, queue, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     else
       hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p,
-                         n_whole, split, stride, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+                         n_whole, split, stride, n_tiles, queue, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

@@ -1,6 +1,6 @@
-"""GPU: the launch-structure variants of the drone row kernel compute the same thing.  The balanced grid (several
-tiles per workgroup, default for the products output at M = 1e5) is the SAME kernel code and must reproduce the
-one-tile-per-workgroup launch bit for bit; the persistent double-buffered kernel (off by default, kept for A/B runs) is
+"""GPU: the launch-structure variants of the drone row kernel compute the same thing.  The dynamic tile queue (the
+default for large batches) and the static balanced grid are the SAME kernel code and must reproduce the
+one-tile-per-workgroup launch bit for bit, whatever order the tiles are taken in; the persistent double-buffered kernel (off by default, kept for A/B runs) is
 separate code, where the compiler contracts multiply-adds differently: equal to a few fp32 ulps.  The variant is
 chosen by an environment variable that the library reads once, hence one subprocess per variant."""
 import os
@@ -48,9 +48,11 @@ def run_variant(tmp_path, name, env, S, M):
 
 @pytest.mark.parametrize("S,M", [(50, 100000), (20, 70000)])
 def test_launch_structure_variants_are_bit_identical(tmp_path, S, M):
-    base = run_variant(tmp_path, "base", {"RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0"}, S, M)
-    for name, env in (("balanced", {"RATO_ROWS_BALANCED": "1", "RATO_ROWS_PERSISTENT": "0"}),
-                      ("persistent", {"RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "1"}),
+    off = {"RATO_ROWS_DYNAMIC": "0", "RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0"}
+    base = run_variant(tmp_path, "base", off, S, M)                                  # one tile per workgroup
+    for name, env in (("dynamic", dict(off, RATO_ROWS_DYNAMIC="1")),                 # global tile queue (the default)
+                      ("balanced", dict(off, RATO_ROWS_BALANCED="1")),               # static several tiles per workgroup
+                      ("persistent", dict(off, RATO_ROWS_PERSISTENT="1")),           # double-buffered (A/B only)
                       ("default", {})):
         v = run_variant(tmp_path, name, env, S, M)
         for k in base.files:

@@ -1,5 +1,5 @@
 """Block timeline of drone_linearize_rows_kernel from a -DRATO_DIAG=4 build (load it with RATO_SAA_LIB=...).
-usage: python tools/timeline.py [M] [S]"""
+usage: python tools/timeline.py [M] [S] [products|factored]"""
 import sys, numpy as np, torch, faulthandler
 faulthandler.dump_traceback_later(60, exit=True)
 sys.path.insert(0, '.')
@@ -11,9 +11,10 @@ dW, mass, Q = drone_utils.sample_uncertain_parameters_device(M, S, seed=7, devic
 d = drone_risk.Model.from_device(S, dW, mass, Q, 'saa', 0.1, M=M)
 t = np.arange(S)[:, None]
 us = d._us_device(np.hstack([0.6*np.cos(0.3*t)+0.3, 0.15*np.sin(0.5*t)+0.02, 0.05*np.cos(t)])*(20/S))
-r = d.linearize_device(us)
+fact = not (len(sys.argv) > 3 and sys.argv[3] == "products")
+r = d.linearize_device(us, factored=fact)
 for _ in range(3):
-    r = d.linearize_device(us, out=r)
+    r = d.linearize_device(us, out=r, factored=fact)
 torch.cuda.synchronize()
 raw = r["part"].cpu().numpy()                       # (nblocks, 6S+6) float32
 tl = np.ascontiguousarray(raw[:, :8]).view(np.uint64).astype(np.float64)   # (nblocks, 4) ticks of 100 MHz
@@ -28,7 +29,13 @@ print("block lifetime    mean %.1f  p10 %.1f p90 %.1f us" % ((end - start).mean(
 print("first phase-2 entry at %.1f us; last block start %.1f us; ends: p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
     p1.min(), start.max(), *np.percentile(end, [50, 90, 99, 100])))
 # concurrency profile: blocks in phase 2 over time
-grid = np.linspace(0, end.max(), 26)
+grid = np.linspace(0, end.max(), 61)
 act = [(int(((p1 <= g) & (end > g)).sum()), int(((start <= g) & (end > g)).sum())) for g in grid]
 print("t(us): in-phase-2 / resident")
 print("  ".join("%.0f:%d/%d" % (g, a, b) for g, (a, b) in zip(grid, act)))
+# per-XCD view (workgroups are dealt round-robin over the 8 XCDs: block b and b + 8 share one)
+nb = len(tl)
+for x in range(8):
+    sel = np.arange(nb) % 8 == x
+    print("blocks = %d mod 8: n %3d  lifetime mean %.1f us  last end %.1f us  last start %.1f us" % (
+        x, sel.sum(), (end - start)[sel].mean(), end[sel].max(), start[sel].max()))
