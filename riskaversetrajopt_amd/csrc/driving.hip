@@ -12,6 +12,8 @@
 //   d g_t / d u_c = -n_{t+1}^T (E_{t+1}[pos, c] - dpp_{t+1})
 // Lane = sample; grid.y = groups of control steps s (both controls of a step
 // share one slot because they share the activity window t > s).
+#include <stdlib.h>
+
 #include <atomic>
 
 #include "philox.h"
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
-    float* __restrict__ Z) {
+    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   const size_t M = (size_t)P.M;
   const int S = P.S;
@@ -399,7 +401,12 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   double* DCS = DV + (S + 1);                                                // fp64 speed | cos | sin of the ego
   double* DSN = DCS + (S + 1);
 
-  const size_t m_raw = (size_t)blockIdx.x * CROWS_SAMPLES + lane;
+  // tile_queue != NULL (large batches): the grid fills every workgroup slot once and a workgroup that has finished a
+  // tile takes the next one from a global counter, so that XCDs that run this store stream faster take more tiles
+  // (see drone_linearize_rows_kernel); the sample-independent ego tables are built once per workgroup.
+  for (int tile = blockIdx.x; tile < n_tiles_total;) {
+  const bool first = tile == (int)blockIdx.x;
+  const size_t m_raw = (size_t)tile * CROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
   const float w_s = w_speed[m], w_r = w_rep[m];
@@ -409,11 +416,13 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // this workgroup WHILE those loads are in flight (they queue behind the chip-wide store stream for ~10 us): the
   // separate one-workgroup ego prologue launch (10-30 us in front of every linearize call) is gone.
   {
-    for (int t = threadIdx.x; t < S; t += NT) {
-      cfloat2_t u2;
-      u2.x = us[t * 2 + 0];
-      u2.y = us[t * 2 + 1];
-      US[t] = u2;
+    if (first) {
+      for (int t = threadIdx.x; t < S; t += NT) {
+        cfloat2_t u2;
+        u2.x = us[t * 2 + 0];
+        u2.y = us[t * 2 + 1];
+        US[t] = u2;
+      }
     }
     if (threadIdx.x == 0) {
       head[0] = 0;
@@ -435,6 +444,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     // sample independent, so this costs a microsecond per workgroup and keeps the 40-step accumulation error of
     // the positions (x ~ 20 m, fp32 ulp 2e-6) out of every sample's distance / normal / Jacobian
     const double dt = P.dt;
+    if (first) {
     for (int t = threadIdx.x; t <= S; t += NT) {
       double v = P.ego_init[2], ph = P.ego_init[3];
       for (int k = 0; k < t; ++k) {
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       e.y = (float)y;
       EGOP[t] = e;
     }
+    }  // first tile: ego tables
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
       const int r = wave + i * CROWS_NW;
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   }
   __syncthreads();
   // final rows (sample independent: driving.py:283-288, :311): workgroup 0 propagates one control column per thread
-  if (blockIdx.x == 0 && (final_du || final_rhs)) {
+  if (tile == 0 && (final_du || final_rhs)) {
     const int NC = 2 * S;
     float rhs_acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = threadIdx.x; c < NC; c += NT) {
@@ -570,7 +581,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   };
   constexpr int RT = CROWS_SAMPLES;
   const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * RT;
-  float* __restrict__ Gt = G + (size_t)blockIdx.x * tile_floats + lane;
+  float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
   auto next_task = [&]() -> int {
     int v = 0;
     if (lane == 0) v = atomicAdd(head, 1);
@@ -631,6 +642,21 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       if (valid) g_up[(size_t)t * M + m] = -gt + acc;        // driving.py:295
     }
     task = next_task();
+  }
+  // ---- next tile
+  if (!tile_queue) break;
+  __syncthreads();   // every wave has finished this tile's rows: the sample tables are dead, head[] may be rewritten
+  if (threadIdx.x == 0)
+    head[2] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  tile = head[2];
+  }  // tile loop
+  if (tile_queue && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
+    const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1) {
+      __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -693,6 +719,7 @@ extern "C" int rato_car_separation_distances(const rato_car_params* p, const flo
 }
 
 namespace {
+__device__ unsigned g_car_tile_queues[64 * 2];   // {next tile, workgroups gone} per queue; every launch leaves its queue zeroed
 constexpr size_t CAR_ROWS_LDS_MAX = 160 * 1024;
 size_t car_rows_lds_bytes(int S) { return car_rows_lds_floats(S) * sizeof(float); }
 }  // namespace
@@ -744,9 +771,37 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
       if (e != hipSuccess) return RATO_EHIP - (int)e;
       lds_attr_set.store(lds);
     }
-    dim3 grid((p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES), block(CROWS_NW * RATO_WAVE);
+    const int n_tiles = (p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES;
+    // large batches: one workgroup per slot + a global tile queue (XCD load balance, see the kernel)
+    static std::atomic<int> cu_count{0};
+    int cus = cu_count.load();
+    if (cus == 0) {
+      int dev = 0;
+      cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      cu_count.store(cus);
+    }
+    int per_cu = (int)(CAR_ROWS_LDS_MAX / lds);
+    if (per_cu > 32 / CROWS_NW) per_cu = 32 / CROWS_NW;
+    if (per_cu < 1) per_cu = 1;
+    const int slots = cus * per_cu;
+    static const int dynamic_env = [] { const char* e = getenv("RATO_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
+    unsigned* queue = nullptr;
+    int grid_x = n_tiles;
+    if (dynamic_env && n_tiles > slots) {
+      static unsigned* queues = nullptr;
+      static std::atomic<unsigned> next_queue{0};
+      if (!queues) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_car_tile_queues)) != hipSuccess) return RATO_EHIP;
+        queues = static_cast<unsigned*>(sym);
+      }
+      queue = queues + 2 * (next_queue.fetch_add(1) % 64);
+      grid_x = slots;
+    }
+    dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);
     hipLaunchKernelGGL(car_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                       final_du, final_rhs, G, g_up, Z);
+                       final_du, final_rhs, G, g_up, Z, n_tiles, queue);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
