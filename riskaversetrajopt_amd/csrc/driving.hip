@@ -375,6 +375,7 @@ __host__ __device__ inline size_t car_rows_lds_floats(int S) {
          (size_t)(S + 1) * 2 + 32 + (size_t)(S + 1) * 6 + 2;
 }
 
+template <bool LOOP>   // LOOP: several tiles per workgroup through the global tile queue (large batches)
 __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel(
     rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
@@ -401,50 +402,34 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   double* DCS = DV + (S + 1);                                                // fp64 speed | cos | sin of the ego
   double* DSN = DCS + (S + 1);
 
-  // tile_queue != NULL (large batches): the grid fills every workgroup slot once and a workgroup that has finished a
-  // tile takes the next one from a global counter, so that XCDs that run this store stream faster take more tiles
-  // (see drone_linearize_rows_kernel); the sample-independent ego tables are built once per workgroup.
-  for (int tile = blockIdx.x; tile < n_tiles_total;) {
-  const bool first = tile == (int)blockIdx.x;
-  const size_t m_raw = (size_t)tile * CROWS_SAMPLES + lane;
-  const bool valid = m_raw < M;
-  const size_t m = valid ? m_raw : M - 1;
-  const float w_s = w_speed[m], w_r = w_rep[m];
-  const float ks = P.dt * w_s;
-
-  // ---- phase 0: controls, then the noise tile requested, then the (sample-independent) ego tables computed by
-  // this workgroup WHILE those loads are in flight (they queue behind the chip-wide store stream for ~10 us): the
-  // separate one-workgroup ego prologue launch (10-30 us in front of every linearize call) is gone.
-  {
-    if (first) {
-      for (int t = threadIdx.x; t < S; t += NT) {
-        cfloat2_t u2;
-        u2.x = us[t * 2 + 0];
-        u2.y = us[t * 2 + 1];
-        US[t] = u2;
-      }
-    }
-    if (threadIdx.x == 0) {
-      head[0] = 0;
-      head[1] = 0;   // rollout progress: number of finished steps
-    }
-  }
-  __syncthreads();
-  {
-    float* QPf = reinterpret_cast<float*>(QP);
-    const int nrows = 2 * S;
-    constexpr int MAXR = 16;
-    float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
+  // ---- once per workgroup: the controls and the (sample-independent) ego tables.  With ONE tile per workgroup
+  // (small batches, latency bound) the noise tile is requested first and the tables are computed while those loads
+  // are in flight; with the tile loop they are requested per tile (keeping 16 more registers live across the fp64 ego
+  // code would cost a workgroup per CU).
+  constexpr int MAXR = 16;
+  const int nrows = 2 * S;
+  float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
+  if (!LOOP) {
+    const size_t mr = (size_t)blockIdx.x * CROWS_SAMPLES + lane;
+    const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
       const int r = wave + i * CROWS_NW;
-      tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
+      tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + mm];
     }
+  }
+  for (int t = threadIdx.x; t < S; t += NT) {
+    cfloat2_t u2;
+    u2.x = us[t * 2 + 0];
+    u2.y = us[t * 2 + 1];
+    US[t] = u2;
+  }
+  __syncthreads();
+  {
     // ego trajectory (driving.py:166-173), one thread per step, folded in fp64 and rounded once: the ego is
     // sample independent, so this costs a microsecond per workgroup and keeps the 40-step accumulation error of
     // the positions (x ~ 20 m, fp32 ulp 2e-6) out of every sample's distance / normal / Jacobian
     const double dt = P.dt;
-    if (first) {
     for (int t = threadIdx.x; t <= S; t += NT) {
       double v = P.ego_init[2], ph = P.ego_init[3];
       for (int k = 0; k < t; ++k) {
@@ -480,7 +465,37 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       e.y = (float)y;
       EGOP[t] = e;
     }
-    }  // first tile: ego tables
+  }
+  __syncthreads();
+
+  // tile_queue != NULL (large batches): the grid fills every workgroup slot once and a workgroup that has finished a
+  // tile takes the next one from a global counter, so that XCDs that run this store stream faster take more tiles
+  // (see drone_linearize_rows_kernel); the sample-independent ego tables are built once per workgroup.
+  for (int tile = blockIdx.x; tile < n_tiles_total;) {
+  const size_t m_raw = (size_t)tile * CROWS_SAMPLES + lane;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;
+  const float w_s = w_speed[m], w_r = w_rep[m];
+  const float ks = P.dt * w_s;
+
+  // ---- phase 0: queue state and the noise tile (the ego tables were built by this workgroup before the loop: the
+  // separate one-workgroup ego prologue launch, 10-30 us in front of every linearize call, is gone)
+  {
+    if (threadIdx.x == 0) {
+      head[0] = 0;
+      head[1] = 0;   // rollout progress: number of finished steps
+    }
+  }
+  __syncthreads();
+  {
+    float* QPf = reinterpret_cast<float*>(QP);
+    if (LOOP) {
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = wave + i * CROWS_NW;
+        tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
       const int r = wave + i * CROWS_NW;
@@ -644,14 +659,14 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     task = next_task();
   }
   // ---- next tile
-  if (!tile_queue) break;
+  if (!LOOP) break;
   __syncthreads();   // every wave has finished this tile's rows: the sample tables are dead, head[] may be rewritten
   if (threadIdx.x == 0)
     head[2] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   tile = head[2];
   }  // tile loop
-  if (tile_queue && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
+  if (LOOP && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == gridDim.x - 1) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -766,8 +781,11 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     const size_t lds = car_rows_lds_bytes(p->S);
     static std::atomic<size_t> lds_attr_set{64 * 1024};   // cached: capture-safe after the first call
     if (lds > lds_attr_set.load()) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
       lds_attr_set.store(lds);
     }
@@ -800,8 +818,12 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
       grid_x = slots;
     }
     dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);
-    hipLaunchKernelGGL(car_linearize_rows_kernel, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                       final_du, final_rhs, G, g_up, Z, n_tiles, queue);
+    if (queue)
+      hipLaunchKernelGGL(car_linearize_rows_kernel<true>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue);
+    else
+      hipLaunchKernelGGL(car_linearize_rows_kernel<false>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
