@@ -20,6 +20,11 @@ namespace {
 
 constexpr int NOBS = RATO_DRONE_NOBS;
 
+// work queues of the dynamic launch forms (row-parallel linearize, eval): {next tile, workgroups gone}; zero at load,
+// every launch leaves its queue zeroed again; 64 of them, handed out round robin (overlapping launches on different
+// streams get different queues)
+__device__ unsigned g_tile_queues[64 * 2];
+
 struct SampleConsts {
   float inv_m, a21, cn, dtm;
   float q00[NOBS], qs[NOBS], q11[NOBS];
@@ -55,12 +60,12 @@ __device__ __forceinline__ void step_axis(const rato_drone_params& P, const Samp
 // read from dW: bit-identical to rato_drone_sample's dW, no 12 B per sample-step of HBM reads, no 3 S floats per
 // sample of HBM capacity.  noise_scale = sqrt(sampler dt) (drone_utils.py:90).
 template <bool PHILOX>
-__global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
-    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW, uint64_t seed,
+__device__ __forceinline__ void drone_eval_block(
+    const rato_drone_params& P, size_t blk, const float* __restrict__ us, const float* __restrict__ dW, uint64_t seed,
     float noise_scale, const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ Z,
     float* __restrict__ xs, float* __restrict__ g) {
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
-  const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const size_t m = blk * RATO_BLOCK + threadIdx.x;
   if (m >= M) return;
   const int S = P.S;
   const SampleConsts c = load_consts(P, mass, Qsym, ld, m);
@@ -119,6 +124,36 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
     }
   }
   if (Z) Z[m] = zmax - P.tol;
+}
+
+// tile_queue != NULL (large batches): 8 workgroups per CU, each taking 256-sample blocks from a global counter until
+// none is left -- the hardware deals a plain grid out to the XCDs up front and every other XCD streams slower (see
+// drone_linearize_rows_kernel), so with one block per workgroup half the chip idles at the end of the launch.
+template <bool PHILOX>
+__global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
+    rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW, uint64_t seed,
+    float noise_scale, const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ Z,
+    float* __restrict__ xs, float* __restrict__ g, unsigned* __restrict__ tile_queue, int nblk) {
+  if (!tile_queue) {
+    drone_eval_block<PHILOX>(P, blockIdx.x, us, dW, seed, noise_scale, mass, Qsym, Z, xs, g);
+    return;
+  }
+  __shared__ int next_blk;
+  for (int blk = blockIdx.x; blk < nblk;) {
+    drone_eval_block<PHILOX>(P, (size_t)blk, us, dW, seed, noise_scale, mass, Qsym, Z, xs, g);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      next_blk = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    blk = next_blk;
+  }
+  if (threadIdx.x == 0) {
+    const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1) {
+      __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -582,9 +617,7 @@ constexpr int ROWS_SAMPLES = 64;  // samples per workgroup (one per lane)
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-// tile queues of the row-parallel kernel's dynamic form: {next tile, workgroups gone}; zero at load, every launch
-// leaves its queue zeroed again
-__device__ unsigned g_tile_queues[64 * 2];
+
 
 #ifndef RATO_DIAG
 #define RATO_DIAG 0  // diagnostic builds only (tools/): 1 = no phase 2, 2 = no phase 1, 3 = phase 2 without G stores,
@@ -907,6 +940,29 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 
 #include "drone_rows_persistent.h"
 
+unsigned* take_tile_queue() {   // address looked up once (outside any capture)
+  static unsigned* queues = nullptr;
+  static std::atomic<unsigned> next_queue{0};
+  if (!queues) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) != hipSuccess) return nullptr;
+    queues = static_cast<unsigned*>(sym);
+  }
+  return queues + 2 * (next_queue.fetch_add(1) % 64);
+}
+
+int device_cus() {
+  static std::atomic<int> cu_count{0};
+  int cus = cu_count.load();
+  if (cus == 0) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cu_count.store(cus);
+  }
+  return cus;
+}
+
 bool params_ok(const rato_drone_params* p) {
   return p && p->M > 0 && p->ld >= p->M && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
 }
@@ -917,9 +973,21 @@ extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, cons
                                const float* Qsym, float* Z, float* xs, float* g, void* stream) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym) return RATO_EINVAL;
-  dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  const int nblk = rato::nblocks_for(p->M);
+  // The block queue buys the READ-bound eval kernel nothing (same box, alternating, M = 1e6 / 1e7: 0.1264-0.1281 /
+  // 1.159-1.168 ms without, 0.1257-0.1276 / 1.153-1.165 ms with): the XCD asymmetry that the row kernels' queue
+  // removes belongs to the store stream.  Off by default (RATO_EVAL_DYNAMIC=1 for A/B runs).
+  static const int eval_dyn = [] { const char* e = getenv("RATO_EVAL_DYNAMIC"); return e ? atoi(e) : 0; }();
+  unsigned* queue = nullptr;
+  int grid_x = nblk;
+  if (eval_dyn && nblk > 4 * 8 * device_cus()) {   // more than four rounds of 8 workgroups per CU
+    queue = take_tile_queue();
+    if (!queue) return RATO_EHIP;
+    grid_x = 8 * device_cus();
+  }
+  dim3 grid(grid_x), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_eval_kernel<false>, grid, block, 0, rato::as_stream(stream), *p, us, dW, (uint64_t)0, 0.0f,
-                     mass, Qsym, Z, xs, g);
+                     mass, Qsym, Z, xs, g, queue, nblk);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
@@ -931,7 +999,7 @@ extern "C" int rato_drone_eval_philox(const rato_drone_params* p, const float* u
   if (!params_ok(p) || !us || !mass || !Qsym || !(sampler_dt >= 0.0f) || p->S > 65535) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_eval_kernel<true>, grid, block, 0, rato::as_stream(stream), *p, us, (const float*)nullptr,
-                     seed, sqrtf(sampler_dt), mass, Qsym, Z, xs, g);
+                     seed, sqrtf(sampler_dt), mass, Qsym, Z, xs, g, (unsigned*)nullptr, 0);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
@@ -1132,14 +1200,8 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         // (RATO_ROWS_DYNAMIC=2 forces the queue for every large batch.)
         // 64 two-word queues in device memory, handed out round robin: launches that overlap on different streams get
         // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
-        static unsigned* queues = nullptr;
-        static std::atomic<unsigned> next_queue{0};
-        if (!queues) {
-          void* sym = nullptr;
-          if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) != hipSuccess) return RATO_EHIP;
-          queues = static_cast<unsigned*>(sym);
-        }
-        queue = queues + 2 * (next_queue.fetch_add(1) % 64);
+        queue = take_tile_queue();
+        if (!queue) return RATO_EHIP;
         grid = slots;
       }
     }
