@@ -13,6 +13,11 @@ t = np.arange(S)[:, None]
 us = d._us_device(np.hstack([0.6*np.cos(0.3*t)+0.3, 0.15*np.sin(0.5*t)+0.02, 0.05*np.cos(t)])*(20/S))
 fact = not (len(sys.argv) > 3 and sys.argv[3] == "products")
 r = d.linearize_device(us, factored=fact)
+shift = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # experiment: G base address shifted by this many bytes
+if shift:
+    big = torch.empty(r["G"].numel() + shift // 4, dtype=torch.float32, device=dev)
+    r = dict(r, G=big[shift // 4:].view(r["G"].shape))
+    print("G base address mod 4096 =", r["G"].data_ptr() % 4096)
 for _ in range(3):
     r = d.linearize_device(us, out=r, factored=fact)
 torch.cuda.synchronize()
