@@ -21,6 +21,7 @@ import time
 
 import numpy as np
 import scipy.sparse as sp
+import scipy.linalg as sla
 import scipy.sparse.linalg as spla
 
 OSQP_INFTY = 1e30
@@ -68,7 +69,7 @@ class OSQP:
               alpha=1.6, max_iter=4000, scaling=10, adaptive_rho=True, adaptive_rho_interval=50,
               adaptive_rho_tolerance=5.0, polish=False, polish_refine_iter=3, delta=1e-6, warm_start=True,
               verbose=False, linsys_solver=None, eps_prim_inf=1e-4, check_termination=25, polish_retry=True,
-              **_ignored):
+              linsys="auto", **_ignored):
         t0 = time.perf_counter()
         self.n, self.m = P.shape[0], A.shape[0]
         self.P = sp.csc_matrix(P, dtype=np.float64)
@@ -86,7 +87,7 @@ class OSQP:
                          adaptive_rho_tolerance=adaptive_rho_tolerance, polish=polish,
                          polish_refine_iter=polish_refine_iter, delta=delta, warm_start=warm_start,
                          verbose=verbose, eps_prim_inf=eps_prim_inf, check_termination=check_termination,
-                         polish_retry=polish_retry)
+                         polish_retry=polish_retry, linsys=linsys)
         self.rho = float(rho)
         self._scale()
         self._make_rho_vec()
@@ -134,11 +135,47 @@ class OSQP:
         rv[free] = RHO_MIN
         self.rho_vec = rv
 
+    # The SAA QPs are tall: m ~ 3 S M rows against n = n_u S + M + 2 columns (M = 500, S = 20: 30,568 x 562).  The
+    # quasi-definite KKT matrix [[P + sigma I, A'], [A, -R^-1]] that osqp's direct solver (and the first version of this
+    # class) factorises has n + m rows; eliminating nu = R (A x - z) + y leaves the n x n SPD system
+    #     (P + sigma I + A' R A) x = sigma x_k - q + A' (R z_k - y_k)
+    # -- osqp's "indirect" form, solved here with a dense Cholesky factorisation (n is a few hundred to a few thousand).
+    # Same iterates as the KKT form up to rounding (tests/test_qp.py runs both).
+    REDUCED_MAX_N = 6000
+
+    def _use_reduced(self):
+        mode = self.opts.get("linsys", "auto")
+        if mode == "kkt":
+            return False
+        if mode == "reduced":
+            return True
+        return self.m > 2 * self.n and self.n <= self.REDUCED_MAX_N
+
     def _factorize(self):
         n, m = self.n, self.m
+        if self._use_reduced():
+            R = sp.diags(self.rho_vec)
+            H = (self.Ps + (self.As.T @ (R @ self.As))).toarray()
+            H[np.diag_indices(n)] += self.opts["sigma"]
+            self._chol = sla.cho_factor(H, lower=True, overwrite_a=True, check_finite=False)
+            self._lu = None
+            return
         K = sp.bmat([[self.Ps + self.opts["sigma"] * sp.eye(n), self.As.T],
                      [self.As, -sp.diags(1.0 / self.rho_vec)]], format="csc")
         self._lu = spla.splu(K)
+        self._chol = None
+
+    def _kkt_solve(self, xs, zs, ys):
+        """-> (x_tilde, nu) of the ADMM linear system at (xs, zs, ys)."""
+        sigma = self.opts["sigma"]
+        if self._chol is not None:
+            rhs = sigma * xs - self.qs + self.As.T @ (self.rho_vec * zs - ys)
+            xt = sla.cho_solve(self._chol, rhs, check_finite=False)
+            nu = self.rho_vec * (self.As @ xt - zs) + ys
+            return xt, nu
+        rhs = np.concatenate([sigma * xs - self.qs, zs - ys / self.rho_vec])
+        sol = self._lu.solve(rhs)
+        return sol[:self.n], sol[self.n:]
 
     # ----------------------------------------------------------------- update
     def update(self, q=None, l=None, u=None, Px=None, Px_idx=None, Ax=None, Ax_idx=None):
@@ -240,9 +277,7 @@ class OSQP:
         status = "maximum iterations reached"
         it = 0
         for it in range(1, o["max_iter"] + 1):
-            rhs = np.concatenate([sigma * xs - self.qs, zs - ys / self.rho_vec])
-            sol = self._lu.solve(rhs)
-            xt, nu = sol[:n], sol[n:]
+            xt, nu = self._kkt_solve(xs, zs, ys)
             zt = zs + (nu - ys) / self.rho_vec
             x_new = alpha * xt + (1 - alpha) * xs
             z_relax = alpha * zt + (1 - alpha) * zs

@@ -99,3 +99,26 @@ def test_nan_bounds_like_the_reference_relaxation():
     res = s.solve()
     assert res.info.status == 'solved'
     np.testing.assert_allclose(res.x, [0.5, 0.5, 0.0], atol=1e-5)
+
+
+def test_reduced_linear_system_equals_kkt_form():
+    """The n x n SPD form (P + sigma I + A' R A) of the ADMM linear system (used for the tall SAA QPs) gives the same
+    iterates as the (n + m) quasi-definite KKT form osqp's direct solver factorises."""
+    import scipy.sparse as sp
+    from riskaversetrajopt_amd import qp
+    rng = np.random.RandomState(3)
+    n, m = 12, 90
+    Pm = sp.diags(rng.rand(n) + 0.5).tocsc()
+    q = rng.randn(n)
+    A = sp.random(m, n, density=0.3, random_state=rng, format="csc")
+    l, u = -rng.rand(m) - 0.1, rng.rand(m) + 0.1
+    out = {}
+    for mode in ("kkt", "reduced"):
+        s = qp.OSQP()
+        s.setup(Pm, q, A, l, u, eps_abs=1e-6, eps_rel=1e-6, polish=True, linsys=mode)
+        r = s.solve()
+        assert r.info.status == "solved"
+        out[mode] = r
+    np.testing.assert_allclose(out["kkt"].x, out["reduced"].x, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(out["kkt"].y, out["reduced"].y, rtol=1e-6, atol=1e-8)
+    assert out["kkt"].info.iter == out["reduced"].info.iter
