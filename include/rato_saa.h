@@ -14,8 +14,10 @@
  *     e.g. torch.Tensor.data_ptr(); nothing is allocated or freed here.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
  *     are asynchronous and stream-ordered; nothing synchronises the device.
- *   - no global state beyond cached device properties (CU count, LDS attribute): safe to call
- *     concurrently from one host thread per GPU, and — after one ordinary call per kernel
+ *   - no global state beyond cached device properties (CU count, LDS attribute) and, for the row-parallel
+ *     linearize kernels on large batches, one self-cleaning two-word work queue per STREAM in device memory
+ *     (up to 64 streams; launches on one stream are ordered and share it, a 65th stream falls back to the static
+ *     launch): safe to call concurrently from one host thread per GPU, and — after one ordinary call per kernel
  *     variant — inside a hipGraph stream capture (no non-stream runtime call is made).
  *   - return value: 0 ok; RATO_EINVAL bad argument; RATO_EHIP-<hipError_t>
  *     when a launch fails.

@@ -808,13 +808,15 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     int grid_x = n_tiles;
     if (dynamic_env && n_tiles > slots) {
       static unsigned* queues = nullptr;
-      static std::atomic<unsigned> next_queue{0};
       if (!queues) {
         void* sym = nullptr;
         if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_car_tile_queues)) != hipSuccess) return RATO_EHIP;
         queues = static_cast<unsigned*>(sym);
       }
-      queue = queues + 2 * (next_queue.fetch_add(1) % 64);
+      const int slot = rato::tile_queue_slot(st);      // one queue per stream; none left: static form
+      if (slot >= 0) queue = queues + 2 * slot;
+    }
+    if (queue) {
       grid_x = slots;
     }
     dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);

@@ -21,8 +21,7 @@ namespace {
 constexpr int NOBS = RATO_DRONE_NOBS;
 
 // work queues of the dynamic launch forms (row-parallel linearize, eval): {next tile, workgroups gone}; zero at load,
-// every launch leaves its queue zeroed again; 64 of them, handed out round robin (overlapping launches on different
-// streams get different queues)
+// every launch leaves its queue zeroed again; 64 of them, one per stream (rato::tile_queue_slot)
 __device__ unsigned g_tile_queues[64 * 2];
 
 struct SampleConsts {
@@ -940,15 +939,15 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 
 #include "drone_rows_persistent.h"
 
-unsigned* take_tile_queue() {   // address looked up once (outside any capture)
+unsigned* take_tile_queue(hipStream_t stream) {   // this stream's queue (NULL: none left); address looked up once
   static unsigned* queues = nullptr;
-  static std::atomic<unsigned> next_queue{0};
   if (!queues) {
     void* sym = nullptr;
     if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) != hipSuccess) return nullptr;
     queues = static_cast<unsigned*>(sym);
   }
-  return queues + 2 * (next_queue.fetch_add(1) % 64);
+  const int slot = rato::tile_queue_slot(stream);
+  return slot < 0 ? nullptr : queues + 2 * slot;
 }
 
 int device_cus() {
@@ -981,9 +980,8 @@ extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, cons
   unsigned* queue = nullptr;
   int grid_x = nblk;
   if (eval_dyn && nblk > 4 * 8 * device_cus()) {   // more than four rounds of 8 workgroups per CU
-    queue = take_tile_queue();
-    if (!queue) return RATO_EHIP;
-    grid_x = 8 * device_cus();
+    queue = take_tile_queue(rato::as_stream(stream));
+    if (queue) grid_x = 8 * device_cus();
   }
   dim3 grid(grid_x), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_eval_kernel<false>, grid, block, 0, rato::as_stream(stream), *p, us, dW, (uint64_t)0, 0.0f,
@@ -1200,9 +1198,8 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         // (RATO_ROWS_DYNAMIC=2 forces the queue for every large batch.)
         // 64 two-word queues in device memory, handed out round robin: launches that overlap on different streams get
         // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
-        queue = take_tile_queue();
-        if (!queue) return RATO_EHIP;
-        grid = slots;
+        queue = take_tile_queue(st);
+        if (queue) grid = slots;
       }
     }
     if (W)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "rato_saa.h"
 
 #define RATO_BLOCK 256           // 4 waves per workgroup (== RATO_TILE of rato_saa.h)
@@ -64,5 +66,21 @@ __host__ __device__ __forceinline__ int pair_row_offset(int t) { return (t * (t 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int nblocks_for(int32_t M) { return (M + RATO_BLOCK - 1) / RATO_BLOCK; }
+
+// Work queues of the dynamic launch forms (row-parallel linearize kernels): each queue is two device words
+// {next tile, workgroups gone}, zero at load, and every launch leaves its queue zeroed.  A queue is bound to a STREAM:
+// launches on one stream are ordered and may share it, launches on different streams never share one.  Up to 64 streams
+// get a queue; a 65th stream gets none (-1) and its launches use the static form.
+static inline int tile_queue_slot(hipStream_t stream) {
+  static std::mutex mu;
+  static hipStream_t owner[64];
+  static int used = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < used; ++i)
+    if (owner[i] == stream) return i;
+  if (used == 64) return -1;
+  owner[used] = stream;
+  return used++;
+}
 
 }  // namespace rato
