@@ -660,19 +660,21 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   int* head = reinterpret_cast<int*>(UZ + S);                       // [0] task queue, [1..2] rollout progress x, y
 
   const int bid = blockIdx.x;
-  const bool whole = bid < n_whole;
-  const int tile0 = whole ? bid : n_whole + (bid - n_whole) / split;
-  const int part_id = whole ? 0 : (bid - n_whole) % split, row_split = whole ? 1 : split;
-  // Several tiles per workgroup (large batches):
-  //   tile_queue != NULL  DYNAMIC: the grid fills every workgroup slot once; a workgroup that has finished a tile
-  //                       takes the next one from a global counter (one returning atomic per tile).  Workgroups on
-  //                       XCDs / CUs that happen to run faster simply take more tiles, so the whole chip finishes
+  // A work UNIT is a whole tile (units [0, n_whole)) or one of `split` row-interleaved parts of a tile (the units after
+  // them).  One unit per workgroup (plain grid), or several:
+  //   tile_queue != NULL  DYNAMIC: the grid fills every workgroup slot once; a workgroup that has finished a unit
+  //                       takes the next one from a global counter (one returning atomic per unit).  Workgroups on
+  //                       XCDs / CUs that happen to run faster simply take more units, so the whole chip finishes
   //                       together (with one tile per workgroup the hardware deals the grid out to the XCDs up front
   //                       and four of them sat idle for the last ~13 % of the launch: DESIGN.md 4.1).
-  //   tile_stride > 0     static: tiles tile0, tile0 + stride, ... (A/B only)
-  int* next_tile = head + 3;   // LDS word: the tile thread 0 has fetched for this workgroup
-  for (int tile = tile0; tile < n_tiles_total;) {
-  if (tile != tile0 && !tile_queue) __syncthreads();   // the previous tile's tables are dead (dynamic: synced below)
+  //   tile_stride > 0     static: units bid, bid + stride, ... (A/B only)
+  const int n_units = n_whole + (n_tiles_total - n_whole) * split;
+  int* next_tile = head + 3;   // LDS word: the unit thread 0 has fetched for this workgroup
+  for (int unit = bid; unit < n_units;) {
+  const bool whole = unit < n_whole;
+  const int tile = whole ? unit : n_whole + (unit - n_whole) / split;
+  const int part_id = whole ? 0 : (unit - n_whole) % split, row_split = whole ? 1 : split;
+  if (unit != bid && !tile_queue) __syncthreads();   // the previous tile's tables are dead (dynamic: synced below)
 #if RATO_DIAG == 4
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
 #endif
@@ -919,9 +921,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     if (threadIdx.x == 0)
       next_tile[0] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    tile = next_tile[0];
+    unit = next_tile[0];
   } else if (tile_stride > 0) {
-    tile += tile_stride;
+    unit += tile_stride;
   } else {
     break;
   }
@@ -1199,7 +1201,25 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         // 64 two-word queues in device memory, handed out round robin: launches that overlap on different streams get
         // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
         queue = take_tile_queue(st);
-        if (queue) grid = slots;
+        if (queue) {
+          grid = slots;
+          // Products output: the LAST slots/2 tiles are handed out as quarter tiles (4 row-interleaved parts each).
+          // The drain at the end of the launch is bounded per workgroup (~19 GB/s each, whatever the residency), so
+          // shorter last units shorten it; the re-staging they cost is paid while the chip is still full.  Same box,
+          // alternating, 100 steps (tools/dyn_tail_sweep.sh): 0.5543-0.5576 -> 0.5415-0.5440 ms (-2.4 %, 0.704-0.708
+          // of 8 TB/s); halves over the last 1024 tiles -1 %; thirds / sixths / eighths no better.  The factored
+          // output loses with any split (its tiles are short already) and keeps whole tiles.
+          // RATO_DYN_TAIL_SPLIT x RATO_DYN_TAIL_TILES override (split 1 = whole tiles only).
+          static const int dts = [] { const char* e = getenv("RATO_DYN_TAIL_SPLIT"); return e ? atoi(e) : 0; }();
+          static const int dtt = [] { const char* e = getenv("RATO_DYN_TAIL_TILES"); return e ? atoi(e) : 0; }();
+          int want_split = dts > 0 ? dts : (W ? 1 : 4);
+          int want_tiles = dtt > 0 ? dtt : slots / 2;
+          if (want_split > max_split) want_split = max_split;
+          if (want_split > 1 && want_tiles > 0) {
+            split = want_split;
+            n_whole = n_tiles - (want_tiles < n_tiles - slots ? want_tiles : n_tiles - slots);
+          }
+        }
       }
     }
     if (W)

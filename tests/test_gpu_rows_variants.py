@@ -48,9 +48,11 @@ def run_variant(tmp_path, name, env, S, M):
 
 @pytest.mark.parametrize("S,M", [(50, 100000), (20, 70000)])
 def test_launch_structure_variants_are_bit_identical(tmp_path, S, M):
-    off = {"RATO_ROWS_DYNAMIC": "0", "RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0"}
+    off = {"RATO_ROWS_DYNAMIC": "0", "RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0", "RATO_DYN_TAIL_SPLIT": "1"}
     base = run_variant(tmp_path, "base", off, S, M)                                  # one tile per workgroup
-    for name, env in (("dynamic", dict(off, RATO_ROWS_DYNAMIC="1")),                 # global tile queue (the default)
+    for name, env in (("dynamic", dict(off, RATO_ROWS_DYNAMIC="1")),                 # global tile queue, whole tiles
+                      ("dynamic_tail", dict(off, RATO_ROWS_DYNAMIC="1", RATO_DYN_TAIL_SPLIT="4")),   # + quarter tiles last
+                      ("dynamic_halves", dict(off, RATO_ROWS_DYNAMIC="2", RATO_DYN_TAIL_SPLIT="2", RATO_DYN_TAIL_TILES="700")),
                       ("balanced", dict(off, RATO_ROWS_BALANCED="1")),               # static several tiles per workgroup
                       ("persistent", dict(off, RATO_ROWS_PERSISTENT="1")),           # double-buffered (A/B only)
                       ("default", {})):
