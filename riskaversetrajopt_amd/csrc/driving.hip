@@ -380,7 +380,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
-    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue) {
+    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   const size_t M = (size_t)P.M;
   const int S = P.S;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   const int nrows = 2 * S;
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
   if (!LOOP) {
-    const size_t mr = (size_t)blockIdx.x * CROWS_SAMPLES + lane;
+    const size_t mr = (size_t)((int)blockIdx.x / split) * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
@@ -471,7 +471,10 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // tile_queue != NULL (large batches): the grid fills every workgroup slot once and a workgroup that has finished a
   // tile takes the next one from a global counter, so that XCDs that run this store stream faster take more tiles
   // (see drone_linearize_rows_kernel); the sample-independent ego tables are built once per workgroup.
-  for (int tile = blockIdx.x; tile < n_tiles_total;) {
+  // split > 1 (small batches, !LOOP): every tile is dealt out to `split` workgroups that each build the tables and take
+  // the row tasks congruent to their part (mod split), so that a batch of a few hundred tiles still fills the chip.
+  const int part_id = LOOP ? 0 : (int)blockIdx.x % split, row_split = LOOP ? 1 : split;
+  for (int tile = LOOP ? (int)blockIdx.x : (int)blockIdx.x / split; tile < n_tiles_total;) {
   const size_t m_raw = (size_t)tile * CROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   }
   __syncthreads();
   // final rows (sample independent: driving.py:283-288, :311): workgroup 0 propagates one control column per thread
-  if (tile == 0 && (final_du || final_rhs)) {
+  if (tile == 0 && part_id == 0 && (final_du || final_rhs)) {
     const int NC = 2 * S;
     float rhs_acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = threadIdx.x; c < NC; c += NT) {
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   auto next_task = [&]() -> int {
     int v = 0;
     if (lane == 0) v = atomicAdd(head, 1);
-    return __builtin_amdgcn_readfirstlane(v);
+    return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
   };
   int task = next_task();
   while (task <= S) {
@@ -819,13 +822,26 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     if (queue) {
       grid_x = slots;
     }
+    // small batches (fewer tiles than workgroup slots): every tile split over several workgroups (>= 4 row tasks each)
+    int split = 1;
+    static const int small_split = [] { const char* e = getenv("RATO_CAR_SMALL_SPLIT"); return e ? atoi(e) : -1; }();
+    if (!queue && n_tiles < slots) {
+      // C3 (M = 1e4: 157 tiles on 768 slots), same box, alternating, kern_ms: split 1 / 2 / 3 / 4 = 0.0302-0.0307 /
+      // 0.0279-0.0282 / 0.0270-0.0271 (one run 0.0411) / 0.0360-0.0361: every part rebuilds the fp64 ego tables and
+      // re-stages the noise tile, so two parts per tile is where it stops paying reliably.
+      split = small_split >= 1 ? small_split : (slots / n_tiles >= 2 ? 2 : 1);
+      const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;
+      if (split > max_split) split = max_split;
+      if (split < 1) split = 1;
+      grid_x = n_tiles * split;
+    }
     dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);
     if (queue)
       hipLaunchKernelGGL(car_linearize_rows_kernel<true>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue);
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, 1);
     else
       hipLaunchKernelGGL(car_linearize_rows_kernel<false>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue);
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, split);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
