@@ -20,6 +20,7 @@ Other workloads (--workload driving|hopper, --M, --S, --mode eval) are for
 sweeps; they print the same line shape.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -250,6 +251,10 @@ class DrivingWork:
         return step
 
 
+# hopper: px / forces by value in the kernel arguments (the eager product path); RATO_BENCH_STAGED=1: pinned upload
+STAGED = bool(os.environ.get("RATO_BENCH_STAGED"))
+
+
 class HopperWork:
     name = "hopper"
     kernel = "hopper_slip_kernel"
@@ -270,13 +275,13 @@ class HopperWork:
         import torch
         self.lam = torch.rand((self.C, self.M), device=device)
 
-    def hot_kernel(self, events=None, slot=0):
+    def hot_kernel(self, events=None, slot=0, reduce=True):
         if events is not None:
             events[0].record()
         if self.mode == "linearize":
-            r = self.model.slip_device(self.px, self.forces, lam=self.lam, want_deriv=True)
+            r = self.model.slip_device(self.px, self.forces, lam=self.lam, want_deriv=True, reduce=reduce, staged=STAGED)
         else:
-            r = self.model.slip_device(self.px, self.forces, want_h=False)
+            r = self.model.slip_device(self.px, self.forces, want_h=False, staged=STAGED)
         if events is not None:
             events[1].record()
         return r
@@ -348,14 +353,14 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def roofline_block(work, kern_ms, workload, mode, M, S, jacobian):
+def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
     alg = work.algorithmic_bytes()
     achieved = alg / (kern_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "frac_of_measured_copy_6290": achieved / 6290.0,
             "algorithmic_bytes_per_launch": alg, "bytes_per_sample_step": alg / (M * S),
-            "kernel_ms": kern_ms, "kernel_ms_source": "HIP events around the launch, mean over the timed steps",
+            "kernel_ms": kern_ms, "kernel_ms_source": kern_src,
             "traffic": None,
             "traffic_from_profile": pmc_traffic(workload, mode, M, S, jacobian)}
 
@@ -387,16 +392,19 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         counter[0] += 1
         if pipelined:
             main_stream.wait_event(ev_free[slot])
-        fold = world == 1 and isinstance(work, DroneWork) and work.mode == "linearize" and not pipelined
+        fold = (world == 1 and isinstance(work, (DroneWork, HopperWork)) and work.mode == "linearize" and not pipelined
+                and not os.environ.get("RATO_BENCH_NO_FOLD"))
         if fold:       # single GPU: linearize, then ONE launch for the sample sums + VaR / CVaR (2 launches per step)
             r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot, reduce=False)
-            stats.sums_and_risk_stats_device(r["part"], r["Z"], args.alpha, workspace=wss[slot], sums_out=r["sums"],
-                                             out=stats_out[slot])
-            return r["sums"]
+            sums, _ = stats.sums_and_risk_stats_device(r["part"], r["Z"], args.alpha, workspace=wss[slot],
+                                                       sums_out=r.get("sums"), out=stats_out[slot])
+            return sums
         r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot)
         if pipelined:
             ev_lin[slot].record(main_stream)
-        with torch.cuda.stream(side):
+        # (only when pipelined: inside a hipGraph capture the current stream is the CAPTURE stream, and switching to a
+        #  stream looked up earlier would take the statistics launches out of the captured step)
+        with (torch.cuda.stream(side) if pipelined else contextlib.nullcontext()):
             if pipelined:
                 side.wait_event(ev_lin[slot])
             sums = work.sums(r)
@@ -420,7 +428,14 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
     for _ in range(args.warmup):
         step()
     if use_graph:
-        for i in range(args.steps):        # eager pre-pass: per-launch kernel time with HIP events
+        # eager pre-pass: per-launch kernel time with HIP events.  The launches are queued BEHIND a spin kernel long
+        # enough for the host to issue all of them, so the events bracket back-to-back GPU work and the host's issue
+        # rate (30-100 us per eager step, more than these kernels) does not leak into the kernel time.
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); torch.cuda._sleep(2_000_000); b.record(); torch.cuda.synchronize()
+        cycles_per_ms = 2_000_000 / max(a.elapsed_time(b), 1e-3)
+        torch.cuda._sleep(int(cycles_per_ms * min(200.0, 5.0 + 0.3 * args.steps)))
+        for i in range(args.steps):
             step(i)
         torch.cuda.synchronize()
         kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -428,7 +443,9 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         graph = torch.cuda.CUDAGraph()     # capture/replay plumbing only: the nodes are this library's kernels
         with torch.cuda.graph(graph):
             step()
-        for _ in range(args.warmup):
+        # setup (untimed): ~10 ms of replays, so that the K timed replays (often < 1 ms in total) do not run at the
+        # clocks the capture pause and the spin kernel left behind; then the W warm-up steps proper
+        for _ in range(200 + args.warmup):
             graph.replay()
     torch.cuda.synchronize()
     barrier()
@@ -452,7 +469,10 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
     launch = "hipGraph replay of the whole step" if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
         if pipelined else "eager, one stream, no overlap between steps")
-    return {"elapsed": elapsed, "kern_ms": kern_ms, "stats": final_stats, "launch": launch}
+    kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
+                "GPU, host issue rate excluded), mean over K launches" if use_graph
+                else "HIP events around the launch, mean over the timed steps")
+    return {"elapsed": elapsed, "kern_ms": kern_ms, "kern_src": kern_src, "stats": final_stats, "launch": launch}
 
 
 def scp_block(work, args):
@@ -552,13 +572,14 @@ def main():
                        "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step "
                                       f"(RCCL behind the C ABI: rato_comm_exchange)",
                        "launch": head["launch"]},
-            "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian),
+            "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
+                                       head["kern_src"]),
             "stats": {"VaR": head["stats"][0], "CVaR": head["stats"][1], "frac_satisfied": head["stats"][2]},
         }
         for res in results[1:]:                           # the other output representation, same run, same samples
             w = res["work"]
             line["roofline_" + res["variant"]] = roofline_block(w, res["kern_ms"], args.workload, args.mode, M, S,
-                                                               res["variant"])
+                                                               res["variant"], res["kern_src"])
             line["value_" + res["variant"]] = world * M * unit_steps * args.steps / res["elapsed"]
             line["ms_per_step_" + res["variant"]] = 1e3 * res["elapsed"] / args.steps
         if world == 1 and is_drone_lin and not args.no_scp:

@@ -64,7 +64,7 @@ extern "C" {
  * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes; 4: rato_comm_*
  * (RCCL behind the ABI), rato_car_separation_distances, rato_count_nonfinite_acc, Philox sampler entry points).  The
  * Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 4
+#define RATO_ABI_VERSION 5
 int rato_abi_version(void);
 
 /* ------------------------------------------------------------------ drone */
@@ -233,6 +233,17 @@ int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, con
                      const float* a, const float* theta, const float* tau, const float* lam,
                      float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
                      void* stream);
+
+/* Same computation with px / fx / fz given as HOST arrays -- what the reference's IPOPT callbacks hold at every
+ * iterate (hopper.py:305-311).  They are read during the call and travel in the kernel's argument block: no staging
+ * buffer and no upload in front of the kernel (the upload was a third of the step at M = 5e4).  C must not exceed
+ * RATO_HOPPER_MAX_HOST_CONTACTS (RATO_EINVAL beyond; use rato_hopper_slip with device arrays).  Under stream capture
+ * the values are frozen into the captured launch: capture rato_hopper_slip if replays must see new inputs. */
+#define RATO_HOPPER_MAX_HOST_CONTACTS 128
+int rato_hopper_slip_host_inputs(int32_t M, int32_t C, const float* px_host, const float* fx_host,
+                                 const float* fz_host, const float* a, const float* theta, const float* tau,
+                                 const float* lam, float* Z, float* h, float* dh_dfz, float* dh_dpx,
+                                 float* part_hess, void* stream);
 
 /* --------------------------------------------------------------- assembly */
 

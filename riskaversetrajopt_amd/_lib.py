@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 4              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 5              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -46,6 +46,7 @@ SIGNATURES = {
     "rato_car_linearize": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [C.c_int32, c_stream]),
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
+    "rato_hopper_slip_host_inputs": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
     "rato_emit_csc_values": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_float, c_float_p, c_stream]),
     "rato_saa_rowmax": (C.c_int, [c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,

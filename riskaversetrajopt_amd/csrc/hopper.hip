@@ -7,6 +7,8 @@
 // One lane = one sample (features live in 90 VGPRs, loaded once, coalesced);
 // the second grid dimension splits the contact steps so that small batches still
 // fill the chip.  This path is transcendental-issue bound, not HBM bound.
+#include <string.h>
+
 #include "rato_common.h"
 
 namespace {
@@ -31,10 +33,17 @@ typedef float hfloat2 __attribute__((ext_vector_type(2)));
 // the loop-invariant products a*theta, a*theta^2 kept in registers.  The lambda-weighted Hessian sums are
 // reduced per wave with DPP into an LDS table and combined once per workgroup at the end (no barrier per
 // contact); lambda for a contact is fetched before that contact's trig block so that its latency is covered.
-template <bool DERIV>
+// The per-contact inputs (foot position and contact force of every contact step) change with every NLP iterate and
+// come from the host.  BYVAL: they travel in the kernel's argument block (scalar loads from the kernarg segment) --
+// no staging buffer, no upload node in front of the kernel; otherwise they are read through device pointers.
+struct HopperContacts {
+  float px[RATO_HOPPER_MAX_HOST_CONTACTS], fx[RATO_HOPPER_MAX_HOST_CONTACTS], fz[RATO_HOPPER_MAX_HOST_CONTACTS];
+};
+
+template <bool DERIV, bool BYVAL>
 __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     int M_, int C, int cpg, const float* __restrict__ px, const float* __restrict__ fx,
-    const float* __restrict__ fz, const float* __restrict__ a, const float* __restrict__ theta,
+    const float* __restrict__ fz, const HopperContacts hc, const float* __restrict__ a, const float* __restrict__ theta,
     const float* __restrict__ tau, const float* __restrict__ lam, float* __restrict__ Z, int z_atomic,
     float* __restrict__ h, float* __restrict__ dh_dfz, float* __restrict__ dh_dpx,
     float* __restrict__ part_hess) {
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
   extern __shared__ float hess_lds[];   // [waves][cpg][2]
   const bool want_hess = DERIV && part_hess;
   for (int c = c0; c < c1; ++c) {
-    const float p = px[c], f_x = fx[c], f_z = fz[c];
+    const float p = BYVAL ? hc.px[c] : px[c], f_x = BYVAL ? hc.fx[c] : fx[c], f_z = BYVAL ? hc.fz[c] : fz[c];
     float l = 0.0f;
     if (want_hess && valid) l = lam[(size_t)c * M + m];   // consumed after the trig block
     hfloat2 p2;
@@ -142,13 +151,21 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
 
 extern "C" int rato_hopper_nblocks(int32_t M) { return M > 0 ? rato::nblocks_for(M) : RATO_EINVAL; }
 
-extern "C" int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,
-                                const float* a, const float* theta, const float* tau, const float* lam,
-                                float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
-                                void* stream) {
+namespace {
+// Z = -inf before the contact groups fold their maxima into it.  A kernel, not hipMemsetD32Async: inside a captured
+// hipGraph a memset node costs ~10 us of cross-queue hand-off on ROCm 7.2, a kernel node stays on the launch queue.
+__global__ __launch_bounds__(RATO_BLOCK) void fill_neg_inf_kernel(float* __restrict__ Z, int M) {
+  const int i = blockIdx.x * RATO_BLOCK + threadIdx.x;
+  if (i < M) Z[i] = -INFINITY;
+}
+
+int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, const float* fz, bool host_inputs,
+                     const float* a, const float* theta, const float* tau, const float* lam, float* Z, float* h,
+                     float* dh_dfz, float* dh_dpx, float* part_hess, void* stream) {
   RATO_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || !px || !fx || !fz || !a || !theta || !tau) return RATO_EINVAL;
   if (part_hess && !lam) return RATO_EINVAL;
+  if (host_inputs && C > RATO_HOPPER_MAX_HOST_CONTACTS) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
   const int nblk = rato::nblocks_for(M);
   // split the contacts until there are ~4 waves per SIMD
@@ -159,18 +176,43 @@ extern "C" int rato_hopper_slip(int32_t M, int32_t C, const float* px, const flo
   const int cpg = (C + groups - 1) / groups;
   groups = (C + cpg - 1) / cpg;
   const int z_atomic = (Z && groups > 1) ? 1 : 0;
-  if (z_atomic) {
-    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(Z), (int)0xff800000u, (size_t)M, st);  // -inf
-    if (e != hipSuccess) return RATO_EHIP - (int)e;
-  }
+  if (z_atomic)
+    hipLaunchKernelGGL(fill_neg_inf_kernel, dim3((M + RATO_BLOCK - 1) / RATO_BLOCK), dim3(RATO_BLOCK), 0, st, Z, (int)M);
   dim3 grid(nblk, groups), block(RATO_BLOCK);
   const bool deriv = dh_dfz || dh_dpx || part_hess;
-  if (deriv)
-    hipLaunchKernelGGL(hopper_slip_kernel<true>, grid, block, (size_t)(RATO_BLOCK / RATO_WAVE) * cpg * 2 * sizeof(float), st, M, C, cpg, px, fx, fz, a, theta, tau, lam, Z,
-                       z_atomic, h, dh_dfz, dh_dpx, part_hess);
-  else
-    hipLaunchKernelGGL(hopper_slip_kernel<false>, grid, block, 0, st, M, C, cpg, px, fx, fz, a, theta, tau, lam, Z,
-                       z_atomic, h, dh_dfz, dh_dpx, part_hess);
+  const size_t lds = deriv ? (size_t)(RATO_BLOCK / RATO_WAVE) * cpg * 2 * sizeof(float) : 0;
+  HopperContacts hc;
+  if (host_inputs) {
+    ::memcpy(hc.px, px, sizeof(float) * C);
+    ::memcpy(hc.fx, fx, sizeof(float) * C);
+    ::memcpy(hc.fz, fz, sizeof(float) * C);
+    px = fx = fz = nullptr;
+  }
+#define RATO_HOPPER_LAUNCH(D, B)                                                                                  \
+  hipLaunchKernelGGL((hopper_slip_kernel<D, B>), grid, block, lds, st, M, C, cpg, px, fx, fz, hc, a, theta, tau, lam, \
+                     Z, z_atomic, h, dh_dfz, dh_dpx, part_hess)
+  if (deriv) {
+    if (host_inputs) RATO_HOPPER_LAUNCH(true, true); else RATO_HOPPER_LAUNCH(true, false);
+  } else {
+    if (host_inputs) RATO_HOPPER_LAUNCH(false, true); else RATO_HOPPER_LAUNCH(false, false);
+  }
+#undef RATO_HOPPER_LAUNCH
   RATO_LAUNCH_CHECK();
   return RATO_OK;
+}
+}  // namespace
+
+extern "C" int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,
+                                const float* a, const float* theta, const float* tau, const float* lam,
+                                float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess,
+                                void* stream) {
+  return hopper_slip_impl(M, C, px, fx, fz, false, a, theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess, stream);
+}
+
+extern "C" int rato_hopper_slip_host_inputs(int32_t M, int32_t C, const float* px_host, const float* fx_host,
+                                            const float* fz_host, const float* a, const float* theta,
+                                            const float* tau, const float* lam, float* Z, float* h, float* dh_dfz,
+                                            float* dh_dpx, float* part_hess, void* stream) {
+  return hopper_slip_impl(M, C, px_host, fx_host, fz_host, true, a, theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess,
+                          stream);
 }

@@ -81,6 +81,7 @@ struct Workspace {
   float tstar;
   unsigned nblocks;
   unsigned magic;   // set by rato_risk_stats_init: the histograms start zeroed and every call leaves them zeroed
+  unsigned ticket;  // rs_coop: completion tickets (0 between calls)
 };
 constexpr unsigned RS_MAGIC = 0x52A70517u;
 
@@ -137,10 +138,10 @@ __device__ void find_bin(const unsigned* __restrict__ hist, unsigned k, unsigned
   __syncthreads();
 }
 
-template <int NB>
+template <int NB, int NT = RATO_BLOCK>
 __device__ void flush_hist(unsigned* lds_hist, unsigned* __restrict__ ghist) {
   __syncthreads();
-  for (int i = threadIdx.x; i < NB; i += RATO_BLOCK) {
+  for (int i = threadIdx.x; i < NB; i += NT) {
     const unsigned c = lds_hist[i];
     if (c) atomicAdd(&ghist[i], c);
   }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 }
 
 // ---- ONE workgroup, ONE launch for M <= RS_SMALL_MAX (BASELINE configs C2 / C3: M = 1e4): Z is read from memory
-// ONCE, its order-preserving keys stay in LDS (4 M bytes, up to 80 KB of the CU's 160 KB) and the three radix passes
+// ONCE, its order-preserving keys stay in LDS (4 M bytes, up to 48 KB of the CU's 160 KB) and the three radix passes
 // and the tail sum run out of LDS -- a pass costs a few hundred cycles instead of a memory round trip, and there is no
 // launch boundary between passes.  The second stage of the sample mean (sum_partials) rides along in extra workgroups of
 // the same launch.  Same arithmetic as the multi-launch form: exact selection, fixed-order fp64 sums.
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 //  time for 1e5 elements, and constraint values cluster in 4 key bins per binade, so almost nothing is filtered by the
 //  first pass.  Removed; git history has it.)
 constexpr int RS1_T = 1024;
-constexpr long RS_SMALL_MAX = 20 * 1024;   // 22.8 us at M = 30,000 against 19-20 us for the 5 launches: crossover ~ 2.5e4
+constexpr long RS_SMALL_MAX = 12 * 1024;   // crossover with rs_coop (below): 14.0 vs 14.7 us at M = 1e4, 19.1 vs 15.6 us at M = 2e4
 
 __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                   int var_is_max, float thr, double* __restrict__ out,
@@ -420,6 +421,228 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
     out[9] = NE;
     out[10] = (double)t;
   }
+}
+
+// ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
+// config: M = 1e5).  The five launches above cost ~4 us each of dependent-launch latency for a few hundred ns of work;
+// here G <= 64 workgroups of 1024 threads keep their keys in REGISTERS (<= 8 per thread), accumulate the same three
+// global histograms with device-scope atomics, and wait on the histograms themselves
+// (find_bin_coop: a pass is complete when its counters add up); the last workgroup to finish (completion ticket) folds the G partial sums in a fixed order and
+// leaves the workspace clean.  All G workgroups must be resident at once for the waits to complete: G <= 64 against
+// 256 CUs x 2 workgroups of this size, launched on an in-order stream behind the producer of Z.
+// Same arithmetic as the other two forms: exact selection, fixed-order fp64 sums (deterministic run to run).
+constexpr int RS_COOP_KEYS = 8;                                   // keys per thread (registers)
+constexpr int RS_COOP_MAX_WG = 64;
+constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 524,288
+
+// find_bin on a histogram that OTHER workgroups of this launch are still adding to: device-scope loads, repeated until
+// the counters add up to `expected` (the number of keys this pass distributes: M, then the count of the chosen bin).
+// Every counter only grows during a pass, so total == expected means every add has landed -- the histogram itself is
+// the barrier, with no arrival counter and no fence (one memory round trip per try instead of three per barrier).
+// Returns false after RS_COOP_TRIES tries (a workspace that was not left clean): the caller fails loudly, never hangs.
+constexpr int RS_COOP_TRIES = 1 << 18;   // ~0.5 s
+template <int NB, int NT>
+__device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, unsigned expected, unsigned& bin,
+                              unsigned& krem, unsigned& bincount) {
+  constexpr int PER = NB / NT;
+  static_assert(PER >= 1 && PER * NT == NB, "bins must divide evenly over the threads");
+  __shared__ unsigned wsum[NT / RATO_WAVE];
+  __shared__ unsigned res[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int tries = 0; tries < RS_COOP_TRIES; ++tries) {
+    unsigned local[PER], tot = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      local[i] = __hip_atomic_load(const_cast<unsigned*>(hist) + tid * PER + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot += local[i];
+    }
+    unsigned incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned n = __shfl_up(incl, off, RATO_WAVE);
+      if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, grand = 0;
+    for (int w = 0; w < NT / RATO_WAVE; ++w) {
+      const unsigned v = wsum[w];
+      if (w < wave) base += v;
+      grand += v;
+    }
+    if (grand == expected) {        // uniform over the workgroup (every thread summed the same LDS words)
+      const unsigned excl = base + incl - tot;
+      if (k >= excl && k < excl + tot) {
+        unsigned run = excl;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          if (k >= run && k < run + local[i]) {
+            res[0] = tid * PER + i;
+            res[1] = k - run;
+            res[2] = local[i];
+          }
+          run += local[i];
+        }
+      }
+      __syncthreads();
+      bin = res[0];
+      krem = res[1];
+      bincount = res[2];
+      __syncthreads();
+      return true;
+    }
+    __syncthreads();                // wsum is rewritten by the next try
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, long M, double alpha, unsigned k,
+                                                 int var_is_max, float thr, int G, Workspace* __restrict__ ws,
+                                                 double* __restrict__ out, const float* __restrict__ part, int nblocks,
+                                                 int ncols, double scale, double* __restrict__ sums_out) {
+  if ((int)blockIdx.x >= G) {   // the sample-mean second stage rides along (independent workgroups, no barriers)
+    sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
+    return;
+  }
+  const int tid = threadIdx.x;
+  if (ws->magic != RS_MAGIC) {  // never initialised: the barrier counter is garbage -> do not wait on it, fail loudly
+    if (blockIdx.x == 0 && tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  __shared__ unsigned h[B1];
+  __shared__ double red[6][RS1_T / RATO_WAVE];
+  __shared__ unsigned last_flag;
+  const int n = (int)M;
+  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  unsigned key[RS_COOP_KEYS];
+  double sum = 0.0, cnt = 0.0;
+  float mx = -INFINITY;
+  {
+    float z[RS_COOP_KEYS];
+#pragma unroll
+    for (int u = 0; u < RS_COOP_KEYS; ++u) {                  // element (u, workgroup, thread): coalesced, all in flight
+      const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
+      z[u] = (i < n) ? Z[i] : 0.0f;
+    }
+    unsigned run_bin = 0xffffffffu, run_cnt = 0;             // runs of equal bins -> one LDS atomic (values cluster)
+#pragma unroll
+    for (int u = 0; u < RS_COOP_KEYS; ++u) {
+      const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
+      key[u] = key_of(z[u]);
+      if (i < n) {
+        const unsigned bin = key[u] >> 21;
+        if (bin != run_bin) {
+          if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+          run_bin = bin;
+          run_cnt = 0;
+        }
+        ++run_cnt;
+        sum += (double)z[u];
+        cnt += (z[u] <= thr) ? 1.0 : 0.0;
+        mx = fmaxf(mx, z[u]);
+      }
+    }
+    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+  }
+  flush_hist<B1, RS1_T>(h, ws->hist1);
+  unsigned b1, k1, c1, b2, k2, c2, b3, k3, c3;
+  bool ok = find_bin_coop<B1, RS1_T>(ws->hist1, k, (unsigned)n, b1, k1, c1);
+  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < RS_COOP_KEYS; ++u) {
+    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
+    if (i < n && (key[u] >> 21) == b1) atomicAdd(&h[(key[u] >> 10) & (B2 - 1)], 1u);
+  }
+  flush_hist<B2, RS1_T>(h, ws->hist2);
+  ok = ok && find_bin_coop<B2, RS1_T>(ws->hist2, k1, c1, b2, k2, c2);
+  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
+  __syncthreads();
+  const unsigned prefix = (b1 << 11) | b2;
+#pragma unroll
+  for (int u = 0; u < RS_COOP_KEYS; ++u) {
+    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
+    if (i < n && (key[u] >> 10) == prefix) atomicAdd(&h[key[u] & (B3 - 1)], 1u);
+  }
+  flush_hist<B3, RS1_T>(h, ws->hist3);
+  ok = ok && find_bin_coop<B3, RS1_T>(ws->hist3, k2, c2, b3, k3, c3);
+  if (!ok) {   // the histograms never added up: the workspace was not clean.  NaN out, un-tag the workspace.
+    if (tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
+    if (tid == 0) ws->magic = 0;
+    return;
+  }
+  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
+  const float t = value_of(tkey);
+  double tail = 0.0, ngt = 0.0, neq = 0.0;
+#pragma unroll
+  for (int u = 0; u < RS_COOP_KEYS; ++u) {
+    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
+    if (i < n) {
+      const float z = value_of(key[u]);
+      tail += (key[u] > tkey) ? ((double)z - (double)t) : 0.0;
+      ngt += (key[u] > tkey) ? 1.0 : 0.0;
+      neq += (key[u] == tkey) ? 1.0 : 0.0;
+    }
+  }
+  sum = rato::wave_sum(sum);
+  cnt = rato::wave_sum(cnt);
+  tail = rato::wave_sum(tail);
+  ngt = rato::wave_sum(ngt);
+  neq = rato::wave_sum(neq);
+  mx = rato::wave_max(mx);
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    red[0][w] = sum; red[1][w] = cnt; red[2][w] = (double)mx; red[3][w] = tail; red[4][w] = ngt; red[5][w] = neq;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double S = 0, C = 0, m = -INFINITY, T = 0, NG = 0, NE = 0;
+    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) {
+      S += red[0][w]; C += red[1][w]; m = fmax(m, red[2][w]); T += red[3][w]; NG += red[4][w]; NE += red[5][w];
+    }
+    double* bp = ws->blockpart[blockIdx.x];
+    bp[0] = S; bp[1] = C; bp[2] = m; bp[3] = T; bp[4] = NG; bp[5] = NE;
+    // release the partials, take a completion ticket; the last workgroup acquires everyone's partials
+    const unsigned tk = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (tk == (unsigned)G - 1u);
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // every workgroup has read hist3 before taking its ticket: zero the histograms and the counters for the next call
+  for (int i = tid; i < B1 + B2 + B3; i += RS1_T) ws->hist1[i] = 0;   // hist1..3 are contiguous
+  if (tid == 0) ws->ticket = 0;
+  if (tid >= RATO_WAVE) return;
+  double s = 0, c = 0, m = -INFINITY, tl = 0, g = 0, e = 0;
+  if (tid < G) {   // G <= 64: one partial per lane, folded by the fixed shuffle tree (independent of who came last)
+    const double* bp = ws->blockpart[tid];
+    s = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = __hip_atomic_load(bp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tl = __hip_atomic_load(bp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g = __hip_atomic_load(bp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e = __hip_atomic_load(bp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s = rato::wave_sum(s);
+  c = rato::wave_sum(c);
+  tl = rato::wave_sum(tl);
+  g = rato::wave_sum(g);
+  e = rato::wave_sum(e);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, RATO_WAVE));
+  if (tid != 0) return;
+  out[0] = var_is_max ? m : (double)t;
+  out[1] = (double)t + (tl / (double)M) / alpha;
+  out[2] = c / (double)M;
+  out[3] = s / (double)M;
+  out[4] = m;
+  out[5] = c;
+  out[6] = tl;
+  out[7] = (double)k;
+  out[8] = g;
+  out[9] = e;
+  out[10] = (double)t;
 }
 
 // one workgroup: zero the whole workspace, then tag it
@@ -532,7 +755,8 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   const int sp_blocks = part ? (ncols + SP_COLS - 1) / SP_COLS : 0;
   // RATO_RS_PATH=multi: diagnostic override (A/B timing of the launch structure; tools/stats_time.py)
   static const int force_multi = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'm') ? 1 : 0; }();
-  if (M <= RS_SMALL_MAX && !force_multi) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
+  static const int force_coop = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'c') ? 1 : 0; }();
+  if (M <= RS_SMALL_MAX && !force_multi && !force_coop) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
     const size_t lds = (size_t)M * sizeof(unsigned);
     static std::atomic<size_t> lds_attr_set{32 * 1024};
     if (lds > lds_attr_set.load()) {
@@ -543,6 +767,15 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     }
     hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), lds, st, Z, (long)M, alpha, k, var_is_max, thr, out,
                        part, (int)nblocks, (int)ncols, scale, sums_out);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
+  }
+  static const int no_coop = [] { const char* e = getenv("RATO_RS_COOP"); return (e && e[0] == '0') ? 1 : 0; }();
+  if (M <= RS_COOP_MAX && !force_multi && (!no_coop || force_coop)) {   // ONE launch, G workgroups, keys in registers
+    long G = (M + RS1_T * 4 - 1) / (RS1_T * 4);
+    if (G > RS_COOP_MAX_WG) G = RS_COOP_MAX_WG;
+    hipLaunchKernelGGL(rs_coop, dim3((unsigned)G + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr,
+                       (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

@@ -2,12 +2,15 @@
 reference's ``class Model`` (hopper/hopper.py:68-81,90-171,300-367,901-958) on
 the MI355X.  The sample-independent NLP rows and the IPOPT glue stay on the
 host and are out of scope."""
+import ctypes as C
+
 import numpy as np
 import torch
 
 from . import _lib, stats
 
 # hopper.py:44-69
+MAX_HOST_CONTACTS = 128   # RATO_HOPPER_MAX_HOST_CONTACTS (include/rato_saa.h)
 S = 30
 M = 30
 T = 2.0
@@ -118,34 +121,55 @@ class Model:
         return px, forces
 
     # ---- device path (K5) --------------------------------------------------
-    def slip_device(self, px, forces, lam=None, want_Z=True, want_h=True, want_deriv=False):
+    def slip_device(self, px, forces, lam=None, want_Z=True, want_h=True, want_deriv=False, reduce=True, staged=None):
         """lam: [C][M] multipliers or None.
-        -> dict of device tensors: Z [M], h/dh_dfz/dh_dpx [C][M], hess [C][2] (float64)."""
-        px = np.asarray(px, dtype=np.float32)
+        -> dict of device tensors: Z [M], h/dh_dfz/dh_dpx [C][M], hess [C][2] (float64).
+        reduce=False: the per-workgroup partial sums of the lambda-weighted second derivatives come back as "part"
+        (hess=None) for a caller that folds their second stage into the statistics launch
+        (stats.sums_and_risk_stats_device).
+        px / forces change with every NLP iterate and come from the host.  staged=False: they travel in the kernel's
+        argument block (rato_hopper_slip_host_inputs: no staging buffer, no upload in front of the kernel);
+        staged=True: one pinned staging buffer + one asynchronous upload into a device buffer the kernel reads
+        (rato_hopper_slip).  Default: by value, except inside a hipGraph capture (where by-value inputs would be frozen
+        into the graph) and for more than 128 contacts."""
+        px = np.ascontiguousarray(px, dtype=np.float32)
         forces = np.asarray(forces, dtype=np.float32)
         Cn, M = px.shape[0], self._a.shape[1]
         dev = self.device
-        # px / fx / fz change with every NLP iterate: ONE pinned staging buffer and one asynchronous upload
-        # (three pageable copies cost ~40 us, more than the kernel at M = 5e4)
-        st = getattr(self, "_stage", None)
-        if st is None or st[0].shape[1] != Cn:
-            st = (torch.empty((3, Cn), dtype=torch.float32).pin_memory(),
-                  torch.empty((3, Cn), dtype=torch.float32, device=dev))
-            self._stage = st
-        host, devbuf = st
-        capturing = torch.cuda.is_current_stream_capturing()   # inside a hipGraph capture: no host-side waits
-        self._stage_event = getattr(self, "_stage_event", None)
-        if self._stage_event is not None and not capturing:
-            self._stage_event.synchronize()          # the previous upload has left the pinned buffer
-        host[0].copy_(torch.from_numpy(px))
-        host[1].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 0])))
-        host[2].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 1])))
-        devbuf.copy_(host, non_blocking=True)
-        if not capturing:
-            if self._stage_event is None:
-                self._stage_event = torch.cuda.Event()
-            self._stage_event.record()
-        pxd, fxd, fzd = devbuf[0], devbuf[1], devbuf[2]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if staged is None:
+            staged = capturing
+        if Cn > MAX_HOST_CONTACTS:
+            staged = True
+        if not staged:
+            fx = np.ascontiguousarray(forces[:, 0])
+            fz = np.ascontiguousarray(forces[:, 1])
+            hp = lambda x: C.c_void_p(x.ctypes.data)
+            entry, pxd, fxd, fzd = self._lib.rato_hopper_slip_host_inputs, hp(px), hp(fx), hp(fz)
+        else:
+            # ONE pinned staging buffer and one asynchronous upload (three pageable copies cost ~40 us, more than the
+            # kernel at M = 5e4)
+            st = getattr(self, "_stage", None)
+            if st is None or st[0].shape[1] != Cn:
+                if capturing:
+                    raise RuntimeError("hopper.slip_device: the pinned staging buffer cannot be allocated inside a "
+                                       "hipGraph capture; call slip_device(..., staged=True) once before capturing")
+                st = (torch.empty((3, Cn), dtype=torch.float32).pin_memory(),
+                      torch.empty((3, Cn), dtype=torch.float32, device=dev))
+                self._stage = st
+            host, devbuf = st
+            self._stage_event = getattr(self, "_stage_event", None)
+            if self._stage_event is not None and not capturing:   # inside a capture: no host-side waits
+                self._stage_event.synchronize()      # the previous upload has left the pinned buffer
+            host[0].copy_(torch.from_numpy(px))
+            host[1].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 0])))
+            host[2].copy_(torch.from_numpy(np.ascontiguousarray(forces[:, 1])))
+            devbuf.copy_(host, non_blocking=True)
+            if not capturing:
+                if self._stage_event is None:
+                    self._stage_event = torch.cuda.Event()
+                self._stage_event.record()
+            entry, pxd, fxd, fzd = self._lib.rato_hopper_slip, _lib.ptr(devbuf[0]), _lib.ptr(devbuf[1]), _lib.ptr(devbuf[2])
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         Z = e(M) if want_Z else None
         h = e(Cn, M) if want_h else None
@@ -158,12 +182,12 @@ class Model:
             if tuple(lamd.shape) != (Cn, M):
                 raise ValueError(f"lam must be [C][M] = ({Cn},{M}), got {tuple(lamd.shape)}")
             part = e(self._lib.rato_hopper_nblocks(M), Cn, 2)
-        _lib.check(self._lib.rato_hopper_slip(
-            M, Cn, _lib.ptr(pxd), _lib.ptr(fxd), _lib.ptr(fzd), _lib.ptr(self._a), _lib.ptr(self._th),
+        _lib.check(entry(
+            M, Cn, pxd, fxd, fzd, _lib.ptr(self._a), _lib.ptr(self._th),
             _lib.ptr(self._tau), _lib.ptr(lamd), _lib.ptr(Z), _lib.ptr(h), _lib.ptr(dfz), _lib.ptr(dpx),
             _lib.ptr(part), _lib.current_stream()), "rato_hopper_slip")
-        hess = stats.sum_partials(part) if part is not None else None
-        return {"Z": Z, "h": h, "dh_dfz": dfz, "dh_dpx": dpx, "hess": hess}
+        hess = stats.sum_partials(part) if (part is not None and reduce) else None
+        return {"Z": Z, "h": h, "dh_dfz": dfz, "dh_dpx": dpx, "hess": hess, "part": part}
 
     def slip_risk_constraints(self, Z):
         """hopper.py:300-367 -> gs (1 + M + M*C + 1,) ['saa'] or (M*C,) ['baseline']."""

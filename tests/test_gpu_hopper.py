@@ -122,3 +122,47 @@ def test_full_size_C4_properties():
     st = d.monte_carlo_statistics(px, forces, alpha=0.1)
     assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.1)) < 5e-5
     assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.1)) < 5e-5
+
+
+@pytest.mark.parametrize("M", [300, 50000])
+def test_inputs_by_value_equal_the_staged_upload(M):
+    """px / forces in the kernel's argument block (rato_hopper_slip_host_inputs, the default) and through the pinned
+    upload into a device buffer (rato_hopper_slip): the same kernel arithmetic, bit for bit; the folded second stage
+    of the Hessian sums (reduce=False + sums_and_risk_stats) equals the separate sum_partials."""
+    import torch
+    from riskaversetrajopt_amd import hopper, stats
+    _, d = _models(60, M)
+    C = d.time_jump + (d.S - d.time_land)
+    rng = np.random.RandomState(3)
+    px = np.linspace(0.0, 0.2, C)
+    fz = 32.0 + rng.randn(C)
+    forces = np.stack([0.08 * fz + 0.3 * rng.randn(C), fz], axis=1)
+    lam = torch.rand((C, M), device="cuda")
+    a = d.slip_device(px, forces, lam=lam, want_deriv=True, staged=False)
+    b = d.slip_device(px, forces, lam=lam, want_deriv=True, staged=True)
+    for k in ("Z", "h", "dh_dfz", "dh_dpx", "hess"):
+        assert torch.equal(a[k], b[k]), k
+    c = d.slip_device(px, forces, lam=lam, want_deriv=True, reduce=False)
+    assert c["hess"] is None
+    sums, st = stats.sums_and_risk_stats_device(c["part"], c["Z"], 0.1)
+    assert torch.equal(sums, a["hess"])
+    assert torch.equal(st, stats.risk_stats_device(a["Z"], 0.1))
+
+
+def test_host_inputs_entry_rejects_too_many_contacts():
+    import ctypes as C
+    import torch
+    from riskaversetrajopt_amd import _lib, hopper
+    lib = _lib.load()
+    n = hopper.MAX_HOST_CONTACTS + 1
+    host = np.zeros(n, np.float32)
+    f = torch.zeros((30, 64), device="cuda")
+    Z = torch.empty(64, device="cuda")
+    hp = C.c_void_p(host.ctypes.data)
+    rc = lib.rato_hopper_slip_host_inputs(64, n, hp, hp, hp, _lib.ptr(f), _lib.ptr(f), _lib.ptr(f), None, _lib.ptr(Z),
+                                          None, None, None, None, _lib.current_stream())
+    assert rc == -1                                   # RATO_EINVAL
+    rc = lib.rato_hopper_slip_host_inputs(64, n - 1, hp, hp, hp, _lib.ptr(f), _lib.ptr(f), _lib.ptr(f), None,
+                                          _lib.ptr(Z), None, None, None, None, _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()

@@ -13,7 +13,8 @@ def _np_stats(Z32, alpha, thr=1e-6):
                 frac=np.mean(Z32 <= np.float32(thr)), mean=Z.mean(), max=Z.max())
 
 
-@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 20 * 1024, 20 * 1024 + 1, 1 << 15, 123457, 1 << 20])
+@pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 12 * 1024, 12 * 1024 + 1, 20 * 1024 + 1, 1 << 15, 123457,
+                               1 << 19, (1 << 19) + 1, 1 << 20])
 @pytest.mark.parametrize("alpha", [0.01, 0.05, 0.3, 1.0])
 def test_risk_stats_exact(M, alpha):
     from riskaversetrajopt_amd import stats
@@ -29,7 +30,8 @@ def test_risk_stats_exact(M, alpha):
     assert st["max"] == ref["max"]
 
 
-@pytest.mark.parametrize("M", [5000, 20480, 100000])       # one workgroup with LDS-resident keys / multi-launch path
+# one workgroup with LDS-resident keys (M <= 12,288) / one launch, keys in registers (<= 524,288) / five launches
+@pytest.mark.parametrize("M", [5000, 12288, 20480, 100000, 524288, 600000])
 def test_risk_stats_edge_distributions(M):
     from riskaversetrajopt_amd import stats
     cases = {
@@ -148,13 +150,73 @@ def test_uninitialised_workspace_fails_loudly():
     import torch
     from riskaversetrajopt_amd import stats, _lib
     lib = _lib.load()
-    M = 50000                                    # the multi-launch path (M > 20,480) is the one that uses the workspace
+    M = 50000                                    # the paths for M > 12,288 are the ones that use the workspace
     Z = torch.randn(M, device="cuda")
     ws = torch.full((lib.rato_risk_stats_workspace_bytes(M),), 0x5A, dtype=torch.uint8, device="cuda")   # never initialised
     out = stats.risk_stats_device(Z, 0.1, workspace=ws)
     assert torch.isnan(out).all()
     good = stats.risk_stats_device(Z, 0.1)
     assert torch.isfinite(good).all()
+
+
+def test_unclean_workspace_fails_loudly_instead_of_waiting_forever():
+    """The one-launch path waits for its histograms to add up; a workspace that some aborted call left with counts in
+    it can never add up -> bounded wait, NaN statistics, the workspace loses its tag (NaN until re-initialised)."""
+    import torch
+    from riskaversetrajopt_amd import stats
+    M = 50000
+    Z = torch.randn(M, device="cuda")
+    ws = stats.new_workspace(M, Z.device)
+    good = stats.risk_stats_device(Z, 0.1, workspace=ws).clone()
+    assert torch.isfinite(good).all()
+    ws.view(torch.int32)[100] = 7                # a stale count in the first-pass histogram
+    torch.cuda.synchronize()
+    bad = stats.risk_stats_device(Z, 0.1, workspace=ws)
+    assert torch.isnan(bad).all()
+    again = stats.risk_stats_device(Z, 0.1, workspace=ws)           # stays loud
+    assert torch.isnan(again).all()
+    ws2 = stats.new_workspace(M, Z.device)
+    assert torch.equal(stats.risk_stats_device(Z, 0.1, workspace=ws2), good)
+
+
+CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from riskaversetrajopt_amd import stats
+out = {}
+for M in (300, 10000, 12289, 50000, 100000, 524288):
+    Z = (np.random.RandomState(M).randn(M) * 0.05 + 0.9).astype(np.float32)
+    for alpha in (0.05, 1.0):
+        ws = stats.new_workspace(M, torch.device("cuda:0"))
+        Zd = torch.from_numpy(Z).cuda()
+        for rep in range(3):
+            st = stats.risk_stats_device(Zd, alpha, workspace=ws)
+        out["%%d_%%g" %% (M, alpha)] = st.cpu().numpy()
+np.savez(%(path)r, **out)
+'''
+
+
+def test_launch_structures_agree(tmp_path):
+    """default (one workgroup / one launch of a few workgroups / five launches by size), the five launches forced, the
+    one-launch form forced: selection, counts and maxima identical, fp64 sums equal to summation order."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("default", {}), ("multi", {"RATO_RS_PATH": "multi"}), ("coop", {"RATO_RS_PATH": "coop"})):
+        path = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", CHILD % dict(root=root, path=path)], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = np.load(path)
+    for k in res["default"].files:
+        a = res["default"][k]
+        for name in ("multi", "coop"):
+            b = res[name][k]
+            for slot in (0, 2, 4, 5, 7, 8, 9, 10):                  # VaR, fraction, max, counts, rank, t*: exact
+                assert a[slot] == b[slot], (k, name, slot)
+            np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-13, err_msg=f"{k} {name}")
 
 
 def test_alpha_one_keeps_the_minimiser_separate_from_the_wrapped_var():
