@@ -149,7 +149,9 @@ class DroneWork:
     def sums(self, r):
         import torch
         if r["du_sum"] is None:
-            return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+            if getattr(self, "_no_sums", None) is None:
+                self._no_sums = torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+            return self._no_sums
         return r["sums"]
 
     def algorithmic_bytes(self):
@@ -229,7 +231,9 @@ class DrivingWork:
 
     def sums(self, r):
         import torch
-        return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)   # final rows are sample independent
+        if getattr(self, "_no_sums", None) is None:          # final rows are sample independent: nothing to sum
+            self._no_sums = torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+        return self._no_sums
 
     def algorithmic_bytes(self):
         M, S = self.M, self.S
@@ -289,7 +293,9 @@ class HopperWork:
     def sums(self, r):
         import torch
         if r.get("hess") is None:
-            return torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+            if getattr(self, "_no_sums", None) is None:
+                self._no_sums = torch.zeros(1, dtype=torch.float64, device=r["Z"].device)
+            return self._no_sums
         return r["hess"].reshape(-1)
 
     def algorithmic_bytes(self):

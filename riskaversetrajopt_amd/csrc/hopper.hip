@@ -7,6 +7,7 @@
 // One lane = one sample (features live in 90 VGPRs, loaded once, coalesced);
 // the second grid dimension splits the contact steps so that small batches still
 // fill the chip.  This path is transcendental-issue bound, not HBM bound.
+#include <stdlib.h>
 #include <string.h>
 
 #include "rato_common.h"
@@ -40,20 +41,33 @@ struct HopperContacts {
   float px[RATO_HOPPER_MAX_HOST_CONTACTS], fx[RATO_HOPPER_MAX_HOST_CONTACTS], fz[RATO_HOPPER_MAX_HOST_CONTACTS];
 };
 
+// Launch shape.  A workgroup is 4 waves = SW sample-waves x NW contact-waves (NW = 2 or 4; 1 only as a diagnostic):
+// the SW sample-waves take 64 samples each, the NW contact-waves of a sample-wave share its samples and take the
+// contacts c = cw, cw + NW, ... ; max_c is folded through LDS.  Small batches split the contacts 4 ways so that the
+// chip still gets ~3 waves per SIMD (M = 5e4: 782 workgroups of 64 samples, 3128 waves; measured per step at C4:
+// NW = 4 53.8-55.2 us, 2 56.0-58.4, 1 64.8-65.9, 8 waves of 5 contacts in 512-thread workgroups 60.4-62.4); large
+// ones 2 ways (M = 1e6: 0.394 ms against 0.404 unsplit and 0.403 at 4).
+// Everything a sample needs meets inside ONE workgroup: no atomics on Z, nothing to initialise before the launch
+// (round 2 until here: contact groups on blockIdx.y folded with atomic max into a Z pre-filled with -inf -- one more
+// node in every step).
 template <bool DERIV, bool BYVAL>
 __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
-    int M_, int C, int cpg, const float* __restrict__ px, const float* __restrict__ fx,
-    const float* __restrict__ fz, const HopperContacts hc, const float* __restrict__ a, const float* __restrict__ theta,
-    const float* __restrict__ tau, const float* __restrict__ lam, float* __restrict__ Z, int z_atomic,
-    float* __restrict__ h, float* __restrict__ dh_dfz, float* __restrict__ dh_dpx,
+    int M_, int C, int nw_log2, const float* __restrict__ px, const float* __restrict__ fx,
+    const float* __restrict__ fz, const HopperContacts hc, const float* __restrict__ a,
+    const float* __restrict__ theta, const float* __restrict__ tau, const float* __restrict__ lam,
+    float* __restrict__ Z, float* __restrict__ h, float* __restrict__ dh_dfz, float* __restrict__ dh_dpx,
     float* __restrict__ part_hess) {
   static_assert(NF % 2 == 0, "features are processed in pairs");
   constexpr int NP = NF / 2;
+  constexpr int WAVES = RATO_BLOCK / RATO_WAVE;
   constexpr float INV_2PI = 0.15915494309189535f;
   const size_t M = (size_t)M_;
-  const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
-  const bool valid = m_raw < M;
-  const size_t m = valid ? m_raw : M - 1;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR)
+  const int NW = 1 << nw_log2, SW = WAVES >> nw_log2;
+  const int sw = wave >> nw_log2, cw = wave & (NW - 1);
+  const unsigned m_raw = (blockIdx.x * SW + sw) * RATO_WAVE + lane;      // M < 2^31
+  const bool valid = m_raw < (unsigned)M_;
+  const unsigned m = valid ? m_raw : (unsigned)M_ - 1u;
   hfloat2 fa[NP], rth[NP], rtau[NP];   // amplitude | theta / 2 pi | tau / 2 pi
 
 #pragma unroll
@@ -68,13 +82,12 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     rth[k] = th * INV_2PI;
     rtau[k] = ta * INV_2PI;
   }
-  const int c0 = blockIdx.y * cpg;
-  const int c1 = min(C, c0 + cpg);
   float zmax = -INFINITY;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  extern __shared__ float hess_lds[];   // [waves][cpg][2]
+  extern __shared__ float lds[];        // [WAVES][64] per-wave maxima | [SW][C][2] per-wave Hessian sums
+  float* zred = lds;
+  float* hess_lds = lds + WAVES * RATO_WAVE;
   const bool want_hess = DERIV && part_hess;
-  for (int c = c0; c < c1; ++c) {
+  for (int c = cw; c < C; c += NW) {
     const float p = BYVAL ? hc.px[c] : px[c], f_x = BYVAL ? hc.fx[c] : fx[c], f_z = BYVAL ? hc.fz[c] : fz[c];
     float l = 0.0f;
     if (want_hess && valid) l = lam[(size_t)c * M + m];   // consumed after the trig block
@@ -118,47 +131,49 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
         if (dh_dpx) dh_dpx[(size_t)c * M + m] = (s1.x + s1.y) * f_z;  // -mu'(p) fz
       }
     }
-    if (want_hess) {  // wave-uniform
+    if (want_hess) {  // wave-uniform; contact c belongs to exactly one contact-wave of each sample-wave
       const float d1 = rato::wave_sum_dpp(l * (s1.x + s1.y));        // lam * d2h/(dpx dfz) = -lam mu'
       const float d2 = rato::wave_sum_dpp(l * (s2.x + s2.y) * f_z);  // lam * d2h/dpx^2   = -lam mu'' fz
       if (lane == 0) {
-        hess_lds[(wave * cpg + (c - c0)) * 2 + 0] = d1;
-        hess_lds[(wave * cpg + (c - c0)) * 2 + 1] = d2;
+        hess_lds[(sw * C + c) * 2 + 0] = d1;
+        hess_lds[(sw * C + c) * 2 + 1] = d2;
       }
     }
   }
+  const bool fold_z = Z && NW > 1;
+  if (fold_z) zred[wave * RATO_WAVE + lane] = zmax;
+  if (want_hess || fold_z) __syncthreads();
   if (want_hess) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < (c1 - c0) * 2; i += RATO_BLOCK) {
+    for (int i = threadIdx.x; i < C * 2; i += RATO_BLOCK) {
       float acc = 0.0f;
-#pragma unroll
-      for (int w = 0; w < RATO_BLOCK / RATO_WAVE; ++w) acc += hess_lds[w * cpg * 2 + i];   // fixed order
-      part_hess[((size_t)blockIdx.x * C + c0) * 2 + i] = acc;
+      for (int w = 0; w < SW; ++w) acc += hess_lds[w * C * 2 + i];   // fixed order
+      part_hess[(size_t)blockIdx.x * C * 2 + i] = acc;
     }
   }
-  if (Z && valid) {
-    if (!z_atomic) {
-      Z[m] = zmax;
-    } else if (zmax >= 0.0f) {  // order-independent float max through integer atomics
-      atomicMax(reinterpret_cast<int*>(Z) + m, __float_as_int(zmax));
-    } else {
-      atomicMin(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax));
-    }
+  if (Z && valid && cw == 0) {
+    for (int j = 1; j < NW; ++j) zmax = fmaxf(zmax, zred[(wave + j) * RATO_WAVE + lane]);
+    Z[m] = zmax;
   }
+}
+
+// contact-waves per sample-wave for a batch of M samples: ~3000 waves or more whenever the batch allows it
+inline int hopper_nw_log2(int32_t M) {
+  // RATO_HOPPER_NW_LOG2=0|1|2: diagnostic override (A/B runs of the launch shape)
+  static const int forced = [] { const char* e = getenv("RATO_HOPPER_NW_LOG2"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+  if (forced >= 0) return forced;
+  const long sample_waves = ((long)M + RATO_WAVE - 1) / RATO_WAVE;
+  return sample_waves >= 1536 ? 1 : 2;
+}
+inline int hopper_blocks(int32_t M) {
+  const int samples_per_block = RATO_BLOCK >> hopper_nw_log2(M);
+  return (int)(((long)M + samples_per_block - 1) / samples_per_block);
 }
 
 }  // namespace
 
-extern "C" int rato_hopper_nblocks(int32_t M) { return M > 0 ? rato::nblocks_for(M) : RATO_EINVAL; }
+extern "C" int rato_hopper_nblocks(int32_t M) { return M > 0 ? hopper_blocks(M) : RATO_EINVAL; }
 
 namespace {
-// Z = -inf before the contact groups fold their maxima into it.  A kernel, not hipMemsetD32Async: inside a captured
-// hipGraph a memset node costs ~10 us of cross-queue hand-off on ROCm 7.2, a kernel node stays on the launch queue.
-__global__ __launch_bounds__(RATO_BLOCK) void fill_neg_inf_kernel(float* __restrict__ Z, int M) {
-  const int i = blockIdx.x * RATO_BLOCK + threadIdx.x;
-  if (i < M) Z[i] = -INFINITY;
-}
-
 int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, const float* fz, bool host_inputs,
                      const float* a, const float* theta, const float* tau, const float* lam, float* Z, float* h,
                      float* dh_dfz, float* dh_dpx, float* part_hess, void* stream) {
@@ -167,20 +182,11 @@ int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, con
   if (part_hess && !lam) return RATO_EINVAL;
   if (host_inputs && C > RATO_HOPPER_MAX_HOST_CONTACTS) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
-  const int nblk = rato::nblocks_for(M);
-  // split the contacts until there are ~4 waves per SIMD
-  long waves = (long)nblk * (RATO_BLOCK / RATO_WAVE);
-  int groups = (int)((4096 + waves - 1) / waves);
-  if (groups < 1) groups = 1;
-  if (groups > C) groups = C;
-  const int cpg = (C + groups - 1) / groups;
-  groups = (C + cpg - 1) / cpg;
-  const int z_atomic = (Z && groups > 1) ? 1 : 0;
-  if (z_atomic)
-    hipLaunchKernelGGL(fill_neg_inf_kernel, dim3((M + RATO_BLOCK - 1) / RATO_BLOCK), dim3(RATO_BLOCK), 0, st, Z, (int)M);
-  dim3 grid(nblk, groups), block(RATO_BLOCK);
+  const int nw_log2 = hopper_nw_log2(M);
+  dim3 grid(hopper_blocks(M)), block(RATO_BLOCK);
   const bool deriv = dh_dfz || dh_dpx || part_hess;
-  const size_t lds = deriv ? (size_t)(RATO_BLOCK / RATO_WAVE) * cpg * 2 * sizeof(float) : 0;
+  const int SW = (RATO_BLOCK / RATO_WAVE) >> nw_log2;
+  const size_t lds = (size_t)(RATO_BLOCK + (part_hess ? SW * C * 2 : 0)) * sizeof(float);
   HopperContacts hc;
   if (host_inputs) {
     ::memcpy(hc.px, px, sizeof(float) * C);
@@ -189,8 +195,8 @@ int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, con
     px = fx = fz = nullptr;
   }
 #define RATO_HOPPER_LAUNCH(D, B)                                                                                  \
-  hipLaunchKernelGGL((hopper_slip_kernel<D, B>), grid, block, lds, st, M, C, cpg, px, fx, fz, hc, a, theta, tau, lam, \
-                     Z, z_atomic, h, dh_dfz, dh_dpx, part_hess)
+  hipLaunchKernelGGL((hopper_slip_kernel<D, B>), grid, block, lds, st, M, C, nw_log2, px, fx, fz, hc, a, theta, tau, \
+                     lam, Z, h, dh_dfz, dh_dpx, part_hess)
   if (deriv) {
     if (host_inputs) RATO_HOPPER_LAUNCH(true, true); else RATO_HOPPER_LAUNCH(true, false);
   } else {

@@ -22,6 +22,9 @@ for c in C2 C3 C4 C5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$c -- $B --config $c --graph off --no-cpu-baseline --no-scp --steps 50 --warmup 5 > /dev/null 2>&1
 done
 cd $R
+# 5. store-only ceilings of this box for the access pattern of the packed Jacobian (tools/store_pattern*.hip)
+for t in store_pattern store_pattern3; do [ -x tools/_build/$t ] && tools/_build/$t > $O/$t.txt 2>&1; done
+python3 tools/store_peak.py 2>/dev/null | tail -4 > $O/store_peak_torch.txt
 for d in kt_metric kt_C2 kt_C3 kt_C4 kt_C5; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 find $O -name "*.csv" -size +2M -delete; find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 ls $O | head -50
