@@ -380,7 +380,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
-    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split) {
+    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   const size_t M = (size_t)P.M;
   const int S = P.S;
@@ -473,8 +473,21 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // (see drone_linearize_rows_kernel); the sample-independent ego tables are built once per workgroup.
   // split > 1 (small batches, !LOOP): every tile is dealt out to `split` workgroups that each build the tables and take
   // the row tasks congruent to their part (mod split), so that a batch of a few hundred tiles still fills the chip.
-  const int part_id = LOOP ? 0 : (int)blockIdx.x % split, row_split = LOOP ? 1 : split;
-  for (int tile = LOOP ? (int)blockIdx.x : (int)blockIdx.x / split; tile < n_tiles_total;) {
+  // LOOP with split > 1: the queue hands the first n_whole tiles out whole and the LAST ones as `split` row-interleaved
+  // parts each (shorter last units shorten the drain of the launch, as in the drone kernel).
+  const int n_units = LOOP ? n_whole + (n_tiles_total - n_whole) * split : n_tiles_total * split;
+  for (int unit = (int)blockIdx.x; unit < n_units;) {
+  int tile, part_id, row_split;
+  if (LOOP && unit < n_whole) {
+    tile = unit;
+    part_id = 0;
+    row_split = 1;
+  } else {
+    const int v = LOOP ? unit - n_whole : unit;
+    tile = (LOOP ? n_whole : 0) + v / split;
+    part_id = v - (v / split) * split;
+    row_split = split;
+  }
   const size_t m_raw = (size_t)tile * CROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
@@ -667,8 +680,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   if (threadIdx.x == 0)
     head[2] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  tile = head[2];
-  }  // tile loop
+  unit = head[2];
+  }  // unit loop
   if (LOOP && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == gridDim.x - 1) {
@@ -836,12 +849,25 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
       grid_x = n_tiles * split;
     }
     dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);
-    if (queue)
+    if (queue) {
+      // the last `tail_tiles` tiles of the queue as `tail_split` parts each (RATO_CAR_TAIL_SPLIT / RATO_CAR_TAIL_TILES).
+      // OFF by default: unlike the drone's products output it does not pay here -- C5 shard (M = 125,000, 1954 tiles
+      // on 768 slots), same box, alternating (tools/ab_car_tail.sh), kernel ms: whole tiles 0.1813-0.1816 | halves over
+      // the last 384 / 768 tiles 0.1817-0.1823 / 0.1844-0.1856 | thirds 0.1904-0.1907 | quarters 0.1994-0.2012.
+      static const int tail_split_env = [] { const char* e = getenv("RATO_CAR_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
+      static const int tail_tiles_env = [] { const char* e = getenv("RATO_CAR_TAIL_TILES"); return e ? atoi(e) : -1; }();
+      int tail_split = tail_split_env < 1 ? 1 : tail_split_env;
+      const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;
+      if (tail_split > max_split) tail_split = max_split;
+      int tail_tiles = tail_tiles_env >= 0 ? tail_tiles_env : slots / 2;
+      if (tail_tiles > n_tiles) tail_tiles = n_tiles;
+      const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
       hipLaunchKernelGGL(car_linearize_rows_kernel<true>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, 1);
-    else
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
+    } else {
       hipLaunchKernelGGL(car_linearize_rows_kernel<false>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, split);
+                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
+    }
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
