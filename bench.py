@@ -471,6 +471,25 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = kern_ms_eager if use_graph else float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    sclk = None
+    if rank == 0:
+        # diagnostic, outside the timed region: the shader clock the device sustains WHILE the hot kernel runs (one wave
+        # on a second stream reads the cycle counter against the 100 MHz counter; rato_device_clock_probe).  Boxes of the pool run this same
+        # binary 5-10 % apart while their store-only ceilings agree to 2 %.
+        try:
+            from riskaversetrajopt_amd import _lib
+            lib = _lib.load()
+            probe = torch.zeros((3, 3), dtype=torch.float64, device=device)
+            side2 = torch.cuda.Stream()
+            probe_us = int(max(5, min(2000, kern_ms * 1e3 * 0.5)))                       # ~ half a kernel long
+            for i in range(3):
+                work.hot_kernel(slot=0)
+                with torch.cuda.stream(side2):
+                    _lib.check(lib.rato_device_clock_probe(_lib.ptr(probe[i]), probe_us, _lib.current_stream()), "clock probe")
+                torch.cuda.synchronize()
+            sclk = float(np.median(probe[:, 0].cpu().numpy()))
+        except Exception as e:                          # a diagnostic must never take the bench line down
+            print(f"note: clock probe skipped ({e})", file=sys.stderr)
     final_stats = stats_out[(counter[0] - 1) & 1].cpu().numpy()
     launch = "hipGraph replay of the whole step" if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
@@ -478,7 +497,8 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
                 "GPU, host issue rate excluded), mean over K launches" if use_graph
                 else "HIP events around the launch, mean over the timed steps")
-    return {"elapsed": elapsed, "kern_ms": kern_ms, "kern_src": kern_src, "stats": final_stats, "launch": launch}
+    return {"elapsed": elapsed, "kern_ms": kern_ms, "kern_src": kern_src, "stats": final_stats, "launch": launch,
+            "sclk_mhz": sclk}
 
 
 def scp_block(work, args):
@@ -581,6 +601,9 @@ def main():
             "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
                                        head["kern_src"]),
             "stats": {"VaR": head["stats"][0], "CVaR": head["stats"][1], "frac_satisfied": head["stats"][2]},
+            "device": {"sclk_mhz_beside_hot_kernel": head["sclk_mhz"],
+                       "how": "shader-cycle counter against the 100 MHz counter, one wave on a second stream while the hot "
+                              "kernel runs (rato_device_clock_probe); diagnostic, outside the timed region"},
         }
         for res in results[1:]:                           # the other output representation, same run, same samples
             w = res["work"]

@@ -67,6 +67,12 @@ extern "C" {
 #define RATO_ABI_VERSION 5
 int rato_abi_version(void);
 
+/* Diagnostic (no reference counterpart): the shader clock the device sustains at this moment -- shader-cycle counter
+ * against the constant 100 MHz counter over `us` microseconds (1..100000), one wave.  out3 (device, 3 doubles) =
+ * { MHz, elapsed us, 0 }.  bench.py quotes it beside the roofline (boxes of one pool run the same binary several
+ * percent apart). */
+int rato_device_clock_probe(double* out3, int32_t us, void* stream);
+
 /* ------------------------------------------------------------------ drone */
 
 /* Constants of drone_params.py:1-45 / Model.__init__ drone_risk.py:71-93. */

@@ -28,6 +28,7 @@ class CarParams(C.Structure):
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
 SIGNATURES = {
     "rato_abi_version": (C.c_int, []),
+    "rato_device_clock_probe": (C.c_int, [c_float_p, C.c_int32, c_stream]),
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

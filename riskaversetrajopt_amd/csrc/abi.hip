@@ -2,3 +2,33 @@
 #include "rato_common.h"
 
 extern "C" int rato_abi_version(void) { return RATO_ABI_VERSION; }
+
+// Diagnostic: the shader clock the device sustains right now.  One wave reads the shader-cycle counter (s_memtime)
+// and the constant 100 MHz counter (s_memrealtime) `us` microseconds apart: sclk = cycles / elapsed.  (Calibrated
+// against a chain of dependent fp32 FMAs, 7 cycles each: tools/clock_probe.py.)  bench.py reports it beside the
+// roofline, because the pool's boxes run the same binary 5-10 % apart while their store-only ceilings agree to 2 %.
+namespace {
+__global__ void clock_probe_kernel(double* out, unsigned ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long c0 = clock64();
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long t1 = t0;
+  while (t1 - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    t1 = wall_clock64();
+  }
+  const unsigned long long c1 = clock64();
+  const double us = (double)(t1 - t0) / 100.0;
+  out[0] = (double)(c1 - c0) / us;   // MHz
+  out[1] = us;
+  out[2] = 0.0;
+}
+}  // namespace
+
+extern "C" int rato_device_clock_probe(double* out3, int32_t us, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!out3 || us < 1 || us > 100000) return RATO_EINVAL;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(RATO_WAVE), 0, rato::as_stream(stream), out3, (unsigned)us * 100u);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
