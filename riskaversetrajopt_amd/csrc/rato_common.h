@@ -48,6 +48,60 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
 }
 
+// The same DPP tree for doubles (both halves moved, zero filled where the source lane does not exist: +0.0) and
+// for unsigned integers; wave_scan_dpp leaves the INCLUSIVE prefix sum in every lane (lane 63 = total).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double a) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double a) {
+  a += dpp_move<0x111, 0xf>(a);
+  a += dpp_move<0x112, 0xf>(a);
+  a += dpp_move<0x114, 0xf>(a);
+  a += dpp_move<0x118, 0xf>(a);
+  a += dpp_move<0x142, 0xa>(a);
+  a += dpp_move<0x143, 0xc>(a);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63));
+}
+__device__ __forceinline__ unsigned wave_scan_dpp(unsigned a) {
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x111, 0xf, 0xf, true);
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x112, 0xf, 0xf, true);
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xf, true);
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xf, true);
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, true);
+  a += (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, true);
+  return a;
+}
+__device__ __forceinline__ float wave_max_dpp(float a) {   // max in every lane; out-of-range sources read as -inf
+  const int ninf = (int)0xff800000u;
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x111, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x112, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x114, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x118, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x142, 0xa, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x143, 0xc, 0xf, false)));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+}
+// max over the 16 lanes of a DPP row, in lane 15 of the row
+__device__ __forceinline__ float row16_max_dpp(float a) {
+  const int ninf = (int)0xff800000u;
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x111, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x112, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x114, 0xf, 0xf, false)));
+  a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(a), 0x118, 0xf, 0xf, false)));
+  return a;
+}
+// sum over the 16 lanes of a DPP row, total in lane 15 of the row (fixed order)
+__device__ __forceinline__ double row16_sum_dpp(double a) {
+  a += dpp_move<0x111, 0xf>(a);
+  a += dpp_move<0x112, 0xf>(a);
+  a += dpp_move<0x114, 0xf>(a);
+  a += dpp_move<0x118, 0xf>(a);
+  return a;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, RATO_WAVE);

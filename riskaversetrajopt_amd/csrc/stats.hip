@@ -110,12 +110,7 @@ __device__ void find_bin(const unsigned* __restrict__ hist, unsigned k, unsigned
     local[i] = hist[tid * PER + i];
     tot += local[i];
   }
-  unsigned incl = tot;  // inclusive scan across the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned n = __shfl_up(incl, off, RATO_WAVE);
-    if (lane >= off) incl += n;
-  }
+  const unsigned incl = rato::wave_scan_dpp(tot);  // inclusive scan across the wave (DPP, no LDS round trips)
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   unsigned base = 0;
@@ -301,9 +296,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 }
 
 // ---- ONE workgroup, ONE launch for M <= RS_SMALL_MAX (BASELINE configs C2 / C3: M = 1e4): Z is read from memory
-// ONCE, its order-preserving keys stay in LDS (4 M bytes, up to 48 KB of the CU's 160 KB) and the three radix passes
-// and the tail sum run out of LDS -- a pass costs a few hundred cycles instead of a memory round trip, and there is no
-// launch boundary between passes.  The second stage of the sample mean (sum_partials) rides along in extra workgroups of
+// ONCE (every load of a thread in flight together), its order-preserving keys stay in REGISTERS (<= 12 per thread)
+// and the three radix passes and the tail sum never touch memory again -- a pass costs a few hundred cycles instead
+// of a memory round trip, and there is no launch boundary between passes.  The second stage of the sample mean (sum_partials) rides along in extra workgroups of
 // the same launch.  Same arithmetic as the multi-launch form: exact selection, fixed-order fp64 sums.
 // Measured per call, host issue excluded (tools/stats_time.py, hipGraph replay): see DESIGN.md 4.5.
 // (A single-launch form for larger M -- histogram workgroups + an atomic ticket, the last workgroup finishing alone --
@@ -313,6 +308,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 constexpr int RS1_T = 1024;
 constexpr long RS_SMALL_MAX = 12 * 1024;   // crossover with rs_coop (below): 14.0 vs 14.7 us at M = 1e4, 19.1 vs 15.6 us at M = 2e4
 
+constexpr int RS_SMALL_KEYS = (int)(RS_SMALL_MAX / RS1_T);   // keys per thread (registers)
+
 __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                   int var_is_max, float thr, double* __restrict__ out,
                                                   const float* __restrict__ part, int nblocks, int ncols,
@@ -321,33 +318,37 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
     sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
     return;
   }
-  extern __shared__ unsigned keys[];                     // [M]
   __shared__ unsigned h[B1];
-  __shared__ double red[6][RS1_T / RATO_WAVE];
+  __shared__ double red[5][RS1_T / RATO_WAVE];
+  __shared__ float redmax[RS1_T / RATO_WAVE];
   const int tid = threadIdx.x;
   const int n = (int)M;
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 0] = (double)wall_clock64();
+#endif
+  // every load of the thread in flight before anything else (Z comes from HBM: its producer's L2 was written back)
+  float z[RS_SMALL_KEYS];
+#pragma unroll
+  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
+    const int i = tid + u * RS1_T;
+    z[u] = (i < n) ? Z[i] : 0.0f;
+  }
   for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
   __syncthreads();
+  unsigned key[RS_SMALL_KEYS];
   double sum = 0.0, cnt = 0.0;
   float mx = -INFINITY;
-  for (int i0 = tid; i0 < n; i0 += 8 * RS1_T) {          // 8 loads in flight per thread
-    float z[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * RS1_T;
-      z[u] = (i < n) ? Z[i] : 0.0f;
-    }
+  {
     // constraint values cluster (a binade holds only 4 of the 2048 first-pass bins), and same-address LDS atomics
-    // serialise: a thread folds runs of equal bins of its own 8 elements into one atomic (measured: 18 -> 12 us at
+    // serialise: a thread folds runs of equal bins of its own elements into one atomic (measured: 18 -> 12 us at
     // M = 1e4 of clustered values)
     unsigned run_bin = 0xffffffffu, run_cnt = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * RS1_T;
+    for (int u = 0; u < RS_SMALL_KEYS; ++u) {
+      const int i = tid + u * RS1_T;
+      key[u] = key_of(z[u]);
       if (i < n) {
-        const unsigned key = key_of(z[u]);
-        keys[i] = key;
-        const unsigned bin = key >> 21;
+        const unsigned bin = key[u] >> 21;
         if (bin != run_bin) {
           if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
           run_bin = bin;
@@ -362,74 +363,107 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
     if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
   }
   __syncthreads();
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 1] = (double)wall_clock64();
+#endif
   unsigned b1, k1, b2, k2, b3, k3;
   find_bin<B1, RS1_T>(h, k, b1, k1);
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 2] = (double)wall_clock64();
+#endif
   for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += RS1_T) {
-    const unsigned key = keys[i];
-    if ((key >> 21) == b1) atomicAdd(&h[(key >> 10) & (B2 - 1)], 1u);
+#pragma unroll
+  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
+    const int i = tid + u * RS1_T;
+    if (i < n && (key[u] >> 21) == b1) atomicAdd(&h[(key[u] >> 10) & (B2 - 1)], 1u);
   }
   __syncthreads();
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 3] = (double)wall_clock64();
+#endif
   find_bin<B2, RS1_T>(h, k1, b2, k2);
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 4] = (double)wall_clock64();
+#endif
   for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
   __syncthreads();
   const unsigned prefix = (b1 << 11) | b2;
-  for (int i = tid; i < n; i += RS1_T) {
-    const unsigned key = keys[i];
-    if ((key >> 10) == prefix) atomicAdd(&h[key & (B3 - 1)], 1u);
+#pragma unroll
+  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
+    const int i = tid + u * RS1_T;
+    if (i < n && (key[u] >> 10) == prefix) atomicAdd(&h[key[u] & (B3 - 1)], 1u);
   }
   __syncthreads();
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 5] = (double)wall_clock64();
+#endif
   find_bin<B3, RS1_T>(h, k2, b3, k3);
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 6] = (double)wall_clock64();
+#endif
   const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
   const float t = value_of(tkey);
   double tail = 0.0, ngt = 0.0, neq = 0.0;
-  for (int i = tid; i < n; i += RS1_T) {
-    const unsigned key = keys[i];
-    const float z = value_of(key);
-    tail += (key > tkey) ? ((double)z - (double)t) : 0.0;
-    ngt += (key > tkey) ? 1.0 : 0.0;
-    neq += (key == tkey) ? 1.0 : 0.0;
+#pragma unroll
+  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
+    const int i = tid + u * RS1_T;
+    if (i < n) {
+      tail += (key[u] > tkey) ? ((double)z[u] - (double)t) : 0.0;
+      ngt += (key[u] > tkey) ? 1.0 : 0.0;
+      neq += (key[u] == tkey) ? 1.0 : 0.0;
+    }
   }
-  // one barrier for all six block reductions (fixed order: wave tree, then waves 0..15 in order)
-  sum = rato::wave_sum(sum);
-  cnt = rato::wave_sum(cnt);
-  tail = rato::wave_sum(tail);
-  ngt = rato::wave_sum(ngt);
-  neq = rato::wave_sum(neq);
-  mx = rato::wave_max(mx);
+#ifdef RATO_RS_DIAG
+  if (tid == 0) out[16 + 7] = (double)wall_clock64();
+#endif
+  // one barrier for all six block reductions; fixed order: DPP tree inside a wave, then the 16 wave totals through
+  // one DPP row of wave 0 (a serial fold by one thread + shuffle trees cost 3.8 us of the 12-14 us of this kernel)
+  sum = rato::wave_sum_dpp(sum);
+  cnt = rato::wave_sum_dpp(cnt);
+  tail = rato::wave_sum_dpp(tail);
+  ngt = rato::wave_sum_dpp(ngt);
+  neq = rato::wave_sum_dpp(neq);
+  mx = rato::wave_max_dpp(mx);
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
-    red[0][w] = sum; red[1][w] = cnt; red[2][w] = tail; red[3][w] = ngt; red[4][w] = neq; red[5][w] = (double)mx;
+    red[0][w] = sum; red[1][w] = cnt; red[2][w] = tail; red[3][w] = ngt; red[4][w] = neq;
+    redmax[w] = mx;
   }
   __syncthreads();
-  if (tid == 0) {
-    double S = 0, C = 0, T = 0, NG = 0, NE = 0, m = -INFINITY;
-    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) {
-      S += red[0][w]; C += red[1][w]; T += red[2][w]; NG += red[3][w]; NE += red[4][w];
-      m = fmax(m, red[5][w]);
+  if (tid < RATO_WAVE) {
+    static_assert(RS1_T / RATO_WAVE == 16, "one DPP row folds the wave totals");
+    const bool in = tid < RS1_T / RATO_WAVE;
+    const double S = rato::row16_sum_dpp(in ? red[0][tid] : 0.0), C = rato::row16_sum_dpp(in ? red[1][tid] : 0.0);
+    const double T = rato::row16_sum_dpp(in ? red[2][tid] : 0.0), NG = rato::row16_sum_dpp(in ? red[3][tid] : 0.0);
+    const double NE = rato::row16_sum_dpp(in ? red[4][tid] : 0.0);
+    const double m = (double)rato::row16_max_dpp(in ? redmax[tid] : -INFINITY);
+    if (tid == 15) {
+      out[0] = var_is_max ? m : (double)t;
+      out[1] = (double)t + (T / (double)M) / alpha;
+      out[2] = C / (double)M;                   // true divisions: the fraction is compared bit for bit with np.mean
+      out[3] = S / (double)M;
+      out[4] = m;
+      out[5] = C;
+      out[6] = T;
+      out[7] = (double)k;
+      out[8] = NG;
+      out[9] = NE;
+      out[10] = (double)t;
+#ifdef RATO_RS_DIAG
+      out[16 + 8] = (double)wall_clock64();
+#endif
     }
-    out[0] = var_is_max ? m : (double)t;
-    out[1] = (double)t + (T / (double)M) / alpha;
-    out[2] = C / (double)M;
-    out[3] = S / (double)M;
-    out[4] = m;
-    out[5] = C;
-    out[6] = T;
-    out[7] = (double)k;
-    out[8] = NG;
-    out[9] = NE;
-    out[10] = (double)t;
   }
 }
 
 // ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
 // config: M = 1e5).  The five launches above cost ~4 us each of dependent-launch latency for a few hundred ns of work;
 // here G <= 64 workgroups of 1024 threads keep their keys in REGISTERS (<= 8 per thread), accumulate the same three
-// global histograms with device-scope atomics, and wait on the histograms themselves
-// (find_bin_coop: a pass is complete when its counters add up); the last workgroup to finish (completion ticket) folds the G partial sums in a fixed order and
-// leaves the workspace clean.  All G workgroups must be resident at once for the waits to complete: G <= 64 against
-// 256 CUs x 2 workgroups of this size, launched on an in-order stream behind the producer of Z.
+// global histograms with device-scope atomics, and wait on the histograms themselves (find_bin_coop: a pass is
+// complete when its counters add up); the last workgroup to finish (completion ticket) folds the G partial sums in a
+// fixed order and leaves the workspace clean.  All G workgroups must be resident at once for the waits to complete:
+// G <= 64 against 256 CUs x 2 workgroups of this size, launched on an in-order stream behind the producer of Z.
 // Same arithmetic as the other two forms: exact selection, fixed-order fp64 sums (deterministic run to run).
 constexpr int RS_COOP_KEYS = 8;                                   // keys per thread (registers)
 constexpr int RS_COOP_MAX_WG = 64;
@@ -456,12 +490,7 @@ __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, uns
       local[i] = __hip_atomic_load(const_cast<unsigned*>(hist) + tid * PER + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       tot += local[i];
     }
-    unsigned incl = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned n = __shfl_up(incl, off, RATO_WAVE);
-      if (lane >= off) incl += n;
-    }
+    const unsigned incl = rato::wave_scan_dpp(tot);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     unsigned base = 0, grand = 0;
@@ -514,8 +543,6 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
   __shared__ double red[6][RS1_T / RATO_WAVE];
   __shared__ unsigned last_flag;
   const int n = (int)M;
-  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
-  __syncthreads();
   unsigned key[RS_COOP_KEYS];
   double sum = 0.0, cnt = 0.0;
   float mx = -INFINITY;
@@ -526,6 +553,8 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
       const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
       z[u] = (i < n) ? Z[i] : 0.0f;
     }
+    for (int i = tid; i < B1; i += RS1_T) h[i] = 0;           // while the loads are in flight
+    __syncthreads();
     unsigned run_bin = 0xffffffffu, run_cnt = 0;             // runs of equal bins -> one LDS atomic (values cluster)
 #pragma unroll
     for (int u = 0; u < RS_COOP_KEYS; ++u) {
@@ -586,27 +615,30 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
       neq += (key[u] == tkey) ? 1.0 : 0.0;
     }
   }
-  sum = rato::wave_sum(sum);
-  cnt = rato::wave_sum(cnt);
-  tail = rato::wave_sum(tail);
-  ngt = rato::wave_sum(ngt);
-  neq = rato::wave_sum(neq);
-  mx = rato::wave_max(mx);
+  sum = rato::wave_sum_dpp(sum);
+  cnt = rato::wave_sum_dpp(cnt);
+  tail = rato::wave_sum_dpp(tail);
+  ngt = rato::wave_sum_dpp(ngt);
+  neq = rato::wave_sum_dpp(neq);
+  mx = rato::wave_max_dpp(mx);
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
     red[0][w] = sum; red[1][w] = cnt; red[2][w] = (double)mx; red[3][w] = tail; red[4][w] = ngt; red[5][w] = neq;
   }
   __syncthreads();
-  if (tid == 0) {
-    double S = 0, C = 0, m = -INFINITY, T = 0, NG = 0, NE = 0;
-    for (int w = 0; w < RS1_T / RATO_WAVE; ++w) {
-      S += red[0][w]; C += red[1][w]; m = fmax(m, red[2][w]); T += red[3][w]; NG += red[4][w]; NE += red[5][w];
+  if (tid < RATO_WAVE) {   // the 16 wave totals through one DPP row (fixed order), result in lane 15
+    const bool in = tid < RS1_T / RATO_WAVE;
+    const double S = rato::row16_sum_dpp(in ? red[0][tid] : 0.0), C = rato::row16_sum_dpp(in ? red[1][tid] : 0.0);
+    const double T = rato::row16_sum_dpp(in ? red[3][tid] : 0.0), NG = rato::row16_sum_dpp(in ? red[4][tid] : 0.0);
+    const double NE = rato::row16_sum_dpp(in ? red[5][tid] : 0.0);
+    const double m = (double)rato::row16_max_dpp(in ? (float)red[2][tid] : -INFINITY);
+    if (tid == 15) {
+      double* bp = ws->blockpart[blockIdx.x];
+      bp[0] = S; bp[1] = C; bp[2] = m; bp[3] = T; bp[4] = NG; bp[5] = NE;
+      // release the partials, take a completion ticket; the last workgroup acquires everyone's partials
+      const unsigned tk = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = (tk == (unsigned)G - 1u);
     }
-    double* bp = ws->blockpart[blockIdx.x];
-    bp[0] = S; bp[1] = C; bp[2] = m; bp[3] = T; bp[4] = NG; bp[5] = NE;
-    // release the partials, take a completion ticket; the last workgroup acquires everyone's partials
-    const unsigned tk = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last_flag = (tk == (unsigned)G - 1u);
   }
   __syncthreads();
   if (!last_flag) return;
@@ -624,13 +656,12 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
     g = __hip_atomic_load(bp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e = __hip_atomic_load(bp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  s = rato::wave_sum(s);
-  c = rato::wave_sum(c);
-  tl = rato::wave_sum(tl);
-  g = rato::wave_sum(g);
-  e = rato::wave_sum(e);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, RATO_WAVE));
+  s = rato::wave_sum_dpp(s);
+  c = rato::wave_sum_dpp(c);
+  tl = rato::wave_sum_dpp(tl);
+  g = rato::wave_sum_dpp(g);
+  e = rato::wave_sum_dpp(e);
+  m = (double)rato::wave_max_dpp((float)m);      // maxima of fp32 values: exact in float
   if (tid != 0) return;
   out[0] = var_is_max ? m : (double)t;
   out[1] = (double)t + (tl / (double)M) / alpha;
@@ -757,15 +788,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   static const int force_multi = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'm') ? 1 : 0; }();
   static const int force_coop = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'c') ? 1 : 0; }();
   if (M <= RS_SMALL_MAX && !force_multi && !force_coop) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
-    const size_t lds = (size_t)M * sizeof(unsigned);
-    static std::atomic<size_t> lds_attr_set{32 * 1024};
-    if (lds > lds_attr_set.load()) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rs_small),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RS_SMALL_MAX * sizeof(unsigned)));
-      if (e != hipSuccess) return RATO_EHIP - (int)e;
-      lds_attr_set.store(RS_SMALL_MAX * sizeof(unsigned));
-    }
-    hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), lds, st, Z, (long)M, alpha, k, var_is_max, thr, out,
+    hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out,
                        part, (int)nblocks, (int)ncols, scale, sums_out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
