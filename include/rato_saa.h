@@ -472,7 +472,7 @@ int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream);
  *        reference's index -1 wraps to max(Z) (NumPy negative index, drone_main_plot.py:651) while CVaR, the counts
  *        and every consumer of the threshold (rato_saa_tail_rows*) keep using t = out[10].
  * Launches: 1 for M <= 12,288 (one workgroup, Z read once, keys resident in LDS: csrc/stats.hip rs_small); 1 for
- * M <= 524,288 (<= 64 workgroups, keys in registers, global histograms that the workgroups wait on: rs_coop -- these
+ * M <= 1,048,576 (<= 64 workgroups, keys in registers, global histograms that the workgroups wait on: rs_coop -- these
  * workgroups must be resident together, which an otherwise idle or normally loaded GPU guarantees; a wait that does
  * not complete within ~0.5 s, e.g. on a workspace some aborted call left unclean, ends in NaN statistics and an
  * un-tagged workspace, never in a hang); 5 beyond (3 histogram passes, tail, final).  Exact selection, deterministic
@@ -483,7 +483,7 @@ int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
                     void* workspace, size_t workspace_bytes, double* out, void* stream);
 
 /* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
- * M <= 524,288 (the partial-sum workgroups ride along with the selection workgroups; two stream-ordered calls
+ * M <= 1,048,576 (the partial-sum workgroups ride along with the selection workgroups; two stream-ordered calls
  * otherwise): the whole reduction stage of a single-GPU SAA step. */
 int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
                              const float* Z, int64_t M, double alpha, float thr, void* workspace,

@@ -459,15 +459,15 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
 
 // ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
 // config: M = 1e5).  The five launches above cost ~4 us each of dependent-launch latency for a few hundred ns of work;
-// here G <= 64 workgroups of 1024 threads keep their keys in REGISTERS (<= 8 per thread), accumulate the same three
+// here G <= 64 workgroups of 1024 threads keep their keys in REGISTERS (<= 16 per thread), accumulate the same three
 // global histograms with device-scope atomics, and wait on the histograms themselves (find_bin_coop: a pass is
 // complete when its counters add up); the last workgroup to finish (completion ticket) folds the G partial sums in a
 // fixed order and leaves the workspace clean.  All G workgroups must be resident at once for the waits to complete:
 // G <= 64 against 256 CUs x 2 workgroups of this size, launched on an in-order stream behind the producer of Z.
 // Same arithmetic as the other two forms: exact selection, fixed-order fp64 sums (deterministic run to run).
-constexpr int RS_COOP_KEYS = 8;                                   // keys per thread (registers)
+constexpr int RS_COOP_KEYS = 16;                                  // keys per thread (registers)
 constexpr int RS_COOP_MAX_WG = 64;
-constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 524,288
+constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 1,048,576
 
 // find_bin on a histogram that OTHER workgroups of this launch are still adding to: device-scope loads, repeated until
 // the counters add up to `expected` (the number of keys this pass distributes: M, then the count of the chosen bin).

@@ -35,7 +35,7 @@ def new_workspace(M, device):
 
 def sums_and_risk_stats_device(part, Z, alpha, thr=SATISFIED_THRESHOLD, scale=1.0, workspace=None, sums_out=None,
                                out=None, stream=None):
-    """sum_partials(part) and risk_stats_device(Z) as ONE launch for M <= 524,288 (rato_sums_and_risk_stats)
+    """sum_partials(part) and risk_stats_device(Z) as ONE launch for M <= 1,048,576 (rato_sums_and_risk_stats)
     -> (sums fp64 (part.shape[1:]), stats fp64 [N_STATS])."""
     lib = _lib.load()
     _lib.require_f32_device(part, "part")

@@ -14,7 +14,7 @@ def _np_stats(Z32, alpha, thr=1e-6):
 
 
 @pytest.mark.parametrize("M", [1, 2, 63, 64, 1000, 1 << 13, (1 << 13) + 1, 10000, 12 * 1024, 12 * 1024 + 1, 20 * 1024 + 1, 1 << 15, 123457,
-                               1 << 19, (1 << 19) + 1, 1 << 20])
+                               1 << 19, (1 << 19) + 1, 1 << 20, (1 << 20) + 1])
 @pytest.mark.parametrize("alpha", [0.01, 0.05, 0.3, 1.0])
 def test_risk_stats_exact(M, alpha):
     from riskaversetrajopt_amd import stats
@@ -30,8 +30,8 @@ def test_risk_stats_exact(M, alpha):
     assert st["max"] == ref["max"]
 
 
-# one workgroup with LDS-resident keys (M <= 12,288) / one launch, keys in registers (<= 524,288) / five launches
-@pytest.mark.parametrize("M", [5000, 12288, 20480, 100000, 524288, 600000])
+# one workgroup with LDS-resident keys (M <= 12,288) / one launch, keys in registers (<= 1,048,576) / five launches
+@pytest.mark.parametrize("M", [5000, 12288, 20480, 100000, 1048576, 1100000])
 def test_risk_stats_edge_distributions(M):
     from riskaversetrajopt_amd import stats
     cases = {
@@ -184,7 +184,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, %(root)r)
 from riskaversetrajopt_amd import stats
 out = {}
-for M in (300, 10000, 12289, 50000, 100000, 524288):
+for M in (300, 10000, 12289, 50000, 100000, 1048576):
     Z = (np.random.RandomState(M).randn(M) * 0.05 + 0.9).astype(np.float32)
     for alpha in (0.05, 1.0):
         ws = stats.new_workspace(M, torch.device("cuda:0"))

@@ -6,7 +6,7 @@ from riskaversetrajopt_amd import stats
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
 N = 20
-for M in (1000, 4096, 10000, 20000, 30000, 50000, 100000, 200000, 500000, 800000, 1000000, 8000000):
+for M in (1000, 4096, 10000, 20000, 30000, 50000, 100000, 200000, 500000, 800000, 1000000, 1048577, 8000000):
     for name, Z in (("clustered", 0.9 + 0.05 * torch.randn(M, generator=g, device=dev)),
                     ("spread", torch.randn(M, generator=g, device=dev) * torch.exp(8 * torch.rand(M, generator=g, device=dev)))):
         ws = stats.new_workspace(M, dev)
