@@ -229,3 +229,29 @@ def test_alpha_one_keeps_the_minimiser_separate_from_the_wrapped_var():
         assert st["var"] == float(Z.max()) and st["t_star"] == float(Z.min())
         assert st["count_above_var"] + st["count_at_var"] == M
         np.testing.assert_allclose(st["cvar"], Z.astype(np.float64).mean(), rtol=1e-12, atol=1e-12)
+
+
+def test_one_launch_selection_on_concurrent_streams():
+    """The one-launch selection waits inside the launch for its own workgroups; calls on different streams (each with
+    its own workspace) may overlap on the device, beside a bandwidth-heavy kernel, and still finish and agree."""
+    import torch
+    from riskaversetrajopt_amd import stats, _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    Ms = (50000, 200000, 1000000, 30000)
+    Zs = [0.9 + 0.05 * torch.randn(M, generator=g, device=dev) for M in Ms]
+    refs = [stats.risk_stats_device(Z, 0.1).clone() for Z in Zs]
+    streams = [torch.cuda.Stream() for _ in Ms]
+    wss = [stats.new_workspace(M, dev) for M in Ms]
+    outs = [torch.empty(stats.N_STATS, dtype=torch.float64, device=dev) for _ in Ms]
+    big = torch.empty(1 << 28, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(20):
+        big.fill_(float(rep))                                    # keeps every CU busy on the default stream
+        for Z, st, ws, out in zip(Zs, streams, wss, outs):
+            with torch.cuda.stream(st):
+                stats.risk_stats_device(Z, 0.1, workspace=ws, out=out, stream=_lib.current_stream())
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, refs):
+        assert torch.equal(out, ref)
