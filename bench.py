@@ -359,6 +359,20 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def board_info():
+    """Serial number and HBM vendor of GPU 0 from rocm-smi, for the ``device`` block of the line: boxes of one pool run
+    the same binary several percent apart.  A child process, started BEFORE this process initialises the GPU; any
+    failure is swallowed (diagnostic only)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showserial", "--showmemvendor", "--json"], capture_output=True, text=True,
+                             timeout=10).stdout
+        card = json.loads(out[out.index("{"):]).get("card0", {})
+        return {"serial": card.get("Serial Number"), "hbm_vendor": card.get("GPU memory vendor")}
+    except Exception:
+        return None
+
+
 def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
     alg = work.algorithmic_bytes()
     achieved = alg / (kern_ms * 1e-3) / 1e9
@@ -542,6 +556,7 @@ def main():
         print(f"error: --gpus {args.gpus} but WORLD_SIZE={env_world} (launch with --nproc-per-node {args.gpus}, or "
               f"let bench.py start the ranks itself: python bench.py --gpus {args.gpus})", file=sys.stderr)
         sys.exit(2)
+    board = board_info() if int(os.environ.get("RANK", "0")) == 0 else None   # before this process touches the GPU
     import torch
     import torch.distributed as dist
     from riskaversetrajopt_amd import dist as rdist, stats
@@ -604,7 +619,7 @@ def main():
             "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
                                        head["kern_src"]),
             "stats": {"VaR": head["stats"][0], "CVaR": head["stats"][1], "frac_satisfied": head["stats"][2]},
-            "device": {"sclk_mhz_beside_hot_kernel": head["sclk_mhz"],
+            "device": {"board": board, "sclk_mhz_beside_hot_kernel": head["sclk_mhz"],
                        "how": "shader-cycle counter against the 100 MHz counter, one wave on a second stream while the hot "
                               "kernel runs (rato_device_clock_probe); diagnostic, outside the timed region"},
         }
