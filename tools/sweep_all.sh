@@ -1,6 +1,6 @@
 #!/bin/bash
 # M-sweep of every kernel: prints one line per (workload, mode, M)
-run() { timeout 120 python bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" 2>/dev/null | python tools/pline.py "$*"; }
+run() { timeout 200 python bench.py --no-cpu-baseline --no-scp --steps 20 --warmup 3 "$@" 2>/dev/null | python tools/pline.py "$*"; }
 for M in 10000 100000 1000000; do run --workload drone --mode linearize --M $M; done
 for M in 10000 100000 1000000 10000000; do run --workload drone --mode eval --M $M; done
 for M in 10000 100000 1000000 4000000; do run --workload driving --mode linearize --M $M; done
