@@ -360,15 +360,23 @@ def spawn_ranks(args):
 
 
 def board_info():
-    """Serial number and HBM vendor of GPU 0 from rocm-smi, for the ``device`` block of the line: boxes of one pool run
-    the same binary several percent apart.  A child process, started BEFORE this process initialises the GPU; any
-    failure is swallowed (diagnostic only)."""
-    import subprocess
+    """Serial number, VBIOS and HBM vendor of the visible GPU from sysfs, for the ``device`` block of the line: boxes
+    of one pool run the same binary several percent apart.  Plain file reads (no child process: under rocprofv3 the
+    GPU is initialised before this program starts, and such a process must not exec anything); failures are swallowed."""
+    import glob
     try:
-        out = subprocess.run(["rocm-smi", "--showserial", "--showmemvendor", "--json"], capture_output=True, text=True,
-                             timeout=10).stdout
-        card = json.loads(out[out.index("{"):]).get("card0", {})
-        return {"serial": card.get("Serial Number"), "hbm_vendor": card.get("GPU memory vendor")}
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device"), key=lambda x: int("".join(c for c in x.split("/")[4] if c.isdigit()) or 0)):
+            try:
+                info = {}
+                for key, f in (("serial", "serial_number"), ("vbios", "vbios_version"), ("hbm_vendor", "mem_info_vram_vendor")):
+                    info[key] = open(os.path.join(d, f)).read().strip()
+                cards.append(info)
+            except OSError:
+                continue
+        if not cards:
+            return None
+        return cards[min(int(os.environ.get("LOCAL_RANK", "0")), len(cards) - 1)]
     except Exception:
         return None
 
