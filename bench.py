@@ -7,7 +7,7 @@ mean -> chance-constraint / VaR / CVaR statistics (what one SCP iteration asks
 of the SAA inner loop).  Default workload = the configuration the metric is
 quoted on: drone_risk, M = 1e5 samples per GPU, S = 50 steps, fp32.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -39,8 +39,8 @@ B = 4                       # fp32
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=["drone", "driving", "hopper"])
     ap.add_argument("--mode", default="linearize", choices=["linearize", "eval"])
     ap.add_argument("--M", type=int, default=0, help="samples per GPU (default: 1e5 drone/driving, 5e4 hopper)")
@@ -452,7 +452,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         return sums
 
     # setup, not part of the W warm-up steps or of the timed region: ~10 ms of the hot kernel so that a short run
-    # (the default K = 20, W = 3) does not time the first launches at idle clocks (measured: 0.301 vs 0.289 ms per step)
+    # (e.g. K = 20, W = 3) does not time the first launches at idle clocks (measured: 0.301 vs 0.289 ms per step)
     for _ in range(40):
         work.hot_kernel(slot=0)
     torch.cuda.synchronize()
@@ -496,6 +496,9 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = kern_ms_eager if use_graph else float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if os.environ.get("RATO_BENCH_TRACE") and not use_graph and rank == 0:      # per-launch kernel times, to stderr
+        ts = [a.elapsed_time(b) for a, b in ev]
+        print("kernel ms per launch:", " ".join("%.4f" % t for t in ts), file=sys.stderr)
     sclk = None
     if rank == 0:
         # diagnostic, outside the timed region: the shader clock the device sustains WHILE the hot kernel runs (one wave
