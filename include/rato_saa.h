@@ -34,6 +34,12 @@
  * as a stream:
  *     G[tile][row][lane],  tile = m / TILE, lane = m % TILE,
  *     n_tiles = ceil(M / TILE); lanes >= M of the last tile are not written.
+ * Tile stride: consecutive tiles are rato_packed_tile_stride(rows * TILE) floats apart -- back to back while a tile
+ * is smaller than 1 MiB, otherwise every tile starts on a 2 MiB boundary and G itself must be 2 MiB aligned
+ * (buffer size: n_tiles * stride floats).  One rule from the tile shape alone, shared by every producer and consumer
+ * of the layout in this library (linearize, rowmax / tail rows, CSC emission).  It is there for the write path: the
+ * row-parallel kernels keep one store stream per resident tile, and 512 streams a power-of-two distance apart are
+ * spread evenly over the memory channels (1.88 MB tiles, store-only: 5.1-5.2 TB/s back to back, 5.7 at 2 MiB).
  * TILE depends on the kernel variant and is reported by the *_plan() call
  * (64 for the row-parallel drone kernel, RATO_TILE = 256 otherwise).
  */
@@ -64,8 +70,11 @@ extern "C" {
  * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes; 4: rato_comm_*
  * (RCCL behind the ABI), rato_car_separation_distances, rato_count_nonfinite_acc, Philox sampler entry points).  The
  * Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 5
+#define RATO_ABI_VERSION 6
 int rato_abi_version(void);
+
+/* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
+size_t rato_packed_tile_stride(size_t payload_floats);
 
 /* Diagnostic (no reference counterpart): the shader clock the device sustains at this moment -- shader-cycle counter
  * against the constant 100 MHz counter over `us` microseconds (1..100000), one wave.  out3 (device, 3 doubles) =

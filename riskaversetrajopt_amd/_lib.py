@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 5              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 6              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -28,6 +28,7 @@ class CarParams(C.Structure):
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
 SIGNATURES = {
     "rato_abi_version": (C.c_int, []),
+    "rato_packed_tile_stride": (C.c_size_t, [C.c_size_t]),
     "rato_device_clock_probe": (C.c_int, [c_float_p, C.c_int32, c_stream]),
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -160,3 +161,46 @@ def require_f32_device(t, name):
     if not t.is_contiguous():
         raise RatoError(f"{name} must be contiguous")
     return t
+
+
+PACKED_ALIGN_BYTES = int(os.environ.get("RATO_PACKED_ALIGN_BYTES", 2 << 20))   # tiles of >= 1 MiB start on 2 MiB boundaries
+#                                  (rato_packed_tile_stride, rato_saa.h; the variable only serves A/B builds of tools/)
+
+
+def packed_tile_stride(shape):
+    """Floats between consecutive tiles of a packed tile-blocked buffer of ``shape`` = (n_tiles, rows..., TILE)."""
+    payload = 1
+    for d in shape[1:]:
+        payload *= int(d)
+    return int(load().rato_packed_tile_stride(payload)), payload
+
+
+def packed_buffer(shape, device):
+    """Device buffer for a packed, tile-blocked Jacobian [n_tiles][rows...][TILE] in the layout the kernels use: a
+    plain contiguous tensor when the tiles are packed back to back, otherwise a strided VIEW (tile stride =
+    rato_packed_tile_stride, first tile on a 2 MiB boundary) of a larger flat allocation; ``.data_ptr()`` is what the
+    kernels take either way."""
+    import torch
+    stride, payload = packed_tile_stride(shape)
+    if stride == payload:
+        return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    pad = PACKED_ALIGN_BYTES // 4
+    flat = torch.empty(int(shape[0]) * stride + pad, dtype=torch.float32, device=device)
+    off = (-(flat.data_ptr() // 4)) % pad
+    strides = [stride]
+    acc = payload
+    for d in shape[1:]:
+        acc //= int(d)
+        strides.append(acc)
+    return torch.as_strided(flat, tuple(int(d) for d in shape), tuple(strides), storage_offset=off)
+
+
+def is_packed_layout(t, shape):
+    """``t`` has ``shape`` and the tile stride / alignment ``packed_buffer`` would give it."""
+    if t is None or tuple(t.shape) != tuple(int(d) for d in shape):
+        return False
+    stride, payload = packed_tile_stride(shape)
+    if stride == payload:
+        return t.is_contiguous()
+    inner = t[0]
+    return inner.is_contiguous() and t.stride(0) == stride and t.data_ptr() % PACKED_ALIGN_BYTES == 0

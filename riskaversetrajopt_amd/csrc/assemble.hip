@@ -27,7 +27,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void emit_csc_kernel(const float* __res
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   const bool fact = (W != nullptr);         // factored Jacobian: entry = W[r,t,g] * Phi[t,s,g]
   const int RR = fact ? 1 : R;
-  const size_t tile_floats = n_pairs * n_g * RR * tileW;
+  const size_t tile_floats = rato::packed_tile_stride(n_pairs * n_g * RR * tileW);
   const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * tile_floats + (i0 % tileW) + lane;
   const long before = (long)s * (S - 1) - (long)s * (s - 1) / 2;      // sum_{s'<s} (S-1-s')
   for (int g = 0; g < n_g; ++g) {

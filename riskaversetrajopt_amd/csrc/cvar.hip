@@ -45,7 +45,7 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
   const long m = valid ? m_raw : M - 1;
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   constexpr int RR = FACT ? 1 : R;   // row groups stored per (pair, control): factored keeps only Phi
-  const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * (n_pairs * 2 * RR * tileW) + (i0 % tileW) + lane;
+  const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (i0 % tileW) + lane;
   float best = -INFINITY;
   int best_idx = 0;
   auto next_task = [&]() -> int {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   const bool fact = (W != nullptr);
   const int RR = fact ? 1 : R;
-  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * RR * tileW) + (m % tileW);
+  const float* __restrict__ Gm = G + (size_t)(m / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (m % tileW);
   const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
   float w0 = w, w1 = w;
   if (fact && w != 0.0f) {   // factored: entry = W[r,t,a] * Phi[t,s,a]
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   const bool fact = (W != nullptr);
   const int RR = fact ? 1 : R;
-  const float* __restrict__ Gm = G + (size_t)(m / tileW) * (n_pairs * 2 * RR * tileW) + (m % tileW);
+  const float* __restrict__ Gm = G + (size_t)(m / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (m % tileW);
   const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
   float w0 = w, w1 = w, wg = 0.0f;
   if (w != 0.0f) {

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
   c.cn = sqrtf(P.dt) * P.beta;
   float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
   // this workgroup's tile of the packed Jacobian: [n_pairs*2 rows][RATO_TILE lanes]
-  float* __restrict__ Gt = G + (size_t)blockIdx.x * ((size_t)rato::pair_row_offset(S) * 2 * RATO_TILE);
+  float* __restrict__ Gt = G + (size_t)blockIdx.x * rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * 2 * RATO_TILE);
 
   int stp[SPT];
 #pragma unroll
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
   constexpr int RT = CROWS_SAMPLES;
-  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * RT;
+  const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * 2 * RT);
   float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
   auto next_task = [&]() -> int {
     int v = 0;

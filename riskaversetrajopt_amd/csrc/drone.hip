@@ -381,7 +381,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
     }
   }
   // this lane's slot in the tile-blocked Jacobian: tile = m0 / TILE, lane offset m0 % TILE
-  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * 2 * NOBS * RATO_TILE;
+  const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * 2 * NOBS * RATO_TILE);
   float* __restrict__ Gt = G + (m0 / RATO_TILE) * tile_floats + (m0 % RATO_TILE);
 
   int col[CPT];
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   lds_vint* prog = (lds_vint*)(head + 1);
   constexpr int RT = ROWS_SAMPLES;  // tile width: each row sweep below is one contiguous descending stream
   constexpr int RPP = FACT ? 2 : 2 * NOBS;  // tile rows per (t, s) pair
-  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * RPP * RT;
+  const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * RPP * RT);
   float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
 
   if (wave < 3) {

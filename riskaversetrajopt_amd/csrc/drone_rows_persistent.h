@@ -59,7 +59,7 @@ __global__ __launch_bounds__(PR_NW* RATO_WAVE) void drone_linearize_rows_persist
 
   constexpr int RT = ROWS_SAMPLES;
   constexpr int RPP = FACT ? 2 : 2 * NOBS;
-  const size_t tile_floats = (size_t)rato::pair_row_offset(S) * RPP * RT;
+  const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * RPP * RT);
   const int G_ = gridDim.x;
   // number of tiles this workgroup will process: units w, w + G, ...
   const int my_tiles = (n_units > (int)blockIdx.x) ? (n_units - 1 - (int)blockIdx.x) / G_ + 1 : 0;

@@ -114,6 +114,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Distance (in floats) between consecutive tiles of a packed, tile-blocked Jacobian whose tile holds `payload_floats`
+// numbers: tiles of 1 MiB or more start on 2 MiB boundaries (the buffer itself must be 2 MiB aligned), smaller tiles
+// are packed back to back.  Why: the row-parallel kernels keep one store stream per resident tile (512 at a time); with
+// the streams a power-of-two distance apart the memory system's address hash spreads them evenly over the channels --
+// store-only, 512 streams of 1.88 MB tiles: 5.1-5.2 TB/s at the natural stride, 5.7 at 2 MiB (tools/store_pattern5.hip).
+// ONE rule, computed from the tile shape alone, used by every producer and consumer of the layout and exported as
+// rato_packed_tile_stride() for whoever allocates the buffer.
+#ifndef RATO_PACKED_ALIGN_BYTES
+#define RATO_PACKED_ALIGN_BYTES (2u << 20)   // A/B builds only (tools/): another alignment
+#endif
+#ifndef RATO_PACKED_MIN_BYTES
+#define RATO_PACKED_MIN_BYTES (1u << 20)     // A/B builds only: a huge value = tiles always back to back
+#endif
+__host__ __device__ __forceinline__ size_t packed_tile_stride(size_t payload_floats) {
+  constexpr size_t PAGE = (size_t)RATO_PACKED_ALIGN_BYTES / sizeof(float);
+  return payload_floats * sizeof(float) >= (size_t)RATO_PACKED_MIN_BYTES ? (payload_floats + PAGE - 1) / PAGE * PAGE
+                                                                          : payload_floats;
+}
+
 // pair(t, s) = t(t-1)/2 + s for 0 <= s < t  (row-major causal packing)
 __host__ __device__ __forceinline__ int pair_row_offset(int t) { return (t * (t - 1)) >> 1; }
 

@@ -235,7 +235,10 @@ class Model:
                 return t
             return self._empty(*shape)
 
-        G = reuse("G", (num_tiles(M, tile), max(num_pairs(S), 1), 2, tile))
+        g_shape = (num_tiles(M, tile), max(num_pairs(S), 1), 2, tile)
+        G = o.get("G")               # packed Jacobian: tiles of >= 1 MiB start on 2 MiB boundaries (_lib.packed_buffer)
+        if not (_lib.is_packed_layout(G, g_shape) and G.dtype == torch.float32):
+            G = _lib.packed_buffer(g_shape, self.device)
         g_up = reuse("g_up", (S, M))
         Z = reuse("Z", (M,)) if want_Z else None
         final_du = reuse("final_du", (4, n_u * S))

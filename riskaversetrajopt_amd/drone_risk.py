@@ -267,7 +267,10 @@ class Model:
                 return t
             return alloc()
 
-        G = reuse("G", g_shape, lambda: self._empty(*g_shape))
+        # the packed Jacobian: tiles of >= 1 MiB start on 2 MiB boundaries (a strided view; _lib.packed_buffer)
+        G = o.get("G")
+        if not (_lib.is_packed_layout(G, g_shape) and G.dtype == torch.float32):
+            G = _lib.packed_buffer(g_shape, self.device)
         Wf = None
         if factored:
             Wf = reuse("_W", (n_obs, S, 2, ld), lambda: self._empty(n_obs, S, 2, ld))

@@ -274,3 +274,49 @@ def test_bad_arguments_are_rejected_not_computed():
     p = d._params(8, 8)
     assert lib.rato_drone_eval(C.byref(p), None, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, None,
                                _lib.current_stream()) == -1     # null input pointer
+
+
+def test_padded_tile_layout_is_shared_by_producer_and_consumers():
+    """Tiles of >= 1 MiB start on 2 MiB boundaries (rato_packed_tile_stride): the products output at S = 50 is such a
+    layout (1.88 MB per 64-sample tile).  The buffer linearize_device hands out has that stride and alignment, and
+    what the consumers read from it (untile, rato_saa_rowmax, rato_emit_csc_values) equals what they get from the
+    factored output of the same samples, whose tiles are packed back to back."""
+    import torch
+    from riskaversetrajopt_amd import _lib
+    from riskaversetrajopt_amd.drone_risk import untile, num_pairs
+    S, M = 50, 200
+    _, d = _models(S, M)
+    lib = d._lib
+    us = graze(S)
+    rp = d.linearize_device(us, factored=False)
+    rf = d.linearize_device(us, factored=True)
+    payload = num_pairs(S) * 2 * 3 * rp["tile"]
+    stride = lib.rato_packed_tile_stride(payload)
+    assert payload * 4 >= (1 << 20) and stride % ((2 << 20) // 4) == 0 and stride > payload
+    assert rp["G"].stride(0) == stride and rp["G"].data_ptr() % (2 << 20) == 0 and rp["G"][0].is_contiguous()
+    assert rf["G"].is_contiguous() and lib.rato_packed_tile_stride(num_pairs(S) * 2 * rf["tile"]) == num_pairs(S) * 2 * rf["tile"]
+    # the same Jacobian through both representations
+    Gp, Gf = d.packed_jacobian(rp), d.packed_jacobian(rf)                   # (n_pairs, 2, n_obs, M)
+    scale = Gp.abs().max().item()
+    assert (Gp - Gf).abs().max().item() <= 2e-6 * scale
+    # a buffer of an earlier call is reused only in this layout
+    again = d.linearize_device(us, factored=False, out=rp)
+    assert again["G"].data_ptr() == rp["G"].data_ptr()
+    wrong = dict(rp, G=torch.empty(tuple(rp["G"].shape), device=rp["G"].device))     # back-to-back tiles: not the layout
+    fresh = d.linearize_device(us, factored=False, out=wrong)
+    assert fresh["G"].data_ptr() != wrong["G"].data_ptr() and fresh["G"].stride(0) == stride
+    # consumers: rowmax and CSC emission from the padded products buffer == from the factored one
+    ld = rp["_g_up"].shape[-1]
+    u_dev = torch.as_tensor((us + 0.1).astype(np.float32), device=rp["G"].device).contiguous()
+    res = []
+    for r in (rp, rf):
+        m = torch.empty(M, dtype=torch.float32, device=u_dev.device)
+        a = torch.empty(M, dtype=torch.int32, device=u_dev.device)
+        _lib.check(lib.rato_saa_rowmax(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), r["tile"], 3, S, M, ld, _lib.ptr(r["_g_up"]),
+                                       _lib.ptr(u_dev), 3, _lib.ptr(m), _lib.ptr(a), _lib.current_stream()), "rowmax")
+        vals = torch.empty(M * 3 * 2 * num_pairs(S), dtype=torch.float32, device=u_dev.device)
+        _lib.check(lib.rato_emit_csc_values(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), ld, r["tile"], 2, 3, S, M, 0.01,
+                                            _lib.ptr(vals), _lib.current_stream()), "emit_csc")
+        res.append((m.cpu().numpy(), vals.cpu().numpy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5 * max(1.0, np.abs(res[1][0]).max()))
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=2e-6 * 0.01 * scale)
