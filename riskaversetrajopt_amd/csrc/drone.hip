@@ -1194,10 +1194,11 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         const int per_wg = (n_tiles + slots - 1) / slots;
         grid = (n_tiles + per_wg - 1) / per_wg;   // <= slots: every workgroup is resident from the start
         stride = grid;
-      } else if (dynamic_env == 1 ? (W != nullptr || n_tiles <= 4 * slots) : (dynamic_env > 1)) {
+      } else if (dynamic_env >= 1) {
         // Measured, same box, alternating (profiles/r02_ab_rows.txt): factored output -7 % at M = 1e5, -9 % at M = 1e6;
-        // products output -1.5 % at M = 1e5, 0 at 2e5, +1.3 % at 4e5, +5 % at 1e6 -> products only up to 4 rounds.
-        // (RATO_ROWS_DYNAMIC=2 forces the queue for every large batch.)
+        // products output -1.5 % at M = 1e5, and -- since its tiles start on 2 MiB boundaries (rato_packed_tile_stride)
+        // -- also at large batches: M = 4e5 2.148 / 2.147 ms against 2.176 / 2.213 static, M = 1e6 5.298 / 5.369 against
+        // 5.344 / 5.477 (tools/ab_big_products.sh; with the tiles back to back the queue had cost +1.3 % / +5 % there).
         // 64 two-word queues in device memory, handed out round robin: launches that overlap on different streams get
         // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
         queue = take_tile_queue(st);
