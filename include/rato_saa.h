@@ -75,6 +75,9 @@ int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
 size_t rato_packed_tile_stride(size_t payload_floats);
+/* floats a packed buffer of n_tiles such tiles needs (n_tiles * stride): what to allocate for G -- the linearize entry
+ * points take no buffer sizes, so a G allocated as n_tiles * payload_floats is overrun when the tiles are padded */
+size_t rato_packed_buffer_floats(size_t n_tiles, size_t payload_floats);
 
 /* Diagnostic (no reference counterpart): the shader clock the device sustains at this moment -- shader-cycle counter
  * against the constant 100 MHz counter over `us` microseconds (1..100000), one wave.  out3 (device, 3 doubles) =

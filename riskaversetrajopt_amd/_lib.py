@@ -29,6 +29,7 @@ class CarParams(C.Structure):
 SIGNATURES = {
     "rato_abi_version": (C.c_int, []),
     "rato_packed_tile_stride": (C.c_size_t, [C.c_size_t]),
+    "rato_packed_buffer_floats": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "rato_device_clock_probe": (C.c_int, [c_float_p, C.c_int32, c_stream]),
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -185,7 +186,7 @@ def packed_buffer(shape, device):
     if stride == payload:
         return torch.empty(tuple(shape), dtype=torch.float32, device=device)
     pad = PACKED_ALIGN_BYTES // 4
-    flat = torch.empty(int(shape[0]) * stride + pad, dtype=torch.float32, device=device)
+    flat = torch.empty(int(load().rato_packed_buffer_floats(int(shape[0]), payload)) + pad, dtype=torch.float32, device=device)
     off = (-(flat.data_ptr() // 4)) % pad
     strides = [stride]
     acc = payload

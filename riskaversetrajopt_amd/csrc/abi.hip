@@ -5,6 +5,10 @@ extern "C" int rato_abi_version(void) { return RATO_ABI_VERSION; }
 
 extern "C" size_t rato_packed_tile_stride(size_t payload_floats) { return rato::packed_tile_stride(payload_floats); }
 
+extern "C" size_t rato_packed_buffer_floats(size_t n_tiles, size_t payload_floats) {
+  return n_tiles * rato::packed_tile_stride(payload_floats);
+}
+
 // Diagnostic: the shader clock the device sustains right now.  One wave reads the shader-cycle counter (s_memtime)
 // and the constant 100 MHz counter (s_memrealtime) `us` microseconds apart: sclk = cycles / elapsed.  (Calibrated
 // against a chain of dependent fp32 FMAs, 7 cycles each: tools/clock_probe.py.)  bench.py reports it beside the
