@@ -52,15 +52,16 @@ def parse():
                     help="BASELINE.json configuration: metric = drone M=1e5 S=50 (the one the metric is quoted on); "
                          "C2 drone M=1e4 S=50; C3 driving M=1e4 S=40; C4 hopper M=5e4 S=60; C5 driving 125,000 "
                          "samples per GPU, S=40 (M=1e6 over 8 GPUs).  --workload/--M/--S override.")
-    ap.add_argument("--jacobian", default="both", choices=["both", "products", "factored"],
+    ap.add_argument("--jacobian", default="both", choices=["both", "products", "factored", "regenerated"],
                     help="drone linearize: representation the kernel writes.  products = every structural nonzero, "
                          "3S(S-1) numbers per sample (SURVEY 8d; this is what `value` and `roofline` are quoted on); "
-                         "factored = W[j,t,a] * Phi[t,s,a], S(S-1)+6S numbers (reported as *_factored); both = one "
-                         "timed region each, same samples")
+                         "factored = W[j,t,a] * Phi[t,s,a], S(S-1)+6S numbers (reported as *_factored); regenerated = the "
+                         "products output with the noise regenerated in the kernel instead of read (*_regenerated); both "
+                         "= one timed region for each of the three, same samples")
     ap.add_argument("--philox", action="store_true",
-                    help="--mode eval (drone, driving): no noise array in HBM, the Brownian increments are regenerated "
-                         "inside the rollout kernel (Philox4x32-10, rato_*_eval_philox); the algorithmic bytes drop from "
-                         "12 + 56/S (8 + 28/S) to 56/S (28/S) per sample-step")
+                    help="drone, driving: no noise array in HBM, the Brownian increments are regenerated inside the "
+                         "kernels (Philox4x32-10: rato_*_eval_philox, rato_*_linearize_philox); the algorithmic bytes "
+                         "lose the 12 (8) B per sample-step of the noise")
     ap.add_argument("--no-scp", action="store_true", help="skip the SCP wall-clock block (drone, N=1)")
     ap.add_argument("--scp-iters", type=int, default=60)
     ap.add_argument("--dry-run", action="store_true", help="rank start-up + barrier only (no GPU work)")
@@ -104,7 +105,7 @@ class DroneWork:
         self.mode = args.mode
         self.cpt, self.spl = args.cols_per_thread, args.samples_per_lane
         self.fact = False if args.packed_products else (True if getattr(args, "force_factored", False) else None)
-        self.philox = bool(getattr(args, "philox", False)) and args.mode == "eval"
+        self.philox = bool(getattr(args, "philox", False))      # noise regenerated in the kernels instead of read
         dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device,
                                                                         want_dW=not self.philox)
         self.model = drone_risk.Model.from_device(self.S, dW, mass, Qsym, 'saa', args.alpha, M=self.M,
@@ -119,8 +120,9 @@ class DroneWork:
             # i%2 while step i+1 writes the other slot
             self.outs = [r, self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
                                                         factored=self.fact)]
-            self.variant = "cols_per_thread=%d samples_per_lane=%d jacobian=%s" % (
-                r["cols_per_thread"], r["samples_per_lane"], "factored(W,Phi)" if self.fact else "products")
+            self.variant = "cols_per_thread=%d samples_per_lane=%d jacobian=%s%s" % (
+                r["cols_per_thread"], r["samples_per_lane"], "factored(W,Phi)" if self.fact else "products",
+                " noise=regenerated(Philox4x32-10)" if self.philox else "")
             self.kernel = "drone_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "drone_linearize_kernel"
             # the kernels write Z and the partial sums straight into the record the all-gather sends (dist.Record)
             from riskaversetrajopt_amd import dist as rdist
@@ -163,7 +165,8 @@ class DroneWork:
         # Jacobian as written: products (3S(S-1) numbers per sample) or its two factors
         # Phi[t,s,a] (S(S-1)) and W[j,t,a] (6S) -- the bytes the launch really has to move
         jac = (S * (S - 1) + 6 * S) if self.fact else 3 * S * (S - 1)
-        return eval_in + M * B * (3 * S + jac) + nblk * (6 * S + 6) * B       # g_up, Jacobian | partials
+        noise = M * B * 3 * S if self.philox else 0                            # not read when it is regenerated
+        return eval_in - noise + M * B * (3 * S + jac) + nblk * (6 * S + 6) * B       # g_up, Jacobian | partials
 
     def cpu_baseline(self, n, alpha):
         """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples; dense outputs in the
@@ -195,7 +198,7 @@ class DrivingWork:
         self.M = args.M or 100000
         self.mode = args.mode
         self.cpt = args.cols_per_thread
-        self.philox = bool(getattr(args, "philox", False)) and args.mode == "eval"
+        self.philox = bool(getattr(args, "philox", False))
         dW, x0, ws, wr = driving.sample_uncertain_parameters_device(self.M, self.S, seed=seed, device=device,
                                                                     want_dW=not self.philox)
         self.model = driving.Model.from_device(self.S, dW, x0, ws, wr, 'saa', args.alpha,
@@ -213,7 +216,8 @@ class DrivingWork:
                 rec = rdist.Record(0, self.M, device)
                 o["Z"] = rec.Z
                 self.records.append(rec)
-            self.variant = "cols_per_thread=%d" % r["cols_per_thread"]
+            self.variant = "cols_per_thread=%d%s" % (r["cols_per_thread"],
+                                                     " noise=regenerated(Philox4x32-10)" if self.philox else "")
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
             self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_kernel"
@@ -240,7 +244,7 @@ class DrivingWork:
         eval_in = M * B * (2 * S + 6 + 1) + 2 * S * B
         if self.mode == "eval":
             return eval_in - (M * B * 2 * S if self.philox else 0)
-        return eval_in + M * B * (S + S * (S - 1))
+        return eval_in - (M * B * 2 * S if self.philox else 0) + M * B * (S + S * (S - 1))
 
     def cpu_baseline(self, n, alpha):
         from oracle import driving as ocar, stats as ostats
@@ -588,11 +592,15 @@ def main():
     is_drone_lin = args.workload == "drone" and args.mode == "linearize"
     variants = [None]
     if is_drone_lin:
-        variants = {"products": ["products"], "factored": ["factored"], "both": ["products", "factored"]}[args.jacobian]
+        # "regenerated": the products output with the noise regenerated while a tile is staged (rato_drone_linearize_philox)
+        variants = {"products": ["products"], "factored": ["factored"], "regenerated": ["regenerated"],
+                    "both": ["products", "factored", "regenerated"]}[args.jacobian]
     results = []
+    base_philox = bool(args.philox)
     for var in variants:
-        args.packed_products = (var == "products")
+        args.packed_products = var in ("products", "regenerated")
         args.force_factored = (var == "factored")
+        args.philox = base_philox or var == "regenerated"
         work = WORKLOADS[args.workload](args, device, seed=1000 * rank + 7)
         res = timed_region(work, args, world, rank, device, stats, rdist, dist, torch)
         res["work"], res["variant"] = work, var
@@ -621,7 +629,7 @@ def main():
                        "baseline_config": args.config,
                        "M_per_gpu": M, "S": S, "M_total": world * M,
                        "value_is_for": ("the SURVEY 8(d) contract: every structural nonzero of the Jacobian written "
-                                        "(3S(S-1) numbers per sample)" if jacobian == "products" else
+                                        "(3S(S-1) numbers per sample)" if jacobian in ("products", "regenerated") else
                                         ("the factored Jacobian (Phi, W): S(S-1)+6S numbers per sample"
                                          if jacobian == "factored" else "the whole step")),
                        "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step "

@@ -398,6 +398,13 @@ int rato_drone_sample(int64_t M, int64_t ld, int32_t S, float sampler_dt, uint64
 /* rato_drone_eval with the noise of rato_drone_sample(seed, sampler_dt) regenerated in the kernel (no dW array). */
 int rato_drone_eval_philox(const rato_drone_params* p, const float* us, uint64_t seed, float sampler_dt,
                            const float* mass, const float* Qsym, float* Z, float* xs, float* g, void* stream);
+/* rato_drone_linearize (row-parallel kernel, cols_per_thread = -1: S <= 126) with the noise of
+ * rato_drone_sample(seed, sampler_dt) regenerated while a tile is staged: bit for bit the outputs of rato_drone_linearize
+ * on the materialised dW, without the array and without its reads in the middle of the store stream (the reads are
+ * 2 % of the bytes of the products output but cost 3-8 % of the kernel's time: DESIGN.md 4.1). */
+int rato_drone_linearize_philox(const rato_drone_params* p, const float* us, uint64_t seed, float sampler_dt,
+                                const float* mass, const float* Qsym, float* G, float* W, float* A22, float* g_up,
+                                float* Z, float* part, void* stream);
 
 /* driving.py:84-120: dW [S][2][M], x0_ped [4][M] = x0_mean + x0_std * N(0,1) (HOST float[4] each), w_speed, w_rep [M]
  * ~ U(nom -+ del).  dW may be NULL; the three parameter arrays may all be NULL. */
@@ -407,6 +414,11 @@ int rato_car_sample(int64_t M, int32_t S, float sampler_dt, uint64_t seed, float
 int rato_car_eval_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
                          const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch, float* Z,
                          float* xs, float* g, void* stream);
+/* rato_car_linearize (row-parallel kernel, cols_per_thread = -1) with the noise of rato_car_sample(seed, sampler_dt)
+ * regenerated while a tile is staged: bit for bit the outputs of rato_car_linearize on the materialised dW. */
+int rato_car_linearize_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
+                              const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch,
+                              float* G, float* g_up, float* Z, float* final_du, float* final_rhs, void* stream);
 
 /* hopper.py:70-74: a = 0.025 sqrt(2/30) U(0,1), theta = pi U(0,1), tau = 2 pi U(0,1), each [30][M]. */
 int rato_hopper_sample(int64_t M, uint64_t seed, float* a, float* theta, float* tau, void* stream);

@@ -80,10 +80,14 @@ SIGNATURES = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), c_stream]),
     "rato_drone_sample": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_float, C.c_float,
                                     C.POINTER(C.c_float), C.c_float, c_float_p, c_float_p, c_float_p, c_stream]),
+    "rato_drone_linearize_philox": (C.c_int, [C.POINTER(DroneParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 8
+                                    + [c_stream]),
     "rato_drone_eval_philox": (C.c_int, [C.POINTER(DroneParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 5 +
                                [c_stream]),
     "rato_car_sample": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64] + [C.c_float] * 4 +
                         [C.POINTER(C.c_float), C.POINTER(C.c_float)] + [c_float_p] * 4 + [c_stream]),
+    "rato_car_linearize_philox": (C.c_int, [C.POINTER(CarParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 9
+                                  + [c_stream]),
     "rato_car_eval_philox": (C.c_int, [C.POINTER(CarParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 7 +
                              [c_stream]),
     "rato_hopper_sample": (C.c_int, [C.c_int64, C.c_uint64, c_float_p, c_float_p, c_float_p, c_stream]),

@@ -375,9 +375,12 @@ __host__ __device__ inline size_t car_rows_lds_floats(int S) {
          (size_t)(S + 1) * 2 + 32 + (size_t)(S + 1) * 6 + 2;
 }
 
-template <bool LOOP>   // LOOP: several tiles per workgroup through the global tile queue (large batches)
+// LOOP: several tiles per workgroup through the global tile queue (large batches).
+// PHILOX: the tile's noise is regenerated while it is staged (the numbers rato_car_sample would have written) instead
+// of read: no noise array, no reads in the middle of the store stream.
+template <bool LOOP, bool PHILOX = false>
 __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel(
-    rato_car_params P, const float* __restrict__ us, const float* __restrict__ dW,
+    rato_car_params P, uint64_t seed, float noise_scale, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
     float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole) {
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   constexpr int MAXR = 16;
   const int nrows = 2 * S;
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
-  if (!LOOP) {
+  if (!LOOP && !PHILOX) {
     const size_t mr = (size_t)((int)blockIdx.x / split) * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
@@ -505,19 +508,30 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   __syncthreads();
   {
     float* QPf = reinterpret_cast<float*>(QP);
-    if (LOOP) {
+    if (PHILOX) {
+      for (int t = wave; t < S; t += CROWS_NW) {
+        const rato::u32x4 rr = rato::philox_at(seed, rato::PHILOX_STREAM_DW, (uint32_t)t, (uint64_t)m);
+        float x0, x1;
+        rato::box_muller(rr.x, rr.y, x0, x1);
+        QPf[(t * CROWS_SAMPLES + lane) * 2 + 0] = x0 * noise_scale;
+        QPf[(t * CROWS_SAMPLES + lane) * 2 + 1] = x1 * noise_scale;
+      }
+    }
+    if (LOOP && !PHILOX) {
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = wave + i * CROWS_NW;
         tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
       }
     }
+    if (!PHILOX) {
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-      const int r = wave + i * CROWS_NW;
-      if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp0[i];
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = wave + i * CROWS_NW;
+        if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp0[i];
+      }
     }
-    for (int r0 = wave + CROWS_NW * MAXR; r0 < nrows; r0 += CROWS_NW * MAXR) {   // long horizons: further batches
+    for (int r0 = wave + CROWS_NW * MAXR; !PHILOX && r0 < nrows; r0 += CROWS_NW * MAXR) {   // long horizons: further batches
       float tmp[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -778,16 +792,19 @@ extern "C" int rato_car_linearize_plan(int32_t M, int32_t S, int32_t* cols_per_t
   return (c == -1) ? (M + CROWS_SAMPLES - 1) / CROWS_SAMPLES : rato::nblocks_for(M);
 }
 
-extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, const float* dW,
-                                  const float* x0_ped, const float* w_speed, const float* w_rep,
-                                  float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
-                                  float* final_rhs, int32_t cols_per_thread, void* stream) {
+namespace {
+// dW == NULL: the noise is regenerated from (seed, noise_scale) -- the row-parallel kernel only
+int car_linearize_impl(const rato_car_params* p, const float* us, const float* dW, uint64_t seed, float noise_scale,
+                       const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch, float* G,
+                       float* g_up, float* Z, float* final_du, float* final_rhs, int32_t cols_per_thread,
+                       void* stream) {
   RATO_CLEAR_ERROR();
-  if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
+  if (!params_ok(p) || !us || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
     return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
   int32_t spt = cols_per_thread, tile = 0;
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
+  if (!dW && spt != -1) return RATO_EINVAL;
   // the ego prologue (trajectory + per-step tangents Epos, Eu) serves the forward/column kernel; the row-parallel
   // kernel builds its ego tables itself, under the latency of its noise loads
   if (spt != -1)
@@ -797,11 +814,13 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     const size_t lds = car_rows_lds_bytes(p->S);
     static std::atomic<size_t> lds_attr_set{64 * 1024};   // cached: capture-safe after the first call
     if (lds > lds_attr_set.load()) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(car_linearize_rows_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipSuccess;
+      const void* kernels[4] = {reinterpret_cast<const void*>(car_linearize_rows_kernel<false, false>),
+                                reinterpret_cast<const void*>(car_linearize_rows_kernel<true, false>),
+                                reinterpret_cast<const void*>(car_linearize_rows_kernel<false, true>),
+                                reinterpret_cast<const void*>(car_linearize_rows_kernel<true, true>)};
+      for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
       lds_attr_set.store(lds);
     }
@@ -862,11 +881,19 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
       int tail_tiles = tail_tiles_env >= 0 ? tail_tiles_env : slots / 2;
       if (tail_tiles > n_tiles) tail_tiles = n_tiles;
       const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
-      hipLaunchKernelGGL(car_linearize_rows_kernel<true>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
+      if (dW)
+        hipLaunchKernelGGL((car_linearize_rows_kernel<true, false>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
+                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
+      else
+        hipLaunchKernelGGL((car_linearize_rows_kernel<true, true>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
+                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
     } else {
-      hipLaunchKernelGGL(car_linearize_rows_kernel<false>, grid, block, lds, st, *p, us, dW, x0_ped, w_speed, w_rep,
-                         final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
+      if (dW)
+        hipLaunchKernelGGL((car_linearize_rows_kernel<false, false>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
+                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
+      else
+        hipLaunchKernelGGL((car_linearize_rows_kernel<false, true>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
+                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
     }
     RATO_LAUNCH_CHECK();
     return RATO_OK;
@@ -877,4 +904,23 @@ extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, con
     case 16: return launch_car_linearize<16>(p, dW, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, st);
     default: return RATO_EINVAL;
   }
+}
+}  // namespace
+
+extern "C" int rato_car_linearize(const rato_car_params* p, const float* us, const float* dW,
+                                  const float* x0_ped, const float* w_speed, const float* w_rep,
+                                  float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
+                                  float* final_rhs, int32_t cols_per_thread, void* stream) {
+  if (!dW) return RATO_EINVAL;
+  return car_linearize_impl(p, us, dW, 0, 0.0f, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, final_du, final_rhs,
+                            cols_per_thread, stream);
+}
+
+extern "C" int rato_car_linearize_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
+                                         const float* x0_ped, const float* w_speed, const float* w_rep,
+                                         float* ego_scratch, float* G, float* g_up, float* Z, float* final_du,
+                                         float* final_rhs, void* stream) {
+  if (!(sampler_dt > 0.0f)) return RATO_EINVAL;
+  return car_linearize_impl(p, us, nullptr, seed, sqrtf(sampler_dt), x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z,
+                            final_du, final_rhs, -1, stream);
 }

@@ -637,10 +637,12 @@ __host__ __device__ inline size_t rows_lds_floats(int S) {
 // gradient of g wrt position) and Phi = d p_{t+1,a} / d u_{s,a} SHARED by the three obstacles, so the same
 // information is S(S-1) + 6S numbers per sample instead of 3S(S-1): 2.67x less HBM traffic at S = 50, for
 // this kernel and for every consumer that reads the Jacobian (rowmax / tail-rows oracle, CSC emission).
-template <bool FACT>
+// PHILOX: the tile's noise is REGENERATED while staging (Philox4x32-10 at counter (m, t), the numbers rato_drone_sample
+// would have written) instead of read: no noise array, no reads mixed into the store stream.
+template <bool FACT, bool PHILOX = false>
 __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_linearize_rows_kernel(
     rato_drone_params P, int n_whole, int split, int tile_stride, int n_tiles_total, unsigned* __restrict__ tile_queue,
-    const float* __restrict__ us, const float* __restrict__ dW,
+    uint64_t seed, float noise_scale, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
     float* __restrict__ part) {
@@ -698,12 +700,27 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     float* PPf = reinterpret_cast<float*>(PP);
     const int nrows = 3 * S;
     constexpr int MAXR = (160 + ROWS_NW - 1) / ROWS_NW;  // rows per wave per batch: S = 50 needs 150 / 8 = 19 -> one batch, all loads in flight
-    for (int r0 = wave; r0 < nrows; r0 += ROWS_NW * MAXR) {
+    if (PHILOX) {
+      for (int t = wave; t < S; t += ROWS_NW) {
+        const rato::u32x4 rr = rato::philox_at(seed, rato::PHILOX_STREAM_DW, (uint32_t)t, (uint64_t)m);
+        float x0, x1, x2, x3;
+        rato::box_muller(rr.x, rr.y, x0, x1);
+        rato::box_muller(rr.z, rr.w, x2, x3);
+        PPf[(t * ROWS_SAMPLES + lane) * 2 + 0] = x0 * noise_scale;
+        PPf[(t * ROWS_SAMPLES + lane) * 2 + 1] = x1 * noise_scale;
+        AZ[t * ROWS_SAMPLES + lane] = x2 * noise_scale;
+      }
+    }
+    for (int r0 = wave; !PHILOX && r0 < nrows; r0 += ROWS_NW * MAXR) {
       float tmp[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = r0 + i * ROWS_NW;
+#if RATO_DIAG == 5   // diagnostic: no noise reads at all (a cheap hash instead): what do the reads cost beside the stores?
+        tmp[i] = 0.01f * (float)((int)((r * 2654435761u + (unsigned)m * 40503u) >> 20) - 2048) * (1.0f / 2048.0f);
+#else
         tmp[i] = (r < nrows) ? dW[(size_t)r * ld + m] : 0.0f;
+#endif
       }
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -1079,14 +1096,16 @@ extern "C" int rato_drone_linearize_plan(int32_t M, int32_t S, int32_t ld, int32
   return (M + RATO_BLOCK * *samples_per_lane - 1) / (RATO_BLOCK * *samples_per_lane);
 }
 
-extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
-                                    const float* mass, const float* Qsym, float* G, float* W, float* A22,
-                                    float* g_up, float* Z, float* part, int32_t cols_per_thread,
-                                    int32_t samples_per_lane, void* stream) {
+namespace {
+// dW == NULL: the noise is regenerated from (seed, noise_scale) -- the row-parallel kernel only
+int drone_linearize_impl(const rato_drone_params* p, const float* us, const float* dW, uint64_t seed, float noise_scale,
+                         const float* mass, const float* Qsym, float* G, float* W, float* A22, float* g_up, float* Z,
+                         float* part, int32_t cols_per_thread, int32_t samples_per_lane, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!params_ok(p) || !us || !dW || !mass || !Qsym || !G || !g_up || !part) return RATO_EINVAL;
+  if (!params_ok(p) || !us || !mass || !Qsym || !G || !g_up || !part) return RATO_EINVAL;
   int32_t cpt = cols_per_thread, spl = samples_per_lane;
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
+  if (!dW && cpt != -1) return RATO_EINVAL;
   if (W && cpt != -1) return RATO_EINVAL;  // the factored output exists for the row-parallel kernel only
   if (A22 && !W) return RATO_EINVAL;       // the step-Jacobian table goes with the factored output
   hipStream_t st = rato::as_stream(stream);
@@ -1097,11 +1116,13 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
     static std::atomic<size_t> lds_attr_set{64 * 1024};
     static std::atomic<int> cu_count{0};
     if (lds > lds_attr_set.load()) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipSuccess;
+      const void* kernels[4] = {reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, false>),
+                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, false>),
+                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, true>),
+                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, true>)};
+      for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return RATO_EHIP - (int)e;
       lds_attr_set.store(lds);
     }
@@ -1126,7 +1147,8 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
     // S = 50, alternating: products 0.559-0.608 -> 0.569-0.617 ms, factored 0.224-0.255 -> 0.246-0.269 ms; balanced
     // grids of 224 / 196 workgroups no better) -- profiles/r02_ab_rows.txt.  Off by default, kept for A/B runs and
     // covered by a bit-identity test against the default kernel (RATO_ROWS_PERSISTENT=1).
-    static const int persistent = [] { const char* e = getenv("RATO_ROWS_PERSISTENT"); return e ? atoi(e) : 0; }();
+    static const int persistent_knob = [] { const char* e = getenv("RATO_ROWS_PERSISTENT"); return e ? atoi(e) : 0; }();
+    const int persistent = dW ? persistent_knob : 0;   // the A/B kernel reads a materialised noise array
     const size_t lds_p = rowsp_lds_floats(p->S) * sizeof(float);
     if (persistent && lds_p <= ROWS_LDS_MAX && n_tiles >= 2 * cus) {
       static std::atomic<size_t> lds_attr_set_p{64 * 1024};
@@ -1223,12 +1245,15 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
         }
       }
     }
-    if (W)
-      hipLaunchKernelGGL(drone_linearize_rows_kernel<true>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole,
-                         split, stride, n_tiles, queue, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
-    else
-      hipLaunchKernelGGL(drone_linearize_rows_kernel<false>, dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p,
-                         n_whole, split, stride, n_tiles, queue, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
+#define RATO_ROWS_LAUNCH(F, PH)                                                                                    \
+  hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole, \
+                     split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, Z, part)
+    if (W) {
+      if (dW) RATO_ROWS_LAUNCH(true, false); else RATO_ROWS_LAUNCH(true, true);
+    } else {
+      if (dW) RATO_ROWS_LAUNCH(false, false); else RATO_ROWS_LAUNCH(false, true);
+    }
+#undef RATO_ROWS_LAUNCH
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
@@ -1244,4 +1269,22 @@ extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us,
   RATO_CASE(4, 4);
 #undef RATO_CASE
   return RATO_EINVAL;
+}
+}  // namespace
+
+extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
+                                    const float* mass, const float* Qsym, float* G, float* W, float* A22,
+                                    float* g_up, float* Z, float* part, int32_t cols_per_thread,
+                                    int32_t samples_per_lane, void* stream) {
+  if (!dW) return RATO_EINVAL;
+  return drone_linearize_impl(p, us, dW, 0, 0.0f, mass, Qsym, G, W, A22, g_up, Z, part, cols_per_thread,
+                              samples_per_lane, stream);
+}
+
+extern "C" int rato_drone_linearize_philox(const rato_drone_params* p, const float* us, uint64_t seed,
+                                           float sampler_dt, const float* mass, const float* Qsym, float* G, float* W,
+                                           float* A22, float* g_up, float* Z, float* part, void* stream) {
+  if (!(sampler_dt > 0.0f)) return RATO_EINVAL;
+  return drone_linearize_impl(p, us, nullptr, seed, sqrtf(sampler_dt), mass, Qsym, G, W, A22, g_up, Z, part, -1, 0,
+                              stream);
 }

@@ -219,8 +219,6 @@ class Model:
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
-        if dW is None:
-            raise _lib.RatoError("the linearization kernels read a materialised dW (this Model regenerates its noise)")
         M, S = ws.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}
@@ -228,6 +226,9 @@ class Model:
         if self._lib.rato_car_linearize_plan(M, S, C.byref(cpt), C.byref(tile)) < 0:
             raise _lib.RatoError(f"no car linearize variant for cols_per_thread={cols_per_thread}, S={S}")
         cols_per_thread, tile = cpt.value, tile.value
+        if dW is None and cols_per_thread != -1:
+            raise _lib.RatoError("a Model that regenerates its noise linearizes with the row-parallel kernel only "
+                                 "(cols_per_thread=-1); the column kernel reads a materialised dW")
         def reuse(key, shape):
             """a buffer of an earlier call is reused only if it has exactly the shape this launch writes"""
             t = o.get(key)
@@ -244,10 +245,16 @@ class Model:
         final_du = reuse("final_du", (4, n_u * S))
         final_rhs = reuse("final_rhs", (4,))
         p = self._params(M)
-        _lib.check(self._lib.rato_car_linearize(
-            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
-            _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
-            _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
+        if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
+            _lib.check(self._lib.rato_car_linearize_philox(
+                C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
+                _lib.ptr(final_rhs), _lib.current_stream()), "rato_car_linearize_philox")
+        else:
+            _lib.check(self._lib.rato_car_linearize(
+                C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
+                _lib.ptr(final_rhs), int(cols_per_thread), _lib.current_stream()), "rato_car_linearize")
         if self.check_finite:
             stats.assert_finite("driving linearize", g_up, Z, final_du, final_rhs)
         return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M,

@@ -246,11 +246,12 @@ class Model:
         reduction into the single launch of the risk statistics.
         """
         dW, mass, Qsym, M = self._inputs(inputs)
-        if dW is None:
-            raise _lib.RatoError("the linearization kernels read a materialised dW (this Model regenerates its noise)")
         ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
         nblk, cpt, spl, tile = self.linearize_plan(M, ld, cols_per_thread, samples_per_lane)
+        if dW is None and cpt != -1:
+            raise _lib.RatoError("a Model that regenerates its noise linearizes with the row-parallel kernel only "
+                                 "(cols_per_thread=-1, S <= 126); the column kernels read a materialised dW")
         if factored is None:
             factored = (cpt == -1)
         if factored and cpt != -1:
@@ -287,10 +288,16 @@ class Model:
         p = self._params(M, ld)
         if events is not None:
             events[0].record()
-        _lib.check(self._lib.rato_drone_linearize(
-            C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G), _lib.ptr(Wf),
-            _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
-            "rato_drone_linearize")
+        if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
+            _lib.check(self._lib.rato_drone_linearize_philox(
+                C.byref(p), _lib.ptr(us), self._noise_seed, self._sampler_dt, _lib.ptr(mass), _lib.ptr(Qsym),
+                _lib.ptr(G), _lib.ptr(Wf), _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part),
+                _lib.current_stream()), "rato_drone_linearize_philox")
+        else:
+            _lib.check(self._lib.rato_drone_linearize(
+                C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G), _lib.ptr(Wf),
+                _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), cpt, spl, _lib.current_stream()),
+                "rato_drone_linearize")
         if events is not None:
             events[1].record()
         if reduce:
