@@ -649,7 +649,10 @@ def main():
             line["value_" + res["variant"]] = world * M * unit_steps * args.steps / res["elapsed"]
             line["ms_per_step_" + res["variant"]] = 1e3 * res["elapsed"] / args.steps
         if world == 1 and is_drone_lin and not args.no_scp:
-            line["scp"] = scp_block(results[-1]["work"], args)
+            # on the resident samples of a variant that keeps its noise materialised (the reduced SCP reads it)
+            scp_work = next((r["work"] for r in reversed(results) if not r["work"].philox), None)
+            if scp_work is not None:
+                line["scp"] = scp_block(scp_work, args)
         if world == 1 and not args.no_cpu_baseline:
             n = args.cpu_samples or CPU_SAMPLES[args.workload]
             cpu_step = work.cpu_baseline(n, args.alpha)

@@ -320,6 +320,8 @@ class Model:
         Jacobian entries per sample (60 B instead of 245 B of HBM traffic per sample-step).  Same dict keys as
         ``linearize_device`` with G = None."""
         dW, mass, Qsym, M = self._inputs(inputs)
+        if dW is None:
+            raise _lib.RatoError("linearize_generators_device reads a materialised dW (this Model regenerates its noise)")
         ld, S = mass.numel(), self.S
         us = self._us_device(us_mat)
         o = out if out is not None else {}
