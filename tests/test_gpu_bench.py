@@ -1,0 +1,39 @@
+"""GPU: the driver's command line end to end at a small size — `python bench.py` with its default blocks (products,
+factored and regenerated-noise regions, SCP block, CPU baseline) prints exactly ONE JSON line carrying every block."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_blocks_at_a_small_size():
+    d = _run(["--M", "3000", "--S", "20", "--steps", "3", "--warmup", "1", "--scp-iters", "3"])
+    assert d["metric"] == "SAA constraint-eval throughput" and d["n_gpus"] == 1 and d["steps"] == 3
+    assert d["value"] > 0 and d["value_factored"] > 0 and d["value_regenerated"] > 0
+    for k in ("roofline", "roofline_factored", "roofline_regenerated"):
+        r = d[k]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["achieved"] > 0 and 0 < r["frac"] < 1
+    assert d["roofline_regenerated"]["algorithmic_bytes_per_launch"] < d["roofline"]["algorithmic_bytes_per_launch"]
+    assert d["scp"]["iters"] == 3 and d["scp"]["cumulative_s"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["device"]["sclk_mhz_beside_hot_kernel"] > 500
+
+
+@pytest.mark.parametrize("config", ["C3", "C4"])
+def test_other_configs_run(config):
+    d = _run(["--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["value"] > 0 and d["config"]["baseline_config"] == config and d["roofline"]["kernel_ms"] > 0
