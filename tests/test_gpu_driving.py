@@ -58,7 +58,7 @@ def test_rollout_and_distances_vs_oracle(S, M):
 
 @pytest.mark.parametrize("S,M,spt", [(20, 300, 0), (20, 100, 4), (20, 100, 8), (20, 100, 16), (40, 130, 0),
                                       (40, 70, 16), (33, 65, 8), (2, 5, 4), (1, 3, 0), (20, 300, -1), (40, 257, -1),
-                                      (33, 65, -1), (2, 5, -1), (120, 9, 0), (130, 5, 0)])
+                                      (33, 65, -1), (2, 5, -1), (120, 9, 0), (130, 5, 0), (70, 200, -1), (70, 300, 8)])
 def test_linearization_vs_oracle(S, M, spt):
     o, d = _models(S, M)
     us = swerve(S)
