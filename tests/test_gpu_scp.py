@@ -383,3 +383,21 @@ def test_monte_carlo_report_matches_oracle():
         assert abs(rep["avar"][i] - ostats.monte_carlo_avar(Z, alpha)) < 2e-4 * max(1.0, abs(rep["avar"][i]))
         assert abs(rep["cost"][i] - o.monte_carlo_cost(us)) < 1e-9 * max(1.0, rep["cost"][i])
     assert rep["avar_median"] == np.median(rep["avar"]) and rep["cost_mean"] == np.mean(rep["cost"])
+
+
+def test_device_emitted_csc_values_with_padded_tiles():
+    """the same check where the packed Jacobian's tiles are >= 1 MiB and therefore start on 2 MiB boundaries
+    (driving S = 70: 1.2 MB per 64-sample tile, three tiles): CSC emission and the cutting-plane oracle read the layout
+    the linearize kernel wrote"""
+    S, M = 70, 130
+    _, c = _car(M, S)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.4 * np.cos(0.4 * t) - 0.2, 0.05 * np.sin(0.35 * t) + 0.01]) * (20.0 / S)
+    r = c.linearize_device(us)
+    assert r["G"].stride(0) > r["G"][0].numel()                       # padded
+    for scp_iter in (0, 2):
+        A, l, u = c.get_constraints_coeffs(us, scp_iter)
+        Ah, lh, uh = c.get_constraints_coeffs_host(us, scp_iter)
+        assert np.array_equal(A.indptr, Ah.indptr) and np.array_equal(A.indices, Ah.indices)
+        np.testing.assert_allclose(A.data, Ah.data, rtol=3e-7, atol=1e-30)
+        np.testing.assert_allclose(u, uh, rtol=3e-7, atol=1e-12)
