@@ -113,6 +113,19 @@ def nnls_warm(A, b, passive0=None, maxiter=None):
     return y, P, False
 
 
+def _null_space(A):
+    """Orthonormal basis of the null space of a wide full-row-rank A (m x n, m << n) from one complete QR of A^T (the
+    SCP master: 6 x 151, tens of microseconds; scipy's SVD-based null_space took 0.23 ms of every SCP iteration);
+    rank-deficient or ill-conditioned rows fall back to the SVD."""
+    m, n = A.shape
+    if m < n:
+        Q, R = np.linalg.qr(A.T, mode='complete')
+        d = np.abs(np.diagonal(R))
+        if d.size and d.min() > 1e-10 * max(d.max(), 1e-300):
+            return Q[:, m:]
+    return sla.null_space(A)
+
+
 class Master:
     """The same solve with the equality elimination and the Cholesky whitening done ONCE, and inequality rows
     appended incrementally (a cutting-plane loop adds one row per iteration)."""
@@ -124,7 +137,7 @@ class Master:
         if A_eq is not None and len(A_eq):
             A_eq = np.asarray(A_eq, dtype=np.float64)
             self.x0 = np.linalg.lstsq(A_eq, np.asarray(b_eq, dtype=np.float64), rcond=None)[0]
-            self.N = sla.null_space(A_eq)
+            self.N = None                      # one SVD per Master: computed in the branch that uses it
         else:
             self.x0, self.N = np.zeros(n), np.eye(n)
         if np.count_nonzero(P - np.diag(np.diagonal(P))) == 0 and A_eq is not None and len(A_eq):
@@ -132,12 +145,14 @@ class Master:
             # then the null-space basis of the scaled equalities is orthonormal in the whitened metric, the reduced
             # Hessian is the identity and no Cholesky factorization is needed
             d = 1.0 / np.sqrt(np.diagonal(P))
-            Nt = sla.null_space(A_eq * d[None, :])                               # orthonormal, (A_eq D^-1/2) Nt = 0
+            Nt = _null_space(A_eq * d[None, :])                                  # orthonormal, (A_eq D^-1/2) Nt = 0
             self.N = d[:, None] * Nt
             self.L = None
             self.Linv_c = self.N.T @ (P @ self.x0 + q)                           # H = I
             self.NLinvT = self.N
         else:
+            if self.N is None:
+                self.N = _null_space(A_eq)
             H = self.N.T @ P @ self.N
             c = self.N.T @ (P @ self.x0 + q)
             self.L = np.linalg.cholesky(H)
