@@ -1140,6 +1140,9 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     int per_cu = (int)(ROWS_LDS_MAX / lds);
     if (per_cu > 32 / ROWS_NW) per_cu = 32 / ROWS_NW;
     if (per_cu < 1) per_cu = 1;
+    // RATO_ROWS_SLOTS_PER_CU: A/B knob -- fewer queue workgroups than the LDS allows (one per CU = 256 store streams)
+    static const int slots_env = [] { const char* e = getenv("RATO_ROWS_SLOTS_PER_CU"); return e ? atoi(e) : 0; }();
+    if (slots_env >= 1 && slots_env < per_cu) per_cu = slots_env;
     const int slots = cus * per_cu;
     const int n_tiles = (p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
     // Resident workgroups with double-buffered tables (drone_rows_persistent.h): built to hide the staging + rollout of
@@ -1225,7 +1228,14 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
         // different queues; each launch leaves its queue zeroed.  (Address looked up once, outside any capture.)
         queue = take_tile_queue(st);
         if (queue) {
-          grid = slots;
+          // Products output, four or more rounds of tiles: ONE queue workgroup per CU (256 store streams instead of
+          // 512) is as fast or faster than the two the LDS allows -- same box, alternating (tools/ab_slots.sh,
+          // ab_slots2.sh), 2 -> 1 per CU: M = 1e5 0.5600 -> 0.5605 ms (noise read) / 0.5355 -> 0.5256 (regenerated),
+          // 2e5 1.110 -> 1.102 / 1.050 -> 1.025, 1e6 5.425 -> 5.311 / 5.097 -> 5.025; at 5e4 +1.2 % / -1.2 %.
+          // The factored output needs the second workgroup (its tiles are a third as long: 0.2455 -> 0.2648 ms).
+          // RATO_ROWS_SLOTS_PER_CU overrides.
+          const int qslots = (!W && slots_env < 1 && n_tiles >= 1024) ? cus : slots;
+          grid = qslots;
           // Products output: the LAST slots/2 tiles are handed out as quarter tiles (4 row-interleaved parts each).
           // The drain at the end of the launch is bounded per workgroup (~19 GB/s each, whatever the residency), so
           // shorter last units shorten it; the re-staging they cost is paid while the chip is still full.  Same box,
@@ -1236,11 +1246,11 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
           static const int dts = [] { const char* e = getenv("RATO_DYN_TAIL_SPLIT"); return e ? atoi(e) : 0; }();
           static const int dtt = [] { const char* e = getenv("RATO_DYN_TAIL_TILES"); return e ? atoi(e) : 0; }();
           int want_split = dts > 0 ? dts : (W ? 1 : 4);
-          int want_tiles = dtt > 0 ? dtt : slots / 2;
+          int want_tiles = dtt > 0 ? dtt : qslots / 2;
           if (want_split > max_split) want_split = max_split;
           if (want_split > 1 && want_tiles > 0) {
             split = want_split;
-            n_whole = n_tiles - (want_tiles < n_tiles - slots ? want_tiles : n_tiles - slots);
+            n_whole = n_tiles - (want_tiles < n_tiles - qslots ? want_tiles : n_tiles - qslots);
           }
         }
       }
