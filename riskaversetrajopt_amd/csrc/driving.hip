@@ -837,6 +837,8 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
     int per_cu = (int)(CAR_ROWS_LDS_MAX / lds);
     if (per_cu > 32 / CROWS_NW) per_cu = 32 / CROWS_NW;
     if (per_cu < 1) per_cu = 1;
+    static const int slots_env = [] { const char* e = getenv("RATO_CAR_SLOTS_PER_CU"); return e ? atoi(e) : 0; }();   // A/B knob
+    if (slots_env >= 1 && slots_env < per_cu) per_cu = slots_env;
     const int slots = cus * per_cu;
     static const int dynamic_env = [] { const char* e = getenv("RATO_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
     unsigned* queue = nullptr;
@@ -851,8 +853,12 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       const int slot = rato::tile_queue_slot(st);      // one queue per stream; none left: static form
       if (slot >= 0) queue = queues + 2 * slot;
     }
+    // Two queue workgroups per CU, not the three the LDS allows: same box, alternating (tools/ab_car_slots.sh), 3 -> 2:
+    // C5 shard (M = 125,000) 0.1923-0.1938 -> 0.1846-0.1877 ms (noise read), 0.1768-0.1771 -> 0.1728-0.1734 (regenerated);
+    // M = 1e6 1.162-1.175 -> 1.158-1.163 / 1.105-1.108 -> 1.102-1.111; one per CU: +17 %.  RATO_CAR_SLOTS_PER_CU overrides.
+    const int qslots = (slots_env < 1 && per_cu > 2) ? cus * 2 : slots;
     if (queue) {
-      grid_x = slots;
+      grid_x = qslots;
     }
     // small batches (fewer tiles than workgroup slots): every tile split over several workgroups (>= 4 row tasks each)
     int split = 1;
@@ -878,7 +884,7 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       int tail_split = tail_split_env < 1 ? 1 : tail_split_env;
       const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;
       if (tail_split > max_split) tail_split = max_split;
-      int tail_tiles = tail_tiles_env >= 0 ? tail_tiles_env : slots / 2;
+      int tail_tiles = tail_tiles_env >= 0 ? tail_tiles_env : qslots / 2;
       if (tail_tiles > n_tiles) tail_tiles = n_tiles;
       const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
       if (dW)
