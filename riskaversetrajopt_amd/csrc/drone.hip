@@ -1182,7 +1182,12 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;   // keep >= 4 row tasks per workgroup
     int split = 1, n_whole = n_tiles;
     if (n_tiles < slots) {   // small batch: every tile split so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us)
-      split = slots / n_tiles;
+      static const int small_split_env = [] { const char* e = getenv("RATO_SMALL_SPLIT"); return e ? atoi(e) : 0; }();   // A/B
+      // Re-measured with the tiles on 2 MiB boundaries (RATO_SMALL_SPLIT sweep, kernel ms, products / factored):
+      // M = 2000 (32 tiles): split 1 0.0439 / 0.0387, 2 0.0339 / 0.0336, 4 0.0342 / 0.0340, slots / n_tiles 0.0378 / 0.0376;
+      // M = 5000: 1 0.0456 / 0.0397, 2 0.0389 / 0.0349, 4 0.0453 / 0.0387; M = 1e4 (C2): 1 0.0609, 2 0.0645, 3 0.0653;
+      // M = 2e4: 1 0.1208 / 0.0632, 2 0.1213 / 0.0731 -> two parts while that still leaves one workgroup per CU, else none.
+      split = small_split_env > 0 ? small_split_env : (2 * n_tiles <= cus ? 2 : 1);
       if (split > max_split) split = max_split;
       if (split < 1) split = 1;
       n_whole = split > 1 ? 0 : n_tiles;
