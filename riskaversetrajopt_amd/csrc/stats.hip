@@ -795,7 +795,9 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   }
   static const int no_coop = [] { const char* e = getenv("RATO_RS_COOP"); return (e && e[0] == '0') ? 1 : 0; }();
   if (M <= RS_COOP_MAX && !force_multi && (!no_coop || force_coop)) {   // ONE launch, G workgroups, keys in registers
-    long G = (M + RS1_T * 4 - 1) / (RS1_T * 4);
+    static const int kpt_env = [] { const char* e = getenv("RATO_RS_KPT"); return e ? atoi(e) : 0; }();   // A/B: keys per thread
+    const long kpt = (kpt_env >= 1 && kpt_env <= RS_COOP_KEYS) ? kpt_env : 4;
+    long G = (M + RS1_T * kpt - 1) / (RS1_T * kpt);
     if (G > RS_COOP_MAX_WG) G = RS_COOP_MAX_WG;
     hipLaunchKernelGGL(rs_coop, dim3((unsigned)G + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr,
                        (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out);
