@@ -68,9 +68,13 @@ extern "C" {
 
 /* ABI version, bumped on any signature/layout change (2: factored Jacobian W / A22 outputs, CVaR-cut oracle
  * entry points, record unpack; 3: generators-only linearization, Jacobian-free tail rows, a22_axes; 4: rato_comm_*
- * (RCCL behind the ABI), rato_car_separation_distances, rato_count_nonfinite_acc, Philox sampler entry points).  The
- * Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 6
+ * (RCCL behind the ABI), rato_car_separation_distances, rato_count_nonfinite_acc, Philox sampler entry points;
+ * 5: rato_*_linearize_philox, rato_hopper_slip_host_inputs; 6: packed tile stride (rato_packed_tile_stride /
+ * rato_packed_buffer_floats), rato_sums_and_risk_stats; 7: fp64 CVaR-cut oracle -- rato_saa_rowmax /
+ * rato_drone_rowmax_implicit take (base, sign, double xs), the tail-row entry points write double partials
+ * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out).
+ * The Python binding refuses a library that reports another version. */
+#define RATO_ABI_VERSION 7
 int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
@@ -102,6 +106,9 @@ typedef struct rato_drone_params {
   float x_init[6];
   float x_final[6];
   float obs_xy[RATO_DRONE_NOBS][2];  /* obs_positions[:, :2] */
+  int32_t rows_out;     /* what the linearize entry points write into their g_up buffer: 0 = the reference's
+                           g_up = -g + (grad g).u_k (drone_risk.py:278); 1 = the constraint value g at u_k itself
+                           (the base of the oracle's delta form: rows(u) = g + G (u - u_k), see rato_saa_rowmax) */
 } rato_drone_params;
 
 /*
@@ -181,6 +188,8 @@ typedef struct rato_car_params {
   float tol;             /* OSQP_TOL (3e-4) */
   float ego_init[4];     /* state_init[0:4] (sample independent) */
   float ego_goal[4];     /* driving.py:217-220 */
+  int32_t rows_out;      /* g_up buffer of rato_car_linearize*: 0 = g_up = -g + (grad g).u_k (driving.py:295),
+                            1 = g itself (see rato_drone_params.rows_out) */
 } rato_car_params;
 
 /* Scratch floats needed by the driving entry points for the shared ego
@@ -291,82 +300,77 @@ int rato_emit_csc_values(const float* G, const float* W /* NULL, or the factor o
  * y_i >= -slack, y_i >= (G_i u - g_up_i)_r - t for every row r) leaves the single
  * convex constraint  alpha*M*CVaR_alpha(m(u)) - (M*(1-alpha) - 1)*slack <= 0  with
  *     m_i(u) = max_r [ (G_i u)_r - g_up_{i,r} ].
- * These two calls are the device oracle a cutting-plane solve needs per cut
- * (value: rato_risk_stats on m; subgradient: tail-weighted sum of arg-max rows).
+ * These calls are the device oracle a cutting-plane solve needs per cut (selection of the tail: rato_risk_stats on
+ * m; the cut itself: tail-weighted sums of the arg-max rows and of their offsets).  The rows are evaluated as
+ *     (G_i x)_r + sign * base_{i,r}
+ * which covers the reference's expression (x = u, base = g_up, sign = -1) and its delta form (x = u - u_k,
+ * base = g, sign = +1: g_up = -g + G u_k, params.rows_out = 1 makes the linearize kernels write g).  Inputs are the
+ * fp32 arrays of the linearize calls; ALL arithmetic is fp64 (x and the partial sums are double): value and gradient
+ * of a cut agree to 1e-13, which is what the 1e-5 parity of SCP iterates with the full QP rests on.
  *
  * rato_saa_rowmax: one streaming read of the packed Jacobian G (layout of the
  * linearize calls; tile = its TILE; R = 3 drone / 1 driving; rows of sample i
- * indexed r*S + t):  m_out[i], arg_out[i] = max / arg-max (smallest row index on ties).
- *   g_up [R][S][ld], us [S][n_u] (only controls 0 and 1 enter the rows).
+ * indexed r*S + t):  m_out[i], arg_out[i] = max (rounded to fp32) / arg-max (smallest row index on ties).
+ *   base [R][S][ld], xs [S][n_u] doubles (only controls 0 and 1 enter the rows).
  */
 int rato_saa_rowmax(const float* G, const float* W /* NULL, or the factor of a factored G (R = 3) */,
                     int32_t tile, int32_t R, int32_t S, int64_t M, int64_t ld,
-                    const float* g_up, const float* us, int32_t n_u,
+                    const float* base, double sign /* +1 or -1 */, const double* xs, int32_t n_u,
                     float* m_out, int32_t* arg_out, void* stream);
 
 /*
- * The same m_out / arg_out for the drone WITHOUT reading the Jacobian: (G_i u)_{j,t} =
+ * The same m_out / arg_out for the drone WITHOUT reading the Jacobian: (G_i x)_{j,t} =
  * sum_a W[j,t,a] dp_a(t+1), where dp is the response of the linearized dynamics
- * d x_{k+1} = A_k d x_k + B u_k (d x_0 = 0, B = [0, dt/m]^T, A_k from A22: see rato_drone_linearize).
- * One pass over A22, W, g_up (11 S floats per sample instead of S(S-1) + 9 S); values agree with
- * rato_saa_rowmax to fp32 rounding.   us [S][3] (n_u = 3); p supplies M, ld, S, dt, kp.
+ * d x_{k+1} = A_k d x_k + B x_k (d x_0 = 0, B = [0, dt/m]^T, A_k from A22: see rato_drone_linearize).
+ * One pass over A22, W, base (11 S floats per sample instead of S(S-1) + 9 S).  xs [S][3] doubles (n_u = 3);
+ * p supplies M, ld, S, dt, kp.
  */
 int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
                                int32_t a22_axes /* 2: [S][2][ld] of rato_drone_linearize; 3: [S][3][ld] of
                                                    rato_drone_linearize_generators */,
-                               const float* W, const float* g_up, const float* us,
+                               const float* W, const float* base, double sign, const double* xs,
                                float* m_out, int32_t* arg_out, void* stream);
 
 /*
- * Generators-only linearization (drone): A22 [S][3 axes][ld], W [3 obs][S][2][ld], g_up [3 obs][S][ld], Z [M] or
- * NULL, part [ceil(M/256)][6S+6] (per-block sums, layout of rato_drone_linearize) -- the whole linearization in
- * 12 S numbers per sample and NO Jacobian entries: Phi[t,s,a] = e_0' A_t ... A_{s+1} B is regenerated from A22 by
- * the consumers (rato_drone_rowmax_implicit for G.u, rato_drone_tail_rows_implicit for rows of G).  60 B per
- * sample-step of HBM traffic instead of 245 B; what a reduced SCP iteration needs (Model.solve_reduced).
+ * Generators-only linearization (drone): A22 [S][3 axes][ld], W [3 obs][S][2][ld], g_up [3 obs][S][ld] (or g:
+ * p->rows_out), Z [M] or NULL, part [ceil(M/256)][6S+6] (per-block sums, layout of rato_drone_linearize) -- the whole
+ * linearization in 12 S numbers per sample and NO Jacobian entries: Phi[t,s,a] = e_0' A_t ... A_{s+1} B is
+ * regenerated from A22 by the consumers (rato_drone_rowmax_implicit for G.x, rato_drone_tail_rows_implicit for rows
+ * of G).  60 B per sample-step of HBM traffic instead of 245 B; what a reduced SCP iteration needs
+ * (Model.solve_reduced).
  */
 int rato_drone_linearize_generators(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym,
                                     float* A22, float* W, float* g_up, float* Z, float* part, void* stream);
 
 /*
- * rato_saa_tail_rows / rato_saa_tail_rows_batch for the drone without reading the Jacobian: the arg-max row of
- * every tail sample is regenerated from A22 (adjoint sweep from its t*).  slots == NULL: one cut in slot 0 of the
- * rings (K = 1).  part [ceil(M/256)][K][2(S-1) + 1] as in rato_saa_tail_rows_batch.
- */
-int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass, const float* A22, int32_t a22_axes,
-                                  const float* W, const float* g_up,
-                                  const float* m_base, const int32_t* arg_base, const double* stats_base,
-                                  int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
-                                  float* part, void* stream);
-
-/*
- * rato_saa_tail_rows: part[blk][s*2 + g] (blk over ceil(M/256) blocks, s < S-1) =
- * sum over the block's samples of w_i * G_i[arg_i, (s,g)], with w_i = 1 if
- * m_vals[i] > tstar, lambda if == tstar, 0 otherwise.  Reduce with rato_sum_partials.
- * If stats_dev != NULL (the device double[RATO_N_STATS] written by rato_risk_stats on m_vals), tstar (slot 10) and
- * lambda = clamp((alphaM - #{m > t}) / #{m == t}, 0, 1) are taken from it on the device instead
- * of from the arguments (no host round trip between the two calls).
- */
-int rato_saa_tail_rows(const float* G, const float* W /* NULL or factor */, int64_t ld /* stride of W */,
-                       int32_t tile, int32_t R, int32_t S, int64_t M,
-                       const float* m_vals, const int32_t* arg, float tstar, float lambda,
-                       const double* stats_dev, double alphaM, float* part, void* stream);
-
-/*
- * Re-linearized cuts (cut recycling across SCP iterations).  A cut is a tail weighting w (from m_vals and the
- * rato_risk_stats record that was computed on them) plus the arg-max row of every sample; it stays a valid cut
- * under a NEW linearization:  CVaR(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}].
- * K cuts kept in rings  m_base [slot][M], arg_base [slot][M], stats_base [slot][stats_stride >= 10 doubles]  are
- * evaluated in one launch:
- *   part[blk][k][0 .. 2(S-1))  block sums of w_i G_i[r_i, (s,g)]     (k-th entry of slots[], a device array)
- *   part[blk][k][2(S-1)]       block sum  of w_i g_up_{i,r_i}
- * Reduce with rato_sum_partials(part, nblk, K * (2(S-1) + 1), ...).
+ * Cuts under a linearization (the new cut of an oracle call, and cut recycling across SCP iterations).  A cut is a
+ * tail weighting w (from the m values and the rato_risk_stats record that was computed on them: 1 above the
+ * threshold out[10], lambda = clamp((alphaM - #{m > t}) / #{m == t}, 0, 1) on ties) plus the arg-max row of every
+ * sample; it is a valid cut under ANY linearization,
+ *     CVaR(m(x)) >= (1/(alpha M)) sum_i w_i [(G_i x)_{r_i} + sign base_{i,r_i}],
+ * tight at the x it was computed for under the linearization it was computed with.
+ * K cuts kept in rings  m_base [slot][M], arg_base [slot][M], stats_base [slot][stats_stride >= 11 doubles]  are
+ * evaluated in one launch (slots: device array of K ring slots; NULL: K = 1, the pointers are the slot):
+ *   part[blk][k][0 .. 2(S-1))  block sums of w_i G_i[r_i, (s,g)]      (doubles)
+ *   part[blk][k][2(S-1)]       block sum  of w_i base_{i,r_i}
+ * Reduce with rato_sum_partials_f64(part, nblk, K * (2(S-1) + 1), ...).
  */
 int rato_saa_tail_rows_batch(const float* G, const float* W /* NULL or factor */, int64_t ld, int32_t tile,
-                             int32_t R, int32_t S, int64_t M, const float* g_up,
+                             int32_t R, int32_t S, int64_t M, const float* base,
                              const float* m_base, const int32_t* arg_base, const double* stats_base,
-                             int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM, float* part,
+                             int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM, double* part,
                              void* stream);
+
+/*
+ * The same for the drone without reading the Jacobian: the arg-max row of every tail sample is regenerated from A22
+ * (adjoint sweep from its t*, fp64).  Same part layout.
+ */
+int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass, const float* A22, int32_t a22_axes,
+                                  const float* W, const float* base,
+                                  const float* m_base, const int32_t* arg_base, const double* stats_base,
+                                  int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
+                                  double* part, void* stream);
 
 /* ------------------------------------------------------------ device sampler */
 
@@ -465,6 +469,9 @@ int rato_comm_destroy(rato_comm* comm);
  * in a fixed order.  out is double[ncols]. */
 int rato_sum_partials(const float* part, int32_t nblocks, int32_t ncols, double scale,
                       double* out, void* stream);
+/* the same for double partials (the fp64 block sums of the CVaR-cut oracle) */
+int rato_sum_partials_f64(const double* part, int32_t nblocks, int32_t ncols, double scale,
+                          double* out, void* stream);
 
 /* Failure detection (the reference has none: an infeasible QP only prints, drone_risk.py:458-459):
  * counts the NaN/Inf entries of a device array into *count (device uint32). */

@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 6              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 7              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -16,13 +16,13 @@ class DroneParams(C.Structure):
     _fields_ = [("M", C.c_int32), ("ld", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
                 ("drag", C.c_float), ("kp", C.c_float), ("kd", C.c_float), ("tol", C.c_float),
                 ("x_init", C.c_float * 6), ("x_final", C.c_float * 6),
-                ("obs_xy", (C.c_float * 2) * 3)]
+                ("obs_xy", (C.c_float * 2) * 3), ("rows_out", C.c_int32)]
 
 
 class CarParams(C.Structure):
     _fields_ = [("M", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
                 ("speed_ped_des", C.c_float), ("d_min", C.c_float), ("tol", C.c_float),
-                ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4)]
+                ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
@@ -35,8 +35,8 @@ SIGNATURES = {
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rato_drone_linearize": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 10 + [C.c_int32, C.c_int32, c_stream]),
-    "rato_drone_rowmax_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32] +
-                                   [c_float_p] * 5 + [c_stream]),
+    "rato_drone_rowmax_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32, c_float_p,
+                                             c_float_p, C.c_double, c_float_p, c_float_p, c_float_p, c_stream]),
     "rato_drone_linearize_generators": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 9 + [c_stream]),
     "rato_drone_tail_rows_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32] +
                                       [c_float_p] * 5 + [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p,
@@ -53,16 +53,14 @@ SIGNATURES = {
     "rato_emit_csc_values": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_float, c_float_p, c_stream]),
     "rato_saa_rowmax": (C.c_int, [c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
-                                  c_float_p, c_float_p, C.c_int32, c_float_p, c_float_p, c_stream]),
-    "rato_saa_tail_rows": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
-                                     c_float_p, c_float_p, C.c_float, C.c_float, c_float_p, C.c_double, c_float_p,
-                                     c_stream]),
+                                  c_float_p, C.c_double, c_float_p, C.c_int32, c_float_p, c_float_p, c_stream]),
     "rato_saa_tail_rows_batch": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                            c_float_p, c_float_p, c_float_p, c_float_p, C.c_int64, c_float_p,
                                            C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_unpack_records": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_float_p, c_float_p,
                                       c_stream]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_sum_partials_f64": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_count_nonfinite_acc": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -1,40 +1,58 @@
 // Device oracle of the linearized CVaR constraint (gfx950) — what a cutting-plane solve of the SCP
-// subproblem needs per cut, computed where the packed Jacobian already lives (HBM):
+// subproblem needs per cut, computed where the linearization already lives (HBM):
 //
-//   m_i(u) = max_r [ (G_i u)_r - g_up_{i,r} ]       rato_saa_rowmax        (one streaming READ of G)
-//   sum_i mu_i G_i[r*_i, :]                          rato_saa_tail_rows     (reads only the arg-max rows)
+//   m_i(x) = max_r [ (G_i x)_r + sign * base_{i,r} ]     rato_saa_rowmax / rato_drone_rowmax_implicit
+//   sum_i w_i G_i[r*_i, :],  sum_i w_i base_{i,r*_i}     rato_saa_tail_rows_batch / rato_drone_tail_rows_implicit
 //
 // Eliminating the auxiliary y_i of the reference's QP (drone_risk.py:327-368: y_i >= -slack,
 // y_i >= (G_i u - g_up_i)_r - t) leaves  alpha M CVaR_alpha(m(u)) - (M(1-alpha) - 1) slack <= 0  in the
-// variables (u, slack) only; its value comes from rato_risk_stats on m and its subgradient is the
-// tail-weighted sum of arg-max rows.  Both kernels use the tile-blocked packed layout of rato_saa.h.
+// variables (u, slack) only.  The rows come in two algebraically identical forms:
+//   reference form  x = u,         base = g_up = -g + G u_k,  sign = -1     (drone_risk.py:278, :357-364)
+//   delta form      x = u - u_k,   base = g (the constraint value at u_k), sign = +1
+// The data are the fp32 outputs of the linearize kernels; ALL arithmetic here is fp64 (the kernels are HBM-bound
+// on the fp32 reads, the fp64 FMAs are free): a cut's value and its gradient are then consistent to 1e-13, which
+// is what lets the cutting-plane loop reproduce the optimum of the full QP to the 1e-5 the north star asks for
+// (fp32 rows of magnitude 1e2 carried 1e-5 of noise per cut).  The delta form additionally keeps the fp32 rounding
+// of g_up (|g_up| ~ 1e2 against |g| ~ 1e-2 on the rows that matter) out of the rows.
 #include "rato_common.h"
 
 namespace {
 
 constexpr int RM_NW = 8;        // waves per workgroup (64 samples)
-constexpr int RM_MAXR = 4;      // row groups (obstacles): drone 3, driving 1
 
-typedef float rfloat2_t __attribute__((ext_vector_type(2)));
+typedef double rdouble2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float tail_weight(float mv, float tstar, float lambda) {
+  return (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+}
+
+// threshold t (slot 10: the Rockafellar-Uryasev minimiser; slot 0 = VaR wraps to max(Z) when floor(alpha M) = M)
+// and the weight of the samples that tie with it, from a rato_risk_stats record
+__device__ __forceinline__ void tail_rule(const double* __restrict__ st, double alphaM, float& tstar, float& lambda) {
+  tstar = (float)st[10];
+  const double n_gt = st[8], n_eq = st[9];
+  const double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
+  lambda = (float)fmin(fmax(l, 0.0), 1.0);
+}
 
 // grid = ceil(M/64) workgroups; rows t are pulled from an LDS queue, longest first.
 template <int R, bool FACT>
 __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* __restrict__ G,
                                                                    const float* __restrict__ W, int tileW, int S,
-                                                                   long M, long ld, const float* __restrict__ g_up,
-                                                                   const float* __restrict__ us, int n_u,
+                                                                   long M, long ld, const float* __restrict__ base,
+                                                                   double sign, const double* __restrict__ xs, int n_u,
                                                                    float* __restrict__ m_out,
                                                                    int* __restrict__ arg_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rm_lds[];
-  rfloat2_t* US = reinterpret_cast<rfloat2_t*>(rm_lds);              // [S] (u_{s,0}, u_{s,1})
-  float* BV = reinterpret_cast<float*>(US + S);                      // [RM_NW][64] best value per wave
+  rdouble2_t* US = reinterpret_cast<rdouble2_t*>(rm_lds);            // [S] (x_{s,0}, x_{s,1})
+  double* BV = reinterpret_cast<double*>(US + S);                    // [RM_NW][64] best value per wave
   int* BI = reinterpret_cast<int*>(BV + RM_NW * 64);                 // [RM_NW][64] best row index
   int* head = BI + RM_NW * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < S; i += RM_NW * RATO_WAVE) {
-    rfloat2_t u2;
-    u2.x = us[i * n_u + 0];
-    u2.y = us[i * n_u + 1];
+    rdouble2_t u2;
+    u2.x = xs[i * n_u + 0];
+    u2.y = xs[i * n_u + 1];
     US[i] = u2;
   }
   if (threadIdx.x == 0) *head = 0;
@@ -46,7 +64,7 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   constexpr int RR = FACT ? 1 : R;   // row groups stored per (pair, control): factored keeps only Phi
   const float* __restrict__ Gt = G + (size_t)(i0 / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (i0 % tileW) + lane;
-  float best = -INFINITY;
+  double best = -INFINITY;
   int best_idx = 0;
   auto next_task = [&]() -> int {
     int v = 0;
@@ -56,38 +74,38 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
   int task = next_task();
   while (task < S) {
     const int t = S - 1 - task;
-    float acc[R];
+    double acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
     const float* __restrict__ row = Gt + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
     if (FACT) {
-      float ax = 0.0f, ay = 0.0f;   // (Phi u) per axis, shared by the row groups
+      double ax = 0.0, ay = 0.0;   // (Phi x) per axis, shared by the row groups
 #pragma unroll 8
       for (int s2 = 0; s2 < t; ++s2) {
-        const rfloat2_t u2 = US[s2];
+        const rdouble2_t u2 = US[s2];
         const float* __restrict__ o = row + (size_t)s2 * (2 * tileW);
-        ax += (valid ? o[0] : 0.0f) * u2.x;
-        ay += (valid ? o[tileW] : 0.0f) * u2.y;
+        ax += (double)(valid ? o[0] : 0.0f) * u2.x;
+        ay += (double)(valid ? o[tileW] : 0.0f) * u2.y;
       }
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        acc[r] = W[(((size_t)r * S + t) * 2 + 0) * ld + m] * ax + W[(((size_t)r * S + t) * 2 + 1) * ld + m] * ay;
+        acc[r] = (double)W[(((size_t)r * S + t) * 2 + 0) * ld + m] * ax + (double)W[(((size_t)r * S + t) * 2 + 1) * ld + m] * ay;
     } else {
 #pragma unroll 4
       for (int s2 = 0; s2 < t; ++s2) {
-        const rfloat2_t u2 = US[s2];
+        const rdouble2_t u2 = US[s2];
         const float* __restrict__ o = row + (size_t)s2 * (2 * R * tileW);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float g0 = valid ? o[r * tileW] : 0.0f;
           const float g1 = valid ? o[(R + r) * tileW] : 0.0f;
-          acc[r] += g0 * u2.x + g1 * u2.y;
+          acc[r] += (double)g0 * u2.x + (double)g1 * u2.y;
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float v = acc[r] - g_up[((size_t)r * S + t) * ld + m];
+      const double v = acc[r] + sign * (double)base[((size_t)r * S + t) * ld + m];
       if (v > best) {           // strict: ties keep the row found first (deterministic given the row)
         best = v;
         best_idx = r * S + t;
@@ -101,10 +119,10 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
   BI[wave * 64 + lane] = best_idx;
   __syncthreads();
   if (wave == 0) {
-    float b = BV[lane];
+    double b = BV[lane];
     int bi = BI[lane];
     for (int w = 1; w < RM_NW; ++w) {
-      const float v = BV[w * 64 + lane];
+      const double v = BV[w * 64 + lane];
       const int vi = BI[w * 64 + lane];
       if (v > b || (v == b && vi < bi)) {
         b = v;
@@ -112,36 +130,38 @@ __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* _
       }
     }
     if (valid) {
-      m_out[m] = b;
+      m_out[m] = (float)b;
       arg_out[m] = bi;
     }
   }
 }
 
-// grid = ceil(M/256) workgroups of 256 lanes (one sample each).  part[blk][s*2 + g] = sum over the block's
-// samples of weight_i * G_i[arg_i, (s,g)], weight = 1 for m_i > tstar, lambda for m_i == tstar, else 0.
+// Cuts under a linearization.  A cut of the CVaR constraint is a tail weighting (w_i in [0,1], sum = alpha M: 1 above
+// the threshold of the rato_risk_stats record that was computed on the m values, lambda on ties with it) plus one row
+// r_i per sample; under ANY linearization  CVaR_alpha(m(x)) >= (1/(alpha M)) sum_i w_i [(G_i x)_{r_i} + sign base_{i,r_i}],
+// with equality at the x the (w, r) were computed for.  This kernel evaluates K of them in one launch: blockIdx.y = k
+// picks ring slot slots[k] (slots == NULL: K = 1, slot 0); part[blk][k][0 .. 2(S-1)) = block sums of
+// w_i G_i[r_i, (s,g)], part[blk][k][2(S-1)] = block sum of w_i base_{i,r_i}: fp64 throughout.
 template <int R>
-__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __restrict__ G,
-                                                               const float* __restrict__ W, long ld, int tileW, int S,
-                                                               long M, const float* __restrict__ mvals,
-                                                               const int* __restrict__ arg, float tstar,
-                                                               float lambda, const double* __restrict__ stats_dev,
-                                                               double alphaM, float* __restrict__ part) {
-  extern __shared__ float tr_lds[];   // [4 waves][2*(S-1)]
-  if (stats_dev) {  // threshold and tie weight straight from rato_risk_stats' device output (no host round trip)
-    tstar = (float)stats_dev[10];   // the Rockafellar-Uryasev minimiser (slot 0 = VaR wraps to max(Z) when floor(alpha M) = M)
-    const double n_gt = stats_dev[8], n_eq = stats_dev[9];
-    double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
-    lambda = (float)fmin(fmax(l, 0.0), 1.0);
-  }
+__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
+    const float* __restrict__ G, const float* __restrict__ W, long ld, int tileW, int S, long M,
+    const float* __restrict__ base, const float* __restrict__ m_base, const int* __restrict__ arg_base,
+    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
+    double* __restrict__ part) {
+  extern __shared__ double trb_lds[];   // [4 waves][2*(S-1) + 1]
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots ? slots[kk] : 0;
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  float tstar, lambda;
+  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const bool valid = m < M;
   float w = 0.0f;
   int t = 0, r = 0;
   if (valid) {
-    const float mv = mvals[m];
-    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+    w = tail_weight(mvals[m], tstar, lambda);
     const int a = arg[m];
     r = a / S;
     t = a - r * S;
@@ -151,13 +171,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
   const int RR = fact ? 1 : R;
   const float* __restrict__ Gm = G + (size_t)(m / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (m % tileW);
   const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
-  float w0 = w, w1 = w;
-  if (fact && w != 0.0f) {   // factored: entry = W[r,t,a] * Phi[t,s,a]
-    w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m];
-    w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m];
+  double w0 = w, w1 = w, wg = 0.0;
+  if (w != 0.0f) {
+    wg = (double)w * (double)base[((size_t)r * S + t) * ld + m];
+    if (fact) {   // factored: entry = W[r,t,a] * Phi[t,s,a]
+      w0 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 0) * ld + m];
+      w1 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 1) * ld + m];
+    }
   }
   const int rsel = fact ? 0 : r;
-  const int nw = 2 * (S - 1);
+  const int nw = 2 * (S - 1), nc = nw + 1;
   constexpr int SB = 8;   // columns per batch: 16 gathers in flight, then 16 wave reductions
   for (int sb = 0; sb < S - 1; sb += SB) {
     float g0[SB], g1[SB];
@@ -176,93 +199,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_kernel(const float* __re
     for (int i = 0; i < SB; ++i) {
       const int s2 = sb + i;
       if (s2 < S - 1) {
-        const float s0 = rato::wave_sum_dpp(w0 * g0[i]);
-        const float s1 = rato::wave_sum_dpp(w1 * g1[i]);
-        if (lane == 0) {
-          tr_lds[wave * nw + s2 * 2 + 0] = s0;
-          tr_lds[wave * nw + s2 * 2 + 1] = s1;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nw; i += RATO_BLOCK) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += tr_lds[wv * nw + i];
-    part[(size_t)blockIdx.x * nw + i] = acc;
-  }
-}
-
-// Re-linearized cuts.  A cut of the CVaR constraint is a tail weighting (w_i in [0,1], sum = alpha M) plus one row
-// r_i per sample; under ANY linearization  CVaR_alpha(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}],
-// so the (w, r) of cuts found in the previous SCP iteration give valid cuts for the new one.  This kernel
-// evaluates K of them in one launch: blockIdx.y = k picks ring slot slots[k] (m values, arg-max rows and the
-// risk statistics that define w); part[blk][k][0 .. 2(S-1)) = block sums of w_i G_i[r_i, (s,g)],
-// part[blk][k][2(S-1)] = block sum of w_i g_up_{i,r_i}.
-template <int R>
-__global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
-    const float* __restrict__ G, const float* __restrict__ W, long ld, int tileW, int S, long M,
-    const float* __restrict__ g_up, const float* __restrict__ m_base, const int* __restrict__ arg_base,
-    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
-    float* __restrict__ part) {
-  extern __shared__ float trb_lds[];   // [4 waves][2*(S-1) + 1]
-  const int K = gridDim.y, kk = blockIdx.y;
-  const long slot = slots[kk];
-  const float* __restrict__ mvals = m_base + slot * M;
-  const int* __restrict__ arg = arg_base + slot * M;
-  const double* __restrict__ st = stats_base + slot * stats_stride;
-  const float tstar = (float)st[10];
-  const double n_gt = st[8], n_eq = st[9];
-  const double l = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
-  const float lambda = (float)fmin(fmax(l, 0.0), 1.0);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
-  const bool valid = m < M;
-  float w = 0.0f;
-  int t = 0, r = 0;
-  if (valid) {
-    const float mv = mvals[m];
-    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
-    const int a = arg[m];
-    r = a / S;
-    t = a - r * S;
-  }
-  const size_t n_pairs = (size_t)S * (S - 1) / 2;
-  const bool fact = (W != nullptr);
-  const int RR = fact ? 1 : R;
-  const float* __restrict__ Gm = G + (size_t)(m / tileW) * rato::packed_tile_stride(n_pairs * 2 * RR * tileW) + (m % tileW);
-  const float* __restrict__ row = Gm + (size_t)rato::pair_row_offset(t) * (2 * RR * tileW);
-  float w0 = w, w1 = w, wg = 0.0f;
-  if (w != 0.0f) {
-    wg = w * g_up[((size_t)r * S + t) * ld + m];
-    if (fact) {
-      w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m];
-      w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m];
-    }
-  }
-  const int rsel = fact ? 0 : r;
-  const int nw = 2 * (S - 1), nc = nw + 1;
-  constexpr int SB = 8;
-  for (int sb = 0; sb < S - 1; sb += SB) {
-    float g0[SB], g1[SB];
-#pragma unroll
-    for (int i = 0; i < SB; ++i) {
-      const int s2 = sb + i;
-      g0[i] = 0.0f;
-      g1[i] = 0.0f;
-      if (w != 0.0f && s2 < t) {
-        const float* __restrict__ o = row + (size_t)s2 * (2 * RR * tileW);
-        g0[i] = o[rsel * tileW];
-        g1[i] = o[(RR + rsel) * tileW];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < SB; ++i) {
-      const int s2 = sb + i;
-      if (s2 < S - 1) {
-        const float s0 = rato::wave_sum_dpp(w0 * g0[i]);
-        const float s1 = rato::wave_sum_dpp(w1 * g1[i]);
+        const double s0 = rato::wave_sum_dpp(w0 * (double)g0[i]);
+        const double s1 = rato::wave_sum_dpp(w1 * (double)g1[i]);
         if (lane == 0) {
           trb_lds[wave * nc + s2 * 2 + 0] = s0;
           trb_lds[wave * nc + s2 * 2 + 1] = s1;
@@ -270,38 +208,35 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
       }
     }
   }
-  const float sg = rato::wave_sum_dpp(wg);
+  const double sg = rato::wave_sum_dpp(wg);
   if (lane == 0) trb_lds[wave * nc + nw] = sg;
   __syncthreads();
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
     for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += trb_lds[wv * nc + i];
     part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
   }
 }
 
-// Jacobian-free tail rows for the drone (single cut or K kept cuts, like tail_rows_batch_kernel): the arg-max row
-// (j*, t*) of a tail sample is  W[j*,t*,a] Phi[t*,s,a],  Phi[t*, k-1, a] = (mu_k)[1] dt/m  with  mu_{t*+1} = e_0',
-// mu_k = mu_{k+1} A_k  -- the adjoint sweep of the linearize kernel, regenerated here from A22.  The lanes walk k
-// from S-1 down together; a lane joins at k = t*_i.  Output layout of tail_rows_batch_kernel.
+// Jacobian-free tail rows for the drone (one cut or K kept cuts, output layout of tail_rows_batch_kernel): the arg-max
+// row (j*, t*) of a tail sample is  W[j*,t*,a] Phi[t*,s,a],  Phi[t*, k-1, a] = (mu_k)[1] dt/m  with  mu_{t*+1} = e_0',
+// mu_k = mu_{k+1} A_k  -- the adjoint sweep of the linearize kernel, regenerated here (fp64) from A22.  The lanes walk
+// k from S-1 down together; a lane joins at k = t*_i.
 __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
     rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22, int a22_axes,
-    const float* __restrict__ W, const float* __restrict__ g_up, const float* __restrict__ m_base,
+    const float* __restrict__ W, const float* __restrict__ base, const float* __restrict__ m_base,
     const int* __restrict__ arg_base, const double* __restrict__ stats_base, long stats_stride,
-    const int* __restrict__ slots, double alphaM, float* __restrict__ part) {
-  extern __shared__ float tri_lds[];   // [4 waves][2*(S-1) + 1]
+    const int* __restrict__ slots, double alphaM, double* __restrict__ part) {
+  extern __shared__ double tri_lds[];   // [4 waves][2*(S-1) + 1]
   const int S = P.S;
   const long M = P.M, ld = P.ld;
   const int K = gridDim.y, kk = blockIdx.y;
   const long slot = slots ? slots[kk] : 0;
   const float* __restrict__ mvals = m_base + slot * M;
   const int* __restrict__ arg = arg_base + slot * M;
-  const double* __restrict__ st = stats_base + slot * stats_stride;
-  const float tstar = (float)st[10];
-  const double n_gt = st[8], n_eq = st[9];
-  const double lq = (n_eq > 0.0) ? (alphaM - n_gt) / n_eq : 0.0;
-  const float lambda = (float)fmin(fmax(lq, 0.0), 1.0);
+  float tstar, lambda;
+  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long m_raw = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const bool valid = m_raw < M;
@@ -309,23 +244,23 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
   float w = 0.0f;
   int t = 0, r = 0;
   if (valid) {
-    const float mv = mvals[m];
-    w = (mv > tstar) ? 1.0f : ((mv == tstar) ? lambda : 0.0f);
+    w = tail_weight(mvals[m], tstar, lambda);
     const int a = arg[m];
     r = a / S;
     t = a - r * S;
   }
-  float w0 = 0.0f, w1 = 0.0f, wg = 0.0f, a21 = 0.0f, dtm = 0.0f;
+  const double dt = (double)P.dt;
+  double w0 = 0.0, w1 = 0.0, wg = 0.0, a21 = 0.0;
   if (w != 0.0f) {
-    const float inv_m = 1.0f / mass[m];
-    a21 = -P.kp * P.dt * inv_m;
-    dtm = P.dt * inv_m;
-    w0 = w * W[(((size_t)r * S + t) * 2 + 0) * ld + m] * dtm;
-    w1 = w * W[(((size_t)r * S + t) * 2 + 1) * ld + m] * dtm;
-    wg = w * g_up[((size_t)r * S + t) * ld + m];
+    const double inv_m = 1.0 / (double)mass[m];
+    a21 = -(double)P.kp * dt * inv_m;
+    const double dtm = dt * inv_m;
+    w0 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 0) * ld + m] * dtm;
+    w1 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 1) * ld + m] * dtm;
+    wg = (double)w * (double)base[((size_t)r * S + t) * ld + m];
   }
   const int nw = 2 * (S - 1), nc = nw + 1;
-  float m0x = 0.0f, m1x = 0.0f, m0y = 0.0f, m1y = 0.0f;
+  double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
   constexpr int SB = 8;
   for (int kb = S - 1; kb >= 1; kb -= SB) {
     float ax[SB], ay[SB];
@@ -342,18 +277,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
       if (k >= 1) {   // wave-uniform
         const bool on = (w != 0.0f) && k <= t;
         if (on && k == t) {
-          m0x = 1.0f; m1x = 0.0f; m0y = 1.0f; m1y = 0.0f;   // mu_{t*+1} = e_0'
+          m0x = 1.0; m1x = 0.0; m0y = 1.0; m1y = 0.0;   // mu_{t*+1} = e_0'
         }
-        float cx = 0.0f, cy = 0.0f;
+        double cx = 0.0, cy = 0.0;
         if (on) {
-          const float n0x = m0x + m1x * a21, n1x = m0x * P.dt + m1x * ax[i];
-          const float n0y = m0y + m1y * a21, n1y = m0y * P.dt + m1y * ay[i];
+          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * (double)ax[i];
+          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * (double)ay[i];
           m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
           cx = w0 * m1x;
           cy = w1 * m1y;
         }
-        const float s0 = rato::wave_sum_dpp(cx);
-        const float s1 = rato::wave_sum_dpp(cy);
+        const double s0 = rato::wave_sum_dpp(cx);
+        const double s1 = rato::wave_sum_dpp(cy);
         if (lane == 0) {
           tri_lds[wave * nc + (k - 1) * 2 + 0] = s0;
           tri_lds[wave * nc + (k - 1) * 2 + 1] = s1;
@@ -361,11 +296,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
       }
     }
   }
-  const float sg = rato::wave_sum_dpp(wg);
+  const double sg = rato::wave_sum_dpp(wg);
   if (lane == 0) tri_lds[wave * nc + nw] = sg;
   __syncthreads();
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
     for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += tri_lds[wv * nc + i];
     part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
@@ -373,21 +308,22 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
 }
 
 // Jacobian-free form of rowmax for the drone: one lane per sample, one pass over the step-Jacobian table
-// A22 [S][2][ld], W [3][S][2][ld] and g_up [3][S][ld] (11 S floats per sample).  (G_i u)_{j,t} =
-// W[j,t,x] dp_x(t+1) + W[j,t,y] dp_y(t+1) with d x_{k+1} = A_k d x_k + B u_k, d x_0 = 0 — the forward form of
-// the adjoint sweep that produced Phi (drone.hip), so the values agree with rowmax_kernel<3, true> to rounding.
+// A22 [S][axes][ld], W [3][S][2][ld] and base [3][S][ld] (11 S floats per sample).  (G_i x)_{j,t} =
+// W[j,t,x] dp_x(t+1) + W[j,t,y] dp_y(t+1) with d x_{k+1} = A_k d x_k + B x_k, d x_0 = 0 — the forward form of
+// the adjoint sweep that produced Phi (drone.hip), evaluated in fp64 on the fp32 tables.
 __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
     rato_drone_params P, const float* __restrict__ mass, const float* __restrict__ A22, int a22_axes,
-    const float* __restrict__ W, const float* __restrict__ g_up, const float* __restrict__ us,
+    const float* __restrict__ W, const float* __restrict__ base, double sign, const double* __restrict__ xs,
     float* __restrict__ m_out, int* __restrict__ arg_out) {
   const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
   if (m >= P.M) return;
   const size_t ld = (size_t)P.ld;
   const int S = P.S;
-  const float inv_m = 1.0f / mass[m];
-  const float a21 = -P.kp * P.dt * inv_m, dtm = P.dt * inv_m;
-  float px = 0.0f, vx = 0.0f, py = 0.0f, vy = 0.0f;   // d x_t (t = 0)
-  float best = -INFINITY;
+  const double dt = (double)P.dt;
+  const double inv_m = 1.0 / (double)mass[m];
+  const double a21 = -(double)P.kp * dt * inv_m, dtm = dt * inv_m;
+  double px = 0.0, vx = 0.0, py = 0.0, vy = 0.0;   // d x_t (t = 0)
+  double best = -INFINITY;
   int best_idx = 0;
   constexpr int TB = 8;   // steps per batch: the 11 loads of a step do not depend on the recursion, so a batch
                           // issues 88 loads back to back and only then runs its 8 dependent steps
@@ -402,20 +338,20 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
       for (int j = 0; j < 3; ++j) {
         wv[i][j][0] = W[(((size_t)j * S + t) * 2 + 0) * ld + m];
         wv[i][j][1] = W[(((size_t)j * S + t) * 2 + 1) * ld + m];
-        gu[i][j] = g_up[((size_t)j * S + t) * ld + m];
+        gu[i][j] = base[((size_t)j * S + t) * ld + m];
       }
     }
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = t0 + i;
       if (t < S) {
-        const float ux = us[t * 3 + 0], uy = us[t * 3 + 1];
-        const float npx = px + P.dt * vx, npy = py + P.dt * vy;
-        const float nvx = a21 * px + a2[i][0] * vx + dtm * ux, nvy = a21 * py + a2[i][1] * vy + dtm * uy;
+        const double ux = xs[t * 3 + 0], uy = xs[t * 3 + 1];
+        const double npx = px + dt * vx, npy = py + dt * vy;
+        const double nvx = a21 * px + (double)a2[i][0] * vx + dtm * ux, nvy = a21 * py + (double)a2[i][1] * vy + dtm * uy;
         px = npx; py = npy; vx = nvx; vy = nvy;             // d x_{t+1}
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const float v = wv[i][j][0] * px + wv[i][j][1] * py - gu[i][j];
+          const double v = (double)wv[i][j][0] * px + (double)wv[i][j][1] * py + sign * (double)gu[i][j];
           const int r = j * S + t;
           if (v > best || (v == best && r < best_idx)) {   // smallest row index among equal values
             best = v;
@@ -425,46 +361,46 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
       }
     }
   }
-  m_out[m] = best;
+  m_out[m] = (float)best;
   arg_out[m] = best_idx;
 }
 
 }  // namespace
 
 extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
-                                          int32_t a22_axes, const float* W, const float* g_up, const float* us,
-                                          float* m_out, int32_t* arg_out, void* stream) {
+                                          int32_t a22_axes, const float* W, const float* base, double sign,
+                                          const double* xs, float* m_out, int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !g_up || !us ||
-      !m_out || !arg_out || (a22_axes != 2 && a22_axes != 3))
+  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !base || !xs ||
+      !m_out || !arg_out || (a22_axes != 2 && a22_axes != 3) || (sign != 1.0 && sign != -1.0))
     return RATO_EINVAL;
   dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_rowmax_implicit_kernel, grid, block, 0, rato::as_stream(stream), *p, mass, A22, a22_axes, W,
-                     g_up, us, m_out, arg_out);
+                     base, sign, xs, m_out, arg_out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
 
 extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int32_t R, int32_t S, int64_t M,
-                               int64_t ld, const float* g_up, const float* us, int32_t n_u, float* m_out,
-                               int32_t* arg_out, void* stream) {
+                               int64_t ld, const float* base, double sign, const double* xs, int32_t n_u,
+                               float* m_out, int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!G || !g_up || !us || !m_out || !arg_out || M <= 0 || S < 1 || ld < M || n_u < 2 || (tile != 64 && tile != 256) ||
-      (R != 1 && R != 3))
+  if (!G || !base || !xs || !m_out || !arg_out || M <= 0 || S < 1 || ld < M || n_u < 2 || (tile != 64 && tile != 256) ||
+      (R != 1 && R != 3) || (sign != 1.0 && sign != -1.0))
     return RATO_EINVAL;
-  const size_t lds = (size_t)S * 8 + RM_NW * 64 * 8 + 16;
+  const size_t lds = (size_t)S * 16 + RM_NW * 64 * 12 + 16;
   if (lds > 64 * 1024) return RATO_EINVAL;
   dim3 grid((unsigned)((M + 63) / 64)), block(RM_NW * RATO_WAVE);
   hipStream_t st = rato::as_stream(stream);
   if (R == 3 && W)
-    hipLaunchKernelGGL((rowmax_kernel<3, true>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us, n_u,
-                       m_out, arg_out);
+    hipLaunchKernelGGL((rowmax_kernel<3, true>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, base, sign, xs,
+                       n_u, m_out, arg_out);
   else if (R == 3)
-    hipLaunchKernelGGL((rowmax_kernel<3, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us,
-                       n_u, m_out, arg_out);
+    hipLaunchKernelGGL((rowmax_kernel<3, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, base, sign,
+                       xs, n_u, m_out, arg_out);
   else if (!W)
-    hipLaunchKernelGGL((rowmax_kernel<1, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, g_up, us,
-                       n_u, m_out, arg_out);
+    hipLaunchKernelGGL((rowmax_kernel<1, false>), grid, block, lds, st, G, W, tile, S, (long)M, (long)ld, base, sign,
+                       xs, n_u, m_out, arg_out);
   else
     return RATO_EINVAL;
   RATO_LAUNCH_CHECK();
@@ -472,58 +408,40 @@ extern "C" int rato_saa_rowmax(const float* G, const float* W, int32_t tile, int
 }
 
 extern "C" int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass, const float* A22,
-                                             int32_t a22_axes, const float* W, const float* g_up,
+                                             int32_t a22_axes, const float* W, const float* base,
                                              const float* m_base, const int32_t* arg_base, const double* stats_base,
                                              int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
-                                             float* part, void* stream) {
+                                             double* part, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!p || p->M <= 0 || p->S < 2 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !g_up || !m_base ||
-      !arg_base || !stats_base || !part || K < 1 || K > 65535 || stats_stride < 10 || (a22_axes != 2 && a22_axes != 3))
+  if (!p || p->M <= 0 || p->S < 2 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !base || !m_base ||
+      !arg_base || !stats_base || !part || K < 1 || K > 65535 || (!slots && K != 1) || stats_stride < 11 ||
+      (a22_axes != 2 && a22_axes != 3))
     return RATO_EINVAL;
-  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (p->S - 1) + 1) * sizeof(float);
+  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (p->S - 1) + 1) * sizeof(double);
   dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_tail_rows_implicit_kernel, grid, block, lds, rato::as_stream(stream), *p, mass, A22,
-                     a22_axes, W, g_up, m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
+                     a22_axes, W, base, m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
 
 extern "C" int rato_saa_tail_rows_batch(const float* G, const float* W, int64_t ld, int32_t tile, int32_t R, int32_t S,
-                                        int64_t M, const float* g_up, const float* m_base, const int32_t* arg_base,
+                                        int64_t M, const float* base, const float* m_base, const int32_t* arg_base,
                                         const double* stats_base, int64_t stats_stride, const int32_t* slots,
-                                        int32_t K, double alphaM, float* part, void* stream) {
+                                        int32_t K, double alphaM, double* part, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!G || !g_up || !m_base || !arg_base || !stats_base || !slots || !part || M <= 0 || S < 2 || K < 1 || K > 65535 ||
-      ld < M || stats_stride < 10 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
+  if (!G || !base || !m_base || !arg_base || !stats_base || !part || M <= 0 || S < 2 || K < 1 || K > 65535 ||
+      (!slots && K != 1) || ld < M || stats_stride < 11 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
     return RATO_EINVAL;
-  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (S - 1) + 1) * sizeof(float);
+  const size_t lds = (size_t)(RATO_BLOCK / 64) * (2 * (S - 1) + 1) * sizeof(double);
   dim3 grid((unsigned)rato::nblocks_for((int32_t)M), (unsigned)K), block(RATO_BLOCK);
   hipStream_t st = rato::as_stream(stream);
   if (R == 3)
-    hipLaunchKernelGGL(tail_rows_batch_kernel<3>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, g_up, m_base,
+    hipLaunchKernelGGL(tail_rows_batch_kernel<3>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, base, m_base,
                        arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   else
-    hipLaunchKernelGGL(tail_rows_batch_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, g_up, m_base,
+    hipLaunchKernelGGL(tail_rows_batch_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, base, m_base,
                        arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
-  RATO_LAUNCH_CHECK();
-  return RATO_OK;
-}
-
-extern "C" int rato_saa_tail_rows(const float* G, const float* W, int64_t ld, int32_t tile, int32_t R, int32_t S,
-                                  int64_t M, const float* m_vals, const int32_t* arg, float tstar, float lambda,
-                                  const double* stats_dev, double alphaM, float* part, void* stream) {
-  RATO_CLEAR_ERROR();
-  if (!G || !m_vals || !arg || !part || M <= 0 || S < 2 || (tile != 64 && tile != 256) || (R != 1 && R != 3))
-    return RATO_EINVAL;
-  const size_t lds = (size_t)(RATO_BLOCK / 64) * 2 * (S - 1) * sizeof(float);
-  dim3 grid((unsigned)rato::nblocks_for((int32_t)M)), block(RATO_BLOCK);
-  hipStream_t st = rato::as_stream(stream);
-  if (R == 3)
-    hipLaunchKernelGGL(tail_rows_kernel<3>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, m_vals, arg, tstar, lambda,
-                       stats_dev, alphaM, part);
-  else
-    hipLaunchKernelGGL(tail_rows_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, m_vals, arg, tstar, lambda,
-                       stats_dev, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
     zmax = fmaxf(zmax, gt);
     if (lead && valid) {
       const float dirv = -(m0 * (Eu[(t + 1) * 2 + 0] - tpx) + m1 * (Eu[(t + 1) * 2 + 1] - tpy));
-      g_up[(size_t)t * M + m] = -gt + dirv;  // driving.py:295
+      g_up[(size_t)t * M + m] = P.rows_out ? gt : (-gt + dirv);  // driving.py:295; rows_out = 1: g itself
     }
     const int row = rato::pair_row_offset(t);
 #pragma unroll
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
           o[RT] = o1;
         }
       }
-      if (valid) g_up[(size_t)t * M + m] = -gt + acc;        // driving.py:295
+      if (valid) g_up[(size_t)t * M + m] = P.rows_out ? gt : (-gt + acc);        // driving.py:295; rows_out = 1: g itself
     }
     task = next_task();
   }

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       if (valid) {
         W[(((size_t)j * S + t) * 2 + 0) * ld + m] = wx;
         W[(((size_t)j * S + t) * 2 + 1) * ld + m] = wy;
-        g_up[((size_t)j * S + t) * ld + m] = -gj + wx * dp[0] + wy * dp[1];   // -g + (grad g) . u   (drone_risk.py:278)
+        // -g + (grad g) . u   (drone_risk.py:278), or -- rows_out = 1 -- the constraint value g itself
+        g_up[((size_t)j * S + t) * ld + m] = P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]);
       }
     }
 #pragma unroll
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_kernel(
         wx[j][i] = -(2.0f * q00[j][i] * dx + qs[j][i] * dy);
         wy[j][i] = -(qs[j][i] * dx + 2.0f * q11[j][i] * dy);
         zmax[i] = fmaxf(zmax[i], gj);
-        gu[i] = -gj + wx[j][i] * dp[0][i] + wy[j][i] * dp[1][i];
+        gu[i] = P.rows_out ? gj : (-gj + wx[j][i] * dp[0][i] + wy[j][i] * dp[1][i]);
       }
       if (lead && any_valid) vstore<SPL>(g_up + ((size_t)j * S + t) * ld + m0, gu);
     }
@@ -919,8 +920,8 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
       }
       if (valid) {
 #pragma unroll
-        for (int j = 0; j < NOBS; ++j)  // g_up = -g + (grad g) . u   (drone_risk.py:278)
-          g_up[((size_t)j * S + t) * ld + m] = -gj[j] + wx[j] * accx + wy[j] * accy;
+        for (int j = 0; j < NOBS; ++j)  // g_up = -g + (grad g) . u   (drone_risk.py:278); rows_out = 1: g itself
+          g_up[((size_t)j * S + t) * ld + m] = P.rows_out ? gj[j] : (-gj[j] + wx[j] * accx + wy[j] * accy);
       }
     }
     task = next_task();
@@ -956,7 +957,6 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   }
 }
 
-#include "drone_rows_persistent.h"
 
 unsigned* take_tile_queue(hipStream_t stream) {   // this stream's queue (NULL: none left); address looked up once
   static unsigned* queues = nullptr;
@@ -1145,40 +1145,6 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     if (slots_env >= 1 && slots_env < per_cu) per_cu = slots_env;
     const int slots = cus * per_cu;
     const int n_tiles = (p->M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
-    // Resident workgroups with double-buffered tables (drone_rows_persistent.h): built to hide the staging + rollout of
-    // every tile behind the previous tile's sweeps; measured SLOWER than one tile per workgroup on every box (M = 1e5,
-    // S = 50, alternating: products 0.559-0.608 -> 0.569-0.617 ms, factored 0.224-0.255 -> 0.246-0.269 ms; balanced
-    // grids of 224 / 196 workgroups no better) -- profiles/r02_ab_rows.txt.  Off by default, kept for A/B runs and
-    // covered by a bit-identity test against the default kernel (RATO_ROWS_PERSISTENT=1).
-    static const int persistent_knob = [] { const char* e = getenv("RATO_ROWS_PERSISTENT"); return e ? atoi(e) : 0; }();
-    const int persistent = dW ? persistent_knob : 0;   // the A/B kernel reads a materialised noise array
-    const size_t lds_p = rowsp_lds_floats(p->S) * sizeof(float);
-    if (persistent && lds_p <= ROWS_LDS_MAX && n_tiles >= 2 * cus) {
-      static std::atomic<size_t> lds_attr_set_p{64 * 1024};
-      if (lds_p > lds_attr_set_p.load()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_persistent_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-        if (e == hipSuccess)
-          e = hipFuncSetAttribute(reinterpret_cast<const void*>(drone_linearize_rows_persistent_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-        if (e != hipSuccess) return RATO_EHIP - (int)e;
-        lds_attr_set_p.store(lds_p);
-      }
-      // balanced grid: every workgroup gets the same number of tiles (the last one possibly one fewer), so that all
-      // of them finish together instead of a few running one more tile alone
-      static const int g_env = [] { const char* e = getenv("RATO_ROWS_G"); return e ? atoi(e) : 0; }();
-      const int per_wg = (n_tiles + cus - 1) / cus;
-      int gp = g_env > 0 ? g_env : (n_tiles + per_wg - 1) / per_wg;
-      if (gp > cus) gp = cus;
-      if (W)
-        hipLaunchKernelGGL(drone_linearize_rows_persistent_kernel<true>, dim3(gp), dim3(PR_NW * RATO_WAVE), lds_p, st, *p,
-                           n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
-      else
-        hipLaunchKernelGGL(drone_linearize_rows_persistent_kernel<false>, dim3(gp), dim3(PR_NW * RATO_WAVE), lds_p, st,
-                           *p, n_tiles, us, dW, mass, Qsym, G, W, A22, g_up, Z, part);
-      RATO_LAUNCH_CHECK();
-      return RATO_OK;
-    }
     const int max_split = (p->S + 3) / 4 < 1 ? 1 : (p->S + 3) / 4;   // keep >= 4 row tasks per workgroup
     int split = 1, n_whole = n_tiles;
     if (n_tiles < slots) {   // small batch: every tile split so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us)
@@ -1191,40 +1157,19 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
       if (split > max_split) split = max_split;
       if (split < 1) split = 1;
       n_whole = split > 1 ? 0 : n_tiles;
-    } else {                 // large batch: the last round's tiles as quarter-size work units (shorter drain)
-      // Measured (tools/tail_sweep.sh, M = 1e5, S = 50, same box, alternating): split 1 / 2 / 4 / 8 over the last round
-      // = 0.557-0.583 / 0.565-0.597 / 0.582-0.607 / 0.625-0.633 ms (products) and 0.237 / 0.231-0.238 / 0.261-0.268 /
-      // 0.342-0.348 ms (factored): every extra work unit spends ~15-25 us staging and rolling out in one of only 512
-      // LDS-limited slots, which costs more slot time than the shorter drain returns.  Off by default; the knobs stay
-      // for A/B runs.
-      static const int tail_split = [] { const char* e = getenv("RATO_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
-      static const int tail_pct = [] { const char* e = getenv("RATO_TAIL_PCT"); return e ? atoi(e) : 100; }();
-      split = tail_split > max_split ? max_split : tail_split;
-      if (split > 1) {
-        long tail_tiles = (long)slots * tail_pct / 100;
-        if (tail_tiles > n_tiles) tail_tiles = n_tiles;
-        n_whole = n_tiles - (int)tail_tiles;
-      } else {
-        split = 1;
-      }
     }
+    // (Splitting the tiles of the last round of a STATIC grid was measured twice and rejected: every extra work unit
+    // spends ~15-25 us staging and rolling out in one of only 512 LDS-limited slots -- profiles/README.md.)
     int grid = n_whole + (n_tiles - n_whole) * split, stride = 0;
     unsigned* queue = nullptr;
     // Large batches: a grid that fills every slot once + a global tile counter (see the kernel).  Why: with one tile
     // per workgroup the timeline (tools/timeline.py, -DRATO_DIAG=4, M = 1e5) shows the workgroups with an even block
     // index -- every other XCD -- running their tiles in 145-151 us and the odd ones in 174-176 us, the hardware
     // having dealt the grid out to the XCDs in advance: the fast half of the chip is done at 500-518 us and idles
-    // until the slow half finishes at 585-590 us.  RATO_ROWS_DYNAMIC=0 switches it off (A/B);
-    // RATO_ROWS_BALANCED=1 selects the static several-tiles-per-workgroup form instead (391 x 4 at M = 1e5), which
-    // only removes the 27-tile last round (-3.5 % for the products output, +8 % for the factored one).
+    // until the slow half finishes at 585-590 us.  RATO_ROWS_DYNAMIC=0 switches it off (the bit-identity test's base).
     static const int dynamic_env = [] { const char* e = getenv("RATO_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
-    static const int balanced_env = [] { const char* e = getenv("RATO_ROWS_BALANCED"); return e ? atoi(e) : 0; }();
     if (split == 1 && n_tiles > slots) {
-      if (balanced_env == 1) {
-        const int per_wg = (n_tiles + slots - 1) / slots;
-        grid = (n_tiles + per_wg - 1) / per_wg;   // <= slots: every workgroup is resident from the start
-        stride = grid;
-      } else if (dynamic_env >= 1) {
+      if (dynamic_env >= 1) {
         // Measured, same box, alternating (profiles/r02_ab_rows.txt): factored output -7 % at M = 1e5, -9 % at M = 1e6;
         // products output -1.5 % at M = 1e5, and -- since its tiles start on 2 MiB boundaries (rato_packed_tile_stride)
         // -- also at large batches: M = 4e5 2.148 / 2.147 ms against 2.176 / 2.213 static, M = 1e6 5.298 / 5.369 against

@@ -21,7 +21,8 @@ namespace {
 // bandwidth-bound), then a fixed-order LDS tree gives a run-to-run identical fp64 sum.
 constexpr int SP_COLS = 16, SP_ROWS = 64;
 
-__device__ __forceinline__ void sum_partials_block(int col_block, const float* __restrict__ part, int nblocks,
+template <typename T>
+__device__ __forceinline__ void sum_partials_block(int col_block, const T* __restrict__ part, int nblocks,
                                                    int ncols, double scale, double* __restrict__ out) {
   __shared__ double red[SP_ROWS][SP_COLS + 1];
   const int cx = threadIdx.x % SP_COLS, ry = threadIdx.x / SP_COLS;
@@ -30,10 +31,10 @@ __device__ __forceinline__ void sum_partials_block(int col_block, const float* _
   if (c < ncols) {
     int b = ry;
     for (; b + 3 * SP_ROWS < nblocks; b += 4 * SP_ROWS) {
-      const float v0 = part[(size_t)b * ncols + c];
-      const float v1 = part[(size_t)(b + SP_ROWS) * ncols + c];
-      const float v2 = part[(size_t)(b + 2 * SP_ROWS) * ncols + c];
-      const float v3 = part[(size_t)(b + 3 * SP_ROWS) * ncols + c];
+      const T v0 = part[(size_t)b * ncols + c];
+      const T v1 = part[(size_t)(b + SP_ROWS) * ncols + c];
+      const T v2 = part[(size_t)(b + 2 * SP_ROWS) * ncols + c];
+      const T v3 = part[(size_t)(b + 3 * SP_ROWS) * ncols + c];
       a0 += (double)v0;
       a1 += (double)v1;
       a2 += (double)v2;
@@ -51,7 +52,8 @@ __device__ __forceinline__ void sum_partials_block(int col_block, const float* _
   if (ry == 0 && c < ncols) out[c] = red[0][cx] * scale;
 }
 
-__global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const float* __restrict__ part, int nblocks,
+template <typename T>
+__global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const T* __restrict__ part, int nblocks,
                                                                        int ncols, double scale,
                                                                        double* __restrict__ out) {
   sum_partials_block(blockIdx.x, part, nblocks, ncols, scale, out);
@@ -729,7 +731,17 @@ extern "C" int rato_sum_partials(const float* part, int32_t nblocks, int32_t nco
   RATO_CLEAR_ERROR();
   if (!part || !out || nblocks <= 0 || ncols <= 0) return RATO_EINVAL;
   dim3 grid((ncols + SP_COLS - 1) / SP_COLS), block(SP_COLS * SP_ROWS);
-  hipLaunchKernelGGL(sum_partials_kernel, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
+  hipLaunchKernelGGL(sum_partials_kernel<float>, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_sum_partials_f64(const double* part, int32_t nblocks, int32_t ncols, double scale, double* out,
+                                     void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!part || !out || nblocks <= 0 || ncols <= 0) return RATO_EINVAL;
+  dim3 grid((ncols + SP_COLS - 1) / SP_COLS), block(SP_COLS * SP_ROWS);
+  hipLaunchKernelGGL(sum_partials_kernel<double>, grid, block, 0, rato::as_stream(stream), part, nblocks, ncols, scale, out);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
@@ -805,7 +817,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     return RATO_OK;
   }
   if (part) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(sp_blocks), dim3(SP_COLS * SP_ROWS), 0, st, part, (int)nblocks,
+    hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sp_blocks), dim3(SP_COLS * SP_ROWS), 0, st, part, (int)nblocks,
                        (int)ncols, scale, sums_out);
   }
   // Grid: 4 elements per thread up to 256 workgroups, then more elements per thread (every workgroup flushes its

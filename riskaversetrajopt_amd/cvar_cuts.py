@@ -12,11 +12,29 @@ minimising over t (the Rockafellar-Uryasev identity) leaves a problem in (u, sla
 
 with t_risk = VaR_alpha(m(u)) + slack.  (*) is convex and piecewise linear; it is handled by Kelley cutting
 planes (the CVaR decomposition of Künzi-Bay & Mayer, 2006): the HOST solves a master QP with 3S+1 variables
-and one row per cut with the same OSQP-equivalent solver; the DEVICE, where the packed Jacobian lives,
-evaluates m(u) (one streaming read of G, rato_saa_rowmax), CVaR/VaR (rato_risk_stats) and the subgradient
-(1/(alpha M)) sum_{tail} G_i[r*_i, :] (rato_saa_tail_rows).  The optimum is the optimum of the reference's
+and one row per cut, solved exactly (dense_qp: least-distance programming through NNLS); the DEVICE, where the
+linearization lives, evaluates m(u) (rato_saa_rowmax / rato_drone_rowmax_implicit), selects the tail exactly
+(rato_risk_stats) and forms the cut -- the tail-weighted sums of the arg-max rows and of their offsets
+(rato_saa_tail_rows_batch / rato_drone_tail_rows_implicit).  The optimum is the optimum of the reference's
 QP (same feasible set and objective after projecting out y, t), so SCP iterates are comparable; checked
-against the full QP at small M in tests/test_gpu_scp.py.
+against the full QP in tests/test_gpu_scp.py to the north star's 1e-5.
+
+Numerics.  The device arrays are fp32 (the kernels' outputs); everything the master sees is fp64: the rows are
+evaluated, maximised and summed in double precision on the device, and a cut's value at the candidate is taken FROM
+the cut (value = gradient . x + offset, both from the same fp64 sums), so that value and gradient are consistent to
+1e-13 -- with fp32 rows (|G u| ~ 1e2) every cut carried ~1e-5 of noise and the iterates matched the full QP only to
+2e-4 (drone) / 2e-3 (driving).  The rows are taken in DELTA form, rows(u) = g + G (u - u_k) (``u_lin``; the linearize
+kernels write g instead of g_up = -g + G u_k: params.rows_out = 1): algebraically the reference's
+(G u - g_up)_r (drone_risk.py:278, :357-364), without the fp32 rounding of g_up (|g_up| ~ 1e2 against |g| ~ 1e-2 on
+the rows that decide the tail).
+
+``mode='baseline'`` (drone_risk.py:303-325, driving.py:320-329): the M R_s rows kappa (G_i u - g_up_i)_r <= -pad are
+the single constraint max_i m_i(u) <= -pad / kappa = CVaR_{1/M}(m(u)) <= rhs0: the same machinery with one tail
+sample, no slack coupling (y, slack, t_risk are unconstrained there: slack sits at the minimiser -1 of its penalty).
+``with_cvar=False`` is the reference's relaxation of the first SCP iterations (drone_risk.py:413-417: rows scaled by
+1e-7 inside [-0.1, 0.1], i.e. |row| <= 1e6, never active; driving.py:411-415): u is the minimum-effort control that
+meets the final constraints, slack = -1 (its row ``-slack <= 0`` is relaxed with the others), and t_risk, which the
+relaxed QP leaves undetermined, is reported as 0.
 
 Cut recycling.  A cut is a tail weighting w (sum = alpha M) and one row r_i per sample; under ANY linearization
 CVaR(m(u)) >= (1/(alpha M)) sum_i w_i [(G_i u)_{r_i} - g_up_{i,r_i}].  The (w, r) of the cuts that were active at
@@ -55,12 +73,12 @@ def _threadpool_controller():
 
 class CvarCutSolver:
     def __init__(self, lib, device, *, n_u, S, M, ld, R, alpha, dt, Rcost, slack_penalty, u_min, u_max,
-                 recycle=True, group=None, world=1):
+                 recycle=True, group=None, world=1, mode='saa', rhs0=0.0):
         self.lib, self.device = lib, device
         self.n_u, self.S, self.M, self.ld, self.R = n_u, S, M, ld, R
         self.group, self.world = group, int(world)      # M = samples of THIS rank; M * world in total
         self.M_total = M * self.world
-        self.alpha = alpha
+        self.mode = mode
         self.nU = n_u * S
         self.u_min, self.u_max = float(u_min), float(u_max)
         # drone: (rato_drone_params, mass, A22, a22_axes) -> Jacobian-free evaluation of m(u); with G = None in
@@ -71,82 +89,112 @@ class CvarCutSolver:
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
         self.q = np.zeros(n)
         self.q[-1] = float(slack_penalty)
-        self.c_s = (self.M_total * (1.0 - alpha) - 1.0) / (alpha * self.M_total)
-        # device scratch.  Every oracle call writes into one slot of three rings (m values, arg-max rows,
-        # [statistics (10) | subgradient sums (2(S-1))]); slots of cuts worth recycling survive the solve.
-        e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=device)
+        if mode == 'saa':
+            self.alpha = float(alpha)
+            self.alphaM = self.alpha * self.M_total           # tail mass of a cut
+            self.c_s = (self.M_total * (1.0 - alpha) - 1.0) / (alpha * self.M_total)
+            self.rhs0 = 0.0
+        elif mode == 'baseline':
+            # max_i m_i(u) = CVaR with a tail of exactly one sample; (1 + 1e-9) keeps floor(alpha M) = 1 in fp64
+            self.alpha = (1.0 + 1e-9) / self.M_total
+            self.alphaM = 1.0
+            self.c_s = 0.0
+            self.rhs0 = float(rhs0)
+        else:
+            raise ValueError(f"mode must be 'saa' or 'baseline', got {mode!r}")
         self.recycle = recycle
         self.keep_max = 48
         self.cap = (160 if recycle else 1) + 1          # last slot: scratch for calls beyond the ring
-        self.nres = stats.N_STATS + 2 * max(S - 1, 0) + 1     # statistics | subgradient sums | (implicit: sum w g_up)
+        self.nc = 2 * max(S - 1, 0) + 1
+        self.nres = stats.N_STATS + self.nc
+        self.keep = []                                   # slots kept from the previous solve
+        self.u_lin = None                                # linearization point of the delta form (None: reference form)
+        if device is not None:                           # (None: a host oracle overrides evaluate / relinearize_kept_cuts
+            self._alloc_device(device)                   #  -- tests/_host_cuts.py, the fp64 checker of this loop)
+
+    def _alloc_device(self, device):
+        """Device scratch.  Every oracle call writes into one slot of three rings (m values, arg-max rows,
+        [statistics | cut sums (2(S-1) gradient entries, then the offset sum)]); slots of cuts worth recycling
+        survive the solve."""
+        S, M, n_u, recycle = self.S, self.M, self.n_u, self.recycle
+        e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=device)
         self.ring_m = e(self.cap, M)
         self.ring_arg = e(self.cap, M, dt=torch.int32)
         self.ring_res = torch.zeros((self.cap, self.nres), dtype=torch.float64, device=device)
-        self.keep = []                                   # slots kept from the previous solve
         self.nblk = (M + 255) // 256
-        self.nc = 2 * max(S - 1, 0) + 1
-        self.part = e(self.nblk, self.nc) if S > 1 else None
-        self.part_b = e(self.nblk, self.keep_max * self.nc) if (recycle and S > 1) else None
+        self.part = e(self.nblk, self.nc, dt=torch.float64) if S > 1 else None
+        self.part_b = e(self.nblk, self.keep_max * self.nc, dt=torch.float64) if (recycle and S > 1) else None
         self.sums_b = torch.zeros(self.keep_max * self.nc, dtype=torch.float64, device=device)
         self.sums_b_host = torch.zeros(self.keep_max * self.nc, dtype=torch.float64).pin_memory()
         self.slots_dev = torch.zeros(self.keep_max, dtype=torch.int32, device=device)
         self.slots_host = torch.zeros(self.keep_max, dtype=torch.int32).pin_memory()
         self.ws = stats.new_workspace(self.M_total, device)
         self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
-        self.u_host = torch.zeros((S, n_u), dtype=torch.float32).pin_memory()
-        self.us_dev = e(S, n_u)
+        self.x_host = torch.zeros((S, n_u), dtype=torch.float64).pin_memory()
+        self.x_dev = e(S, n_u, dt=torch.float64)
+
+    # ---- the two forms of the rows ------------------------------------------
+    def _form(self):
+        """-> (sign, x0): rows(u) = G (u - x0) + sign * base  (delta form: base = g, x0 = u_k; reference form:
+        base = g_up, x0 = 0)."""
+        if self.u_lin is None:
+            return -1.0, np.zeros(self.nU)
+        return 1.0, self.u_lin
 
     # ---- device oracle -----------------------------------------------------
-    def evaluate(self, G, W, tile, g_up_raw, u_vec, slot=None):
-        """-> (phi = CVaR_alpha(m(u)), t* = VaR, g (nU,) subgradient of phi).  One upload of u, four stream-
-        ordered calls, ONE read-back (statistics + subgradient sums).  ``slot``: ring slot that receives the
-        call's m values / arg-max rows / statistics (default: the scratch slot)."""
+    def evaluate(self, G, W, tile, base, u_vec, slot=None):
+        """-> (phi = CVaR_alpha(m(u)), t* = VaR, g (nU,) subgradient of phi).  One upload of x = u - x0, four stream-
+        ordered calls, ONE read-back (statistics + cut sums).  ``slot``: ring slot that receives the call's m
+        values / arg-max rows / statistics (default: the scratch slot)."""
         S, M, n_u = self.S, self.M, self.n_u
         slot = self.cap - 1 if slot is None else slot
         m_buf, arg_buf, res = self.ring_m[slot], self.ring_arg[slot], self.ring_res[slot]
         tstream = torch.cuda.current_stream()
         st = _lib.C.c_void_p(tstream.cuda_stream)        # one stream lookup per call
-        self.u_host.copy_(torch.from_numpy(np.ascontiguousarray(u_vec, dtype=np.float64).reshape(S, n_u)))
-        self.us_dev.copy_(self.u_host, non_blocking=True)
+        sign, x0 = self._form()
+        x = np.ascontiguousarray(np.asarray(u_vec, dtype=np.float64) - x0)
+        self.x_host.copy_(torch.from_numpy(x.reshape(S, n_u)))
+        self.x_dev.copy_(self.x_host, non_blocking=True)
         if self.implicit is not None:
             p, mass, A22, axes = self.implicit
-            _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W),
-                                                           _lib.ptr(g_up_raw), _lib.ptr(self.us_dev),
-                                                           _lib.ptr(m_buf), _lib.ptr(arg_buf),
-                                                           st), "rato_drone_rowmax_implicit")
+            _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes,
+                                                           _lib.ptr(W), _lib.ptr(base), sign, _lib.ptr(self.x_dev),
+                                                           _lib.ptr(m_buf), _lib.ptr(arg_buf), st),
+                       "rato_drone_rowmax_implicit")
         else:
             _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
-                                                _lib.ptr(g_up_raw), _lib.ptr(self.us_dev), n_u, _lib.ptr(m_buf),
+                                                _lib.ptr(base), sign, _lib.ptr(self.x_dev), n_u, _lib.ptr(m_buf),
                                                 _lib.ptr(arg_buf), st), "rato_saa_rowmax")
         m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
         stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
-        nw = 2 * (S - 1)
-        if S > 1 and G is None:                  # generators-only linearization: rows regenerated from A22
-            p, mass, A22, axes = self.implicit
-            _lib.check(self.lib.rato_drone_tail_rows_implicit(
-                _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(g_up_raw), _lib.ptr(m_buf),
-                _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alpha * self.M_total),
-                _lib.ptr(self.part), st), "rato_drone_tail_rows_implicit")
+        if S > 1:
+            if G is None:                # generators-only linearization: rows regenerated from A22
+                p, mass, A22, axes = self.implicit
+                _lib.check(self.lib.rato_drone_tail_rows_implicit(
+                    _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(base),
+                    _lib.ptr(m_buf), _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alphaM),
+                    _lib.ptr(self.part), st), "rato_drone_tail_rows_implicit")
+            else:
+                _lib.check(self.lib.rato_saa_tail_rows_batch(
+                    _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(base), _lib.ptr(m_buf),
+                    _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alphaM), _lib.ptr(self.part),
+                    st), "rato_saa_tail_rows_batch")
             stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
-        elif S > 1:
-            part = self.part.view(-1)[:self.nblk * nw].view(self.nblk, nw)
-            _lib.check(self.lib.rato_saa_tail_rows(_lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M,
-                                                   _lib.ptr(m_buf),
-                                                   _lib.ptr(arg_buf), 0.0, 0.0, _lib.ptr(res),
-                                                   float(self.alpha * self.M_total), _lib.ptr(part),
-                                                   st), "rato_saa_tail_rows")
-            stats.sum_partials(part, out=res[stats.N_STATS:stats.N_STATS + nw], stream=st)
-        if S > 1 and self.world > 1:
-            res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
+            if self.world > 1:
+                res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
         r = self.res_host.numpy()
         g = np.zeros(self.nU)
         if S > 1:
-            g.reshape(S, n_u)[:S - 1, 0:2] = r[stats.N_STATS:stats.N_STATS + nw].reshape(S - 1, 2) / (self.alpha * self.M_total)
-        return float(r[1]), float(r[0]), g
+            sums = r[stats.N_STATS:] / self.alphaM
+            g.reshape(S, n_u)[:S - 1, 0:2] = sums[:self.nc - 1].reshape(S - 1, 2)
+            phi = float(g @ x + sign * sums[self.nc - 1])   # the cut's own value at the candidate (fp64, consistent with g)
+        else:
+            phi = float(r[1])                               # no control enters row t = 0: the value is a constant
+        return phi, float(r[0]), g
 
-    def relinearize_kept_cuts(self, G, W, tile, g_up_raw):
+    def relinearize_kept_cuts(self, G, W, tile, base):
         """The kept cuts under the current linearization -> (rows (K, nU), rhs (K,)):  rows[k].u - c_s s <= rhs[k].
         One batched launch + one partial-sum launch + one read-back."""
         K, S, M, n_u = len(self.keep), self.S, self.M, self.n_u
@@ -158,24 +206,26 @@ class CvarCutSolver:
         if G is None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_tail_rows_implicit(
-                _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(g_up_raw),
+                _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(base),
                 _lib.ptr(self.ring_m), _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres,
-                _lib.ptr(self.slots_dev), K, float(self.alpha * self.M_total), _lib.ptr(part),
+                _lib.ptr(self.slots_dev), K, float(self.alphaM), _lib.ptr(part),
                 _lib.current_stream()), "rato_drone_tail_rows_implicit")
         else:
             _lib.check(self.lib.rato_saa_tail_rows_batch(
-                _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(g_up_raw), _lib.ptr(self.ring_m),
+                _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(base), _lib.ptr(self.ring_m),
                 _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
-                float(self.alpha * self.M_total), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
+                float(self.alphaM), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
         stats.sum_partials(part, out=self.sums_b[:K * self.nc])
         if self.world > 1:
             self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
         self.sums_b_host.copy_(self.sums_b, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / (self.alpha * self.M_total)
+        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / self.alphaM
         rows = np.zeros((K, self.nU))
         rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
-        return rows, r[:, self.nc - 1].copy()
+        # cut k:  rows[k].(u - x0) + sign c0_k - c_s s <= rhs0
+        sign, x0 = self._form()
+        return rows, self.rhs0 + rows @ x0 - sign * r[:, self.nc - 1]
 
     # ---- master QP (host, exact: dense_qp) -----------------------------------------
     def solve(self, *args, **kwargs):
@@ -190,9 +240,12 @@ class CvarCutSolver:
         with ctl.limit(limits=4):
             return self._solve(*args, **kwargs)
 
-    def _solve(self, G, W, tile, g_up_raw, final_du, final_rhs, *, with_cvar=True, tol=1e-7, max_cuts=400,
+    def _solve(self, G, W, tile, base, final_du, final_rhs, *, u_lin=None, with_cvar=True, tol=1e-9, max_cuts=400,
                verbose=False):
+        """``base``: g_up [R][S][ld] of the linearize call (reference form), or -- with ``u_lin`` = the controls the
+        linearization was taken at -- its g output (delta form, params.rows_out = 1)."""
         nU, n = self.nU, self.nU + 1
+        self.u_lin = None if u_lin is None else np.asarray(u_lin, dtype=np.float64).reshape(-1).copy()
         F = np.hstack([np.asarray(final_du, dtype=np.float64), np.zeros((np.shape(final_du)[0], 1))])
         f = np.asarray(final_rhs, dtype=np.float64)
         Pd = self.P.toarray()
@@ -201,16 +254,19 @@ class CvarCutSolver:
         phi = tstar = np.nan
         status = "solved"
         n_cuts = 0
+        slack_row = with_cvar and self.mode == 'saa'    # -slack <= 0 (relaxed with the CVaR rows; absent in 'baseline')
         t0 = time.perf_counter()
         master = dense_qp.Master(Pd, self.q, F, f)      # equality elimination + whitening once per SCP iteration
-        master.add_rows(-I[nU:], [0.0])                 # slack >= 0
-        n_rows = 1
+        n_rows = 0
+        if slack_row:
+            master.add_rows(-I[nU:], [0.0])             # slack >= 0
+            n_rows = 1
         cut_rows = []                                   # (row of the master, ring slot) of every CVaR cut
         kept = list(self.keep) if (self.recycle and with_cvar) else []
         info["master_s"] += time.perf_counter() - t0
         if kept:
             t0 = time.perf_counter()
-            rows, rhs = self.relinearize_kept_cuts(G, W, tile, g_up_raw)
+            rows, rhs = self.relinearize_kept_cuts(G, W, tile, base)
             info["oracle_s"] += time.perf_counter() - t0
             t0 = time.perf_counter()
             master.add_rows(np.hstack([rows, np.full((len(kept), 1), -self.c_s)]), rhs)
@@ -244,9 +300,9 @@ class CvarCutSolver:
                 break
             t0 = time.perf_counter()
             slot = free.pop() if free else None
-            phi, tstar, g = self.evaluate(G, W, tile, g_up_raw, u_vec, slot)
+            phi, tstar, g = self.evaluate(G, W, tile, base, u_vec, slot)
             info["oracle_s"] += time.perf_counter() - t0
-            viol = phi - self.c_s * s
+            viol = phi - self.c_s * s - self.rhs0
             if verbose:
                 print(f"   cut {it:3d}: CVaR {phi:+.6e} slack {s:.3e} violation {viol:+.3e}")
             if viol <= tol:
@@ -254,8 +310,8 @@ class CvarCutSolver:
             if it == max_cuts:
                 status = "maximum cuts reached"
                 break
-            # phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= g_k.u_k - phi_k
-            master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [float(g @ u_vec - phi)])
+            # phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= rhs0 + g_k.u_k - phi_k
+            master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + float(g @ u_vec - phi)])
             if slot is not None:
                 cut_rows.append((n_rows, slot))
             n_rows += 1
@@ -277,6 +333,9 @@ class CvarCutSolver:
                 keep = [int(v) for v in pad[1:1 + int(pad[0])]]
             self.keep = keep
             info["recycled"] = len(kept)
-        info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=float(tstar + s),
+        # t_risk: VaR + slack where the CVaR rows are present (y, t eliminated at their optimum); the relaxed QP of
+        # the first iterations and the 'baseline' QP leave it undetermined (no row and no cost touches it): 0
+        t_risk = float(tstar + s) if slack_row else 0.0
+        info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=t_risk,
                     cuts=n_cuts, phi=float(phi), status=status)
         return info

@@ -215,7 +215,7 @@ class Model:
         return -g.t().double().cpu().numpy()
 
     # ---- linearization (K4) ------------------------------------------------
-    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True):
+    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True, rows_out=0):
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
@@ -245,6 +245,7 @@ class Model:
         final_du = reuse("final_du", (4, n_u * S))
         final_rhs = reuse("final_rhs", (4,))
         p = self._params(M)
+        p.rows_out = int(rows_out)      # 1: g_up receives g itself (base of the cut oracle's delta form, cvar_cuts.py)
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
             _lib.check(self._lib.rato_car_linearize_philox(
                 C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
@@ -258,7 +259,7 @@ class Model:
         if self.check_finite:
             stats.assert_finite("driving linearize", g_up, Z, final_du, final_rhs)
         return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M,
-                "cols_per_thread": cols_per_thread, "tile": tile}
+                "cols_per_thread": cols_per_thread, "tile": tile, "rows_out": int(rows_out)}
 
     def expand_g_obs_du(self, G, M=None):
         """packed G -> dense host (M, S, n_u*S); small M only.  G is either the tile-blocked
@@ -388,12 +389,13 @@ class Model:
         self._cut_solver = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-7, verbose=False):
+    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-9, verbose=False, delta=True):
         """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
-        scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint."""
-        if self.method != 'saa':
-            raise NotImplementedError("the reduced solve covers the 'saa' method")
-        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None))
+        scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint.
+        ``method='baseline'`` (driving.py:320-329): the rows (G_i u)_t <= g_up_{i,t} of every sample as the one
+        constraint max_i m_i(u) <= 0.  (At scp_iter 0 the reference's ``[n_x:]`` with n_x = 8 leaves the rows
+        t = 0..3 of sample 0 in its baseline QP; they are inactive at the initial guess and are not kept here.)"""
+        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), rows_out=1 if delta else 0)
         self._lin_buffers = r
         M, S = r["M"], self.S
         cs = getattr(self, "_cut_solver", None)
@@ -401,10 +403,13 @@ class Model:
             cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=M, R=1, alpha=self.alpha,
                                          dt=self.dt, Rcost=P.R, slack_penalty=self.SLACK_PENALTY,
                                          u_min=self.u_min, u_max=self.u_max,
-                                         group=getattr(self, "_group", None), world=getattr(self, "_world", 1))
+                                         group=getattr(self, "_group", None), world=getattr(self, "_world", 1),
+                                         mode=self.method, rhs0=0.0)
             self._cut_solver = cs
         info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
-                        r["final_rhs"].double().cpu().numpy(), with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
+                        r["final_rhs"].double().cpu().numpy(),
+                        u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
+                        with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
 
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------

@@ -128,9 +128,10 @@ class Model:
     def _inputs(self, inputs):
         return inputs if inputs is not None else (self._dW, self._mass, self._Qsym, self.M)
 
-    def _params(self, M, ld):
+    def _params(self, M, ld, rows_out=0):
         p = _lib.DroneParams()
         p.M, p.ld, p.S = M, ld, self.S
+        p.rows_out = int(rows_out)      # 1: the linearize kernels write g (not g_up = -g + G u_k) into their g_up buffer
         p.dt, p.beta, p.drag = self.dt, self.beta, self.drag_coefficient
         p.kp, p.kd = -float(P.feedback_gain[0, 0]), -float(P.feedback_gain[0, 3])
         p.tol = OSQP_TOL
@@ -226,7 +227,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True):
+                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -244,6 +245,8 @@ class Model:
         linearize launch on the launch stream (bench.py's roofline timing).
         ``reduce=False``: leave the per-block partial sums unreduced (``part``); ``step_device`` folds their
         reduction into the single launch of the risk statistics.
+        ``rows_out=1``: the ``g_up`` buffer receives the constraint values g at ``us_mat`` instead of
+        g_up = -g + (grad g).u (the base of the cut oracle's delta form, cvar_cuts.py).
         """
         dW, mass, Qsym, M = self._inputs(inputs)
         ld, S = mass.numel(), self.S
@@ -285,7 +288,7 @@ class Model:
         part = reuse("part", (nblk, 6 * S + 6), lambda: self._empty(nblk, 6 * S + 6))
         if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
             o = dict(o, sums=None)
-        p = self._params(M, ld)
+        p = self._params(M, ld, rows_out)
         if events is not None:
             events[0].record()
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
@@ -310,11 +313,11 @@ class Model:
         return {"G": G, "g_up": g_up[..., :M], "Z": (Z[:M] if want_Z else None),
                 "du_sum": sums[:6 * S].view(S, 6), "rhs_sum": sums[6 * S:], "sums": sums,
                 "part": part, "M": M, "_g_up": g_up, "_Z": Z, "cols_per_thread": cpt,
-                "samples_per_lane": spl, "tile": tile, "factored": bool(factored),
+                "samples_per_lane": spl, "tile": tile, "factored": bool(factored), "rows_out": int(rows_out),
                 "W": (Wf[..., :M] if factored else None), "_W": Wf,
                 "A22": (A22[..., :M] if A22 is not None else None), "_A22": A22}
 
-    def linearize_generators_device(self, us_mat, inputs=None, out=None):
+    def linearize_generators_device(self, us_mat, inputs=None, out=None, rows_out=0):
         """Generators-only linearization (rato_drone_linearize_generators): A22 [S][3][M], W [n_obs][S][2][M],
         g_up [n_obs][S][M], Z [M] and the sample sums -- everything ``solve_reduced`` needs -- without the S(S-1)
         Jacobian entries per sample (60 B instead of 245 B of HBM traffic per sample-step).  Same dict keys as
@@ -340,7 +343,7 @@ class Model:
         part = reuse("part", (nblk, 6 * S + 6), lambda: self._empty(nblk, 6 * S + 6))
         if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
             o = dict(o, sums=None)
-        p = self._params(M, ld)
+        p = self._params(M, ld, rows_out)
         _lib.check(self._lib.rato_drone_linearize_generators(
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(A22), _lib.ptr(Wf),
             _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()), "rato_drone_linearize_generators")
@@ -350,7 +353,7 @@ class Model:
         return {"G": None, "g_up": g_up[..., :M], "Z": Z[:M], "du_sum": sums[:6 * S].view(S, 6),
                 "rhs_sum": sums[6 * S:], "sums": sums, "part": part, "M": M, "_g_up": g_up, "_Z": Z,
                 "tile": 64, "factored": True, "W": Wf[..., :M], "_W": Wf, "A22": A22[..., :M], "_A22": A22,
-                "a22_axes": 3}
+                "a22_axes": 3, "rows_out": int(rows_out)}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
@@ -559,26 +562,31 @@ class Model:
         self._cut_solver = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-7, verbose=False, implicit=True, generators_only=None):
+    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-9, verbose=False, implicit=True, generators_only=None,
+                      delta=True):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
         planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
         Same optimum as define/update_problem + solve; -> (us_sol (S,n_u), t_risk, info).
+        ``method='baseline'`` (drone_risk.py:303-325): the rows 0.01 (G_i u - g_up_i)_r <= -1e-3 of every sample, as
+        the one constraint max_i m_i(u) <= -0.1 (row generation with the same oracle).
+        ``scp_iter < 2``: the reference's relaxation (drone_risk.py:413-417), see cvar_cuts.py.
         ``implicit``: evaluate the constraint rows of a candidate u from the step-Jacobian table (O(S) per sample,
         rato_drone_rowmax_implicit) instead of reading the packed Jacobian (O(S^2), rato_saa_rowmax).
         ``generators_only`` (default: same as ``implicit``): do not even write the Jacobian -- linearize to
-        (A22, W, g_up) only and regenerate the few rows the subgradients need (rato_drone_tail_rows_implicit)."""
-        if self.method != 'saa':
-            raise NotImplementedError("the reduced solve covers the 'saa' method")
+        (A22, W, g) only and regenerate the few rows the subgradients need (rato_drone_tail_rows_implicit).
+        ``delta``: rows as g + G (u - u_k) (the kernels write g) instead of G u - g_up (they write g_up)."""
         if generators_only is None:
             generators_only = implicit
         if generators_only and not implicit:
             raise ValueError("generators_only needs the implicit oracle")
+        rows_out = 1 if delta else 0
         if generators_only:
-            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None))
+            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None), rows_out=rows_out)
             self._gen_buffers = r
         else:
-            r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit)
+            r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit,
+                                      rows_out=rows_out)
             self._lin_buffers = r
         M, S = r["M"], self.S
         world = getattr(self, "_world", 1)
@@ -587,7 +595,8 @@ class Model:
             cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=r["_g_up"].shape[-1],
                                          R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
                                          slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max,
-                                         group=getattr(self, "_group", None), world=world)
+                                         group=getattr(self, "_group", None), world=world, mode=self.method,
+                                         rhs0=-1e-3 / self.MULTIPLIER)
             self._cut_solver = cs
         sums = r["sums"]
         if world > 1:                                     # sample means over ALL shards, summed in rank order
@@ -600,8 +609,9 @@ class Model:
         if implicit:
             dW, mass, Qsym, _ = self._inputs(None)
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
-        info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs, with_cvar=(scp_iter >= 2),
-                        tol=tol, verbose=verbose)
+        info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs,
+                        u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
+                        with_cvar=(scp_iter >= 2), tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
 
     # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------

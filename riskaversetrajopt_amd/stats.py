@@ -89,16 +89,22 @@ def monte_carlo_avar(Z_samples, alpha):
 
 
 def sum_partials(part, scale=1.0, out=None, stream=None):
-    """part: device (nblocks, ...) fp32 -> device double tensor of shape part.shape[1:]
-    holding scale * sum over blocks (fixed order, fp64)."""
+    """part: device (nblocks, ...) fp32 (or fp64: the block sums of the CVaR-cut oracle) -> device double tensor of
+    shape part.shape[1:] holding scale * sum over blocks (fixed order, fp64)."""
     lib = _lib.load()
-    _lib.require_f32_device(part, "part")
+    f64 = isinstance(part, torch.Tensor) and part.dtype == torch.float64
+    if f64:
+        if not (part.is_cuda and part.is_contiguous()):
+            raise _lib.RatoError("part must be a contiguous device tensor (no CPU fallback)")
+    else:
+        _lib.require_f32_device(part, "part")
     nblocks = part.shape[0]
     ncols = part[0].numel()
     if out is None:
         out = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
-    _lib.check(lib.rato_sum_partials(_lib.ptr(part), nblocks, ncols, float(scale), _lib.ptr(out),
-                                     _lib.current_stream() if stream is None else stream), "rato_sum_partials")
+    fn = lib.rato_sum_partials_f64 if f64 else lib.rato_sum_partials
+    _lib.check(fn(_lib.ptr(part), nblocks, ncols, float(scale), _lib.ptr(out),
+                  _lib.current_stream() if stream is None else stream), "rato_sum_partials")
     return out
 
 

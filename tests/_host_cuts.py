@@ -1,0 +1,101 @@
+"""Test helper: the reduced (u, slack) SCP subproblem with a HOST fp64 cut oracle.
+
+``riskaversetrajopt_amd.cvar_cuts.CvarCutSolver`` owns the cutting-plane loop and the exact master QP; its two
+oracle methods run on the device.  Here they are restated in NumPy fp64 on the fp64 oracle's dense linearization
+(``oracle.drone`` / ``oracle.driving``), so that
+  * the loop itself (elimination of y / t, 'baseline' mode, the relaxed first iterations, cut recycling) can be
+    checked against the full QP on the CPU, and
+  * the device path can be compared with an all-fp64 run of the SAME algorithm at batch sizes no host QP can take.
+Checker only: nothing in the package imports this."""
+import numpy as np
+
+from riskaversetrajopt_amd import cvar_cuts
+
+
+class HostCutSolver(cvar_cuts.CvarCutSolver):
+    """evaluate / relinearize_kept_cuts on dense fp64 rows:  G (M, R*S, nU),  base (M, R*S)."""
+
+    def __init__(self, **kw):
+        super().__init__(None, None, **kw)
+        self.cuts = {}                    # slot -> (weights (M,), arg-max rows (M,))
+
+    def _weights(self, m):
+        """tail weights of CVaR_alpha: 1 above the threshold, the remaining mass spread evenly over the ties with it"""
+        aM = self.alphaM
+        order = np.sort(m)[::-1]
+        t = order[min(int(np.ceil(aM - 1e-12)) - 1, m.size - 1)]
+        gt, eq = m > t, m == t
+        lam = min(max((aM - gt.sum()) / max(eq.sum(), 1), 0.0), 1.0)
+        return gt * 1.0 + eq * lam, float(t)
+
+    def evaluate(self, G, W, tile, base, u_vec, slot=None):
+        sign, x0 = self._form()
+        x = np.asarray(u_vec, dtype=np.float64) - x0
+        rows = G @ x + sign * base                                   # (M, R*S)
+        arg = rows.argmax(axis=1)
+        m = rows[np.arange(rows.shape[0]), arg]
+        w, t = self._weights(m)
+        if slot is not None:
+            self.cuts[slot] = (w, arg)
+        idx = np.arange(rows.shape[0])
+        g = (w[:, None] * G[idx, arg]).sum(axis=0) / self.alphaM
+        phi = float(w @ m) / self.alphaM
+        return phi, t, g
+
+    def relinearize_kept_cuts(self, G, W, tile, base):
+        K = len(self.keep)
+        if K == 0:
+            return np.zeros((0, self.nU)), np.zeros(0)
+        sign, x0 = self._form()
+        idx = np.arange(G.shape[0])
+        rows, rhs = np.zeros((K, self.nU)), np.zeros(K)
+        for k, slot in enumerate(self.keep):
+            w, arg = self.cuts[slot]
+            rows[k] = (w[:, None] * G[idx, arg]).sum(axis=0) / self.alphaM
+            rhs[k] = self.rhs0 + rows[k] @ x0 - sign * float(w @ base[idx, arg]) / self.alphaM
+        return rows, rhs
+
+
+class _ReducedOracleModel:
+    """``solve_reduced`` / ``initial_guess_us_mat`` on the fp64 oracle: what scp.run_*_reduced drives."""
+
+    def __init__(self, om, n_u, R, u_max, Rcost, slack_penalty, rhs0, first_cvar_iter, delta=True):
+        self.o, self.n_u, self.R, self.delta, self.first_cvar_iter = om, n_u, R, delta, first_cvar_iter
+        self.cs = HostCutSolver(n_u=n_u, S=om.S, M=om.M, ld=om.M, R=R, alpha=om.alpha, dt=om.dt, Rcost=Rcost,
+                                slack_penalty=slack_penalty, u_min=-u_max, u_max=u_max, mode=om.method, rhs0=rhs0)
+
+    def initial_guess_us_mat(self):
+        return self.o.initial_guess_us_mat()
+
+    def solve_reduced(self, us, scp_iter, tol=1e-10):
+        fdu, frhs, gdu, gup = self.linearization(us)
+        M, nU = self.o.M, self.n_u * self.o.S
+        G = gdu.reshape(M, -1, nU)
+        gup = gup.reshape(M, -1)
+        if self.delta:
+            base, u_lin = -(gup - G @ np.asarray(us, dtype=np.float64).reshape(-1)), us     # g = -(g_up - G u_k)
+        else:
+            base, u_lin = gup, None
+        info = self.cs.solve(G, None, 0, base, fdu, frhs, u_lin=u_lin, with_cvar=(scp_iter >= self.first_cvar_iter),
+                             tol=tol)
+        return info["us"], info["t_risk"], info
+
+
+class DroneReducedOracle(_ReducedOracleModel):
+    def __init__(self, om, delta=True):
+        from oracle import drone as od
+        super().__init__(om, 3, 3, od.u_max, od.R, 10000.0, -1e-3 / 0.01, 2, delta)
+
+    def linearization(self, us):
+        fdu, flo, _, gdu, gup = self.o.get_all_constraints_coeffs(us)
+        return fdu.mean(0), flo.mean(0), gdu, gup
+
+
+class DrivingReducedOracle(_ReducedOracleModel):
+    def __init__(self, om, delta=True):
+        from oracle import driving as ocar
+        super().__init__(om, 2, 1, ocar.u_max, ocar.R, 1000.0, 0.0, 1, delta)
+
+    def linearization(self, us):
+        fdu, flo, _, gdu, gup = self.o.get_all_constraints_coeffs(us)
+        return fdu[0], flo[0], gdu, gup

@@ -307,13 +307,13 @@ def test_padded_tile_layout_is_shared_by_producer_and_consumers():
     assert fresh["G"].data_ptr() != wrong["G"].data_ptr() and fresh["G"].stride(0) == stride
     # consumers: rowmax and CSC emission from the padded products buffer == from the factored one
     ld = rp["_g_up"].shape[-1]
-    u_dev = torch.as_tensor((us + 0.1).astype(np.float32), device=rp["G"].device).contiguous()
+    u_dev = torch.as_tensor(us + 0.1, dtype=torch.float64, device=rp["G"].device).contiguous()
     res = []
     for r in (rp, rf):
         m = torch.empty(M, dtype=torch.float32, device=u_dev.device)
         a = torch.empty(M, dtype=torch.int32, device=u_dev.device)
         _lib.check(lib.rato_saa_rowmax(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), r["tile"], 3, S, M, ld, _lib.ptr(r["_g_up"]),
-                                       _lib.ptr(u_dev), 3, _lib.ptr(m), _lib.ptr(a), _lib.current_stream()), "rowmax")
+                                       -1.0, _lib.ptr(u_dev), 3, _lib.ptr(m), _lib.ptr(a), _lib.current_stream()), "rowmax")
         vals = torch.empty(M * 3 * 2 * num_pairs(S), dtype=torch.float32, device=u_dev.device)
         _lib.check(lib.rato_emit_csc_values(_lib.ptr(r["G"]), _lib.ptr(r["_W"]), ld, r["tile"], 2, 3, S, M, 0.01,
                                             _lib.ptr(vals), _lib.current_stream()), "emit_csc")

@@ -148,9 +148,9 @@ def test_metric_config_generators_and_implicit_rowmax_vs_oracle():
     m_out = torch.empty(ld, dtype=torch.float32, device=d.device)
     arg = torch.empty(ld, dtype=torch.int32, device=d.device)
     p = d._params(M, ld)
-    u2d = d._us_device(u2)
+    u2d = torch.as_tensor(u2, dtype=torch.float64, device=d.device).contiguous()
     _lib.check(d._lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(d._mass), _lib.ptr(r["_A22"]), 3,
-                                                 _lib.ptr(r["_W"]), _lib.ptr(r["_g_up"]), _lib.ptr(u2d),
+                                                 _lib.ptr(r["_W"]), _lib.ptr(r["_g_up"]), -1.0, _lib.ptr(u2d),
                                                  _lib.ptr(m_out), _lib.ptr(arg), _lib.current_stream()),
                "rato_drone_rowmax_implicit")
     sub = od.Model(S, o.DWs[idx], o.masses[idx], o.obs_Qs[idx])
@@ -159,6 +159,18 @@ def test_metric_config_generators_and_implicit_rowmax_vs_oracle():
     m_o = rows.reshape(len(idx), -1).max(axis=1)
     m_d = m_out[torch.as_tensor(idx, device=d.device)].double().cpu().numpy()
     np.testing.assert_allclose(m_d, m_o, rtol=0, atol=2e-4 * max(1.0, np.abs(rows).max()))
+    # the delta form of the same rows, g + G (u2 - us) with the kernel writing g (rows_out = 1): the differences to the
+    # fp64 oracle are those of the fp32 tables times the SMALL step, not times |G u| ~ 1e2
+    rg = d.linearize_generators_device(us, rows_out=1)
+    x = torch.as_tensor(u2 - us, dtype=torch.float64, device=d.device).contiguous()
+    _lib.check(d._lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(d._mass), _lib.ptr(rg["_A22"]), 3,
+                                                 _lib.ptr(rg["_W"]), _lib.ptr(rg["_g_up"]), 1.0, _lib.ptr(x),
+                                                 _lib.ptr(m_out), _lib.ptr(arg), _lib.current_stream()),
+               "rato_drone_rowmax_implicit")
+    m_delta = m_out[torch.as_tensor(idx, device=d.device)].double().cpu().numpy()
+    print("rowmax vs fp64 oracle: reference form %.2e, delta form %.2e (|rows| <= %.1f)"
+          % (np.abs(m_d - m_o).max(), np.abs(m_delta - m_o).max(), np.abs(rows).max()))
+    np.testing.assert_allclose(m_delta, m_o, rtol=2e-5, atol=1e-4)          # the error of the fp32 rollout's g
 
 
 def test_rows_kernel_full_residency_S20():
