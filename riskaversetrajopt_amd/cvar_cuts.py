@@ -275,6 +275,7 @@ class CvarCutSolver:
             info["master_s"] += time.perf_counter() - t0
         free = [sl for sl in range(self.cap - 1) if sl not in set(kept)]
         in_master = np.zeros(2 * nU, dtype=bool)        # control bounds enter lazily: only the violated ones
+        bound_rows = []                                 # (first master row, variable indices, +1 upper / -1 lower)
         lam = np.zeros(0)
         for it in range(max_cuts + 1):
             t0 = time.perf_counter()
@@ -286,10 +287,12 @@ class CvarCutSolver:
                     break
                 if hi.any():
                     master.add_rows(I[:nU][hi], np.full(int(hi.sum()), self.u_max))
+                    bound_rows.append((n_rows, np.flatnonzero(hi), 1.0))
                     n_rows += int(hi.sum())
                     in_master[:nU] |= hi
                 if lo.any():
                     master.add_rows(-I[:nU][lo], np.full(int(lo.sum()), -self.u_min))
+                    bound_rows.append((n_rows, np.flatnonzero(lo), -1.0))
                     n_rows += int(lo.sum())
                     in_master[nU:] |= lo
             if self.world > 1:                      # every rank solved the same master; keep them bit-identical
@@ -336,6 +339,14 @@ class CvarCutSolver:
         # t_risk: VaR + slack where the CVaR rows are present (y, t eliminated at their optimum); the relaxed QP of
         # the first iterations and the 'baseline' QP leave it undetermined (no row and no cost touches it): 0
         t_risk = float(tstar + s) if slack_row else 0.0
+        # the master's multipliers, for whoever wants to certify the solution against the full QP (tests/_host_cuts.py:
+        # kkt_certificate): per cut (ring slot, lambda), the slack row, the control bounds that entered
+        lam_full = np.zeros(n_rows)
+        lam_full[:lam.shape[0]] = lam
+        info["multipliers"] = {"cuts": [(sl, float(lam_full[row])) for row, sl in cut_rows],
+                               "slack": float(lam_full[0]) if slack_row else 0.0,
+                               "bounds": [(idx, sgn, lam_full[r0:r0 + idx.size].copy()) for r0, idx, sgn in bound_rows],
+                               "uncertified_cuts": n_cuts + len(kept) - len(cut_rows)}
         info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=t_risk,
                     cuts=n_cuts, phi=float(phi), status=status)
         return info

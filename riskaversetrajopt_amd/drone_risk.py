@@ -563,7 +563,7 @@ class Model:
         return self
 
     def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-9, verbose=False, implicit=True, generators_only=None,
-                      delta=True):
+                      delta=True, factored=None):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
         planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
@@ -575,7 +575,8 @@ class Model:
         rato_drone_rowmax_implicit) instead of reading the packed Jacobian (O(S^2), rato_saa_rowmax).
         ``generators_only`` (default: same as ``implicit``): do not even write the Jacobian -- linearize to
         (A22, W, g) only and regenerate the few rows the subgradients need (rato_drone_tail_rows_implicit).
-        ``delta``: rows as g + G (u - u_k) (the kernels write g) instead of G u - g_up (they write g_up)."""
+        ``delta``: rows as g + G (u - u_k) (the kernels write g) instead of G u - g_up (they write g_up).
+        ``factored`` (with the Jacobian written): its representation, see ``linearize_device``."""
         if generators_only is None:
             generators_only = implicit
         if generators_only and not implicit:
@@ -586,7 +587,7 @@ class Model:
             self._gen_buffers = r
         else:
             r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit,
-                                      rows_out=rows_out)
+                                      rows_out=rows_out, factored=factored)
             self._lin_buffers = r
         M, S = r["M"], self.S
         world = getattr(self, "_world", 1)

@@ -26,7 +26,11 @@ class HostCutSolver(cvar_cuts.CvarCutSolver):
         t = order[min(int(np.ceil(aM - 1e-12)) - 1, m.size - 1)]
         gt, eq = m > t, m == t
         lam = min(max((aM - gt.sum()) / max(eq.sum(), 1), 0.0), 1.0)
-        return gt * 1.0 + eq * lam, float(t)
+        # reported VaR: the reference's sort(Z)[M - floor(alpha M) - 1] (drone_main_plot.py:649-651) -- when alpha M is
+        # an integer every t between that value and the next larger one minimises the Rockafellar-Uryasev function, and
+        # the QP leaves t_risk anywhere in that interval; the device reports the same end of it (rato_risk_stats out[0])
+        var = order[min(int(np.floor(aM + 1e-12)), m.size - 1)] if self.mode == 'saa' else t
+        return gt * 1.0 + eq * lam, float(var)
 
     def evaluate(self, G, W, tile, base, u_vec, slot=None):
         sign, x0 = self._form()
@@ -99,3 +103,65 @@ class DrivingReducedOracle(_ReducedOracleModel):
     def linearization(self, us):
         fdu, flo, _, gdu, gup = self.o.get_all_constraints_coeffs(us)
         return fdu[0], flo[0], gdu, gup
+
+
+def kkt_certificate(A, l, u, P, q, info, cut_data, *, n_c, n_u, S, M, R, kappa, alphaM, saa, u_max):
+    """Optimality certificate of a reduced solution against the reference's FULL QP (its own row and column layout:
+    SURVEY appendix A; ``A, l, u`` from ``get_constraints_coeffs`` / ``assemble.saa_constraints``, ``P, q`` from
+    ``get_objective_coeffs``).  The reduced solution is lifted to z = (u, y, slack, t) with y_i = max(-slack, m_i - t)
+    and the master's multipliers are spread over the full QP's rows:
+        cut k (multiplier lam_k, tail weights w_ki, rows r_ki):   kappa rho_{i, r_ki} += lam_k w_ki / (alpha M)
+        CVaR row:  mu = sum_k lam_k / (M alpha);   -y_i - slack rows:  pi_i = mu - kappa sum_r rho_ir;   -slack row: sigma
+        control bounds: the master's own bound multipliers;   final rows: least squares on the u-stationarity.
+    -> dict of the KKT residuals (all 0 at the optimum): primal feasibility, stationarity P z + q + A'y, dual sign,
+    complementarity.  ``cut_data[slot]`` = (weights (M,), arg-max rows (M,)) of every cut with a multiplier."""
+    nU, R_s = n_u * S, R * S
+    us = np.asarray(info["us"], dtype=np.float64).reshape(-1)
+    s = float(info["slack"])
+    mult = info["multipliers"]
+    assert mult["uncertified_cuts"] == 0
+    n_head = (1 + M) if saa else 0
+    obs0 = n_c + n_head
+    Aobs = A[obs0:obs0 + M * R_s]
+    rows_val = (Aobs[:, :nU] @ us - u[obs0:obs0 + M * R_s]) / kappa                    # (G_i u - g_up_i)_r (+ pad / kappa)
+    m_i = rows_val.reshape(M, R_s).max(axis=1)
+    if saa:
+        t = float(info["t_risk"])
+        y = np.maximum(-s, m_i - t)
+    else:
+        t, y = 0.0, np.zeros(M)
+    z = np.concatenate([us, y, [s, t]])
+    ydual = np.zeros(A.shape[0])
+    Lam = 0.0
+    for slot, lam in mult["cuts"]:
+        if lam <= 0.0:
+            continue
+        w, arg = cut_data[slot]
+        ydual[obs0 + np.arange(M) * R_s + arg] += lam * w / (alphaM * kappa)
+        Lam += lam
+    if saa:
+        mu = Lam / alphaM
+        ydual[n_c] = mu
+        rho_sum = ydual[obs0:obs0 + M * R_s].reshape(M, R_s).sum(axis=1)
+        ydual[n_c + 1:n_c + 1 + M] = mu - kappa * rho_sum
+        ydual[obs0 + M * R_s] = mult["slack"]
+    b0 = A.shape[0] - nU
+    for idx, sgn, lam in mult["bounds"]:
+        ydual[b0 + idx] += sgn * lam
+    stat = P @ z + q + A.T @ ydual
+    F = A[:n_c, :nU].toarray()
+    nu = np.linalg.lstsq(F.T, -stat[:nU], rcond=None)[0]
+    ydual[:n_c] = nu
+    stat = P @ z + q + A.T @ ydual
+    Az = A @ z
+    upper_gap, lower_gap = u - Az, Az - l
+    ineq = np.arange(A.shape[0]) >= n_c
+    comp = np.where(ydual > 0, ydual * np.where(np.isfinite(upper_gap), upper_gap, 0.0),
+                    -ydual * np.where(np.isfinite(lower_gap), lower_gap, 0.0))
+    wrong_sign = max(np.max(-ydual[ineq & ~np.isfinite(l)], initial=0.0),          # rows with only an upper bound: y >= 0
+                     0.0)
+    return {"primal": float(max(np.max(-upper_gap, initial=0.0), np.max(-lower_gap, initial=0.0))),
+            "stationarity": float(np.max(np.abs(stat))),
+            "dual_sign": float(wrong_sign),
+            "complementarity": float(np.max(np.abs(comp[ineq]), initial=0.0)),
+            "multiplier_scale": float(np.max(np.abs(ydual), initial=0.0)), "z": z, "y": ydual}

@@ -495,3 +495,57 @@ def test_reduced_scp_device_vs_fp64_host_oracle(system, M, alpha, iters):
           (np.abs(out["us"] - ref["us"]).max(), abs(out["t_risk"] - ref["t_risk"]), out["L2_error"][-1], ref["L2_error"][-1]))
     np.testing.assert_allclose(out["us"], ref["us"], rtol=0, atol=1e-5)
     assert abs(out["t_risk"] - ref["t_risk"]) < 1e-5
+
+
+def _device_cut_data(cs):
+    """(weights, arg-max rows) of every ring slot the last solve gave a multiplier to, from the device rings: the tail
+    rule of rato_saa_tail_rows_batch (1 above t = out[10], lambda on ties)"""
+    out = {}
+    for slot, lam in cs_last_cuts(cs):
+        m = cs.ring_m[slot].double().cpu().numpy()
+        arg = cs.ring_arg[slot].cpu().numpy()
+        st = cs.ring_res[slot].cpu().numpy()
+        t, n_gt, n_eq = np.float32(st[10]), st[8], st[9]
+        lam_tie = min(max((cs.alphaM - n_gt) / n_eq, 0.0), 1.0) if n_eq > 0 else 0.0
+        m32 = m.astype(np.float32)
+        out[slot] = ((m32 > t) * 1.0 + (m32 == t) * lam_tie, arg)
+    return out
+
+
+def cs_last_cuts(cs):
+    return [(sl, lam) for sl, lam in cs._last_info["multipliers"]["cuts"] if lam > 0.0]
+
+
+@pytest.mark.parametrize("system,M,alpha", [("drone", 200, 0.1), ("drone", 1000, 0.05), ("driving", 200, 0.1),
+                                            ("driving", 1000, 0.05)])
+def test_device_reduced_solution_satisfies_the_kkt_conditions_of_the_full_qp(system, M, alpha):
+    """The device-linearized reduced solution against the FULL QP assembled (reference layout, host fp64 arithmetic)
+    from the same device linearization: lifted to (u, y, slack, t), with the master's multipliers spread over the
+    full QP's rows, it meets primal feasibility / stationarity / dual signs / complementarity -- the optimum of the
+    reference's QP without relying on a host solver that cannot take this M (tests/test_reduced_host.py has the same
+    certificate in pure fp64).  Explicit Jacobian (products), reference form of the rows: exactly the numbers A holds."""
+    from tests._host_cuts import kkt_certificate
+    S = 20
+    if system == "drone":
+        _, d = _drone(M, S, alpha=alpha, seed=21)
+        kw, n_c, n_u, R, kappa, first = dict(implicit=False, generators_only=False, delta=False, factored=False), 6, 3, 3, 0.01, 2
+    else:
+        _, d = _car(M, S, alpha=alpha, seed=21)
+        kw, n_c, n_u, R, kappa, first = dict(delta=False), 4, 2, 1, 1.0, 1
+    P, q = d.get_objective_coeffs()
+    us = d.initial_guess_us_mat()
+    worst = {}
+    for it in range(6):
+        nxt, _, info = d.solve_reduced(us, it, tol=1e-10, **kw)
+        if it >= first:
+            d._cut_solver._last_info = info
+            A, l, u = d.get_constraints_coeffs_host(us, it)
+            c = kkt_certificate(A, l, u, P, q, info, _device_cut_data(d._cut_solver), n_c=n_c, n_u=n_u, S=S, M=M, R=R,
+                                kappa=kappa, alphaM=d._cut_solver.alphaM, saa=True, u_max=None)
+            scale = max(1.0, c["multiplier_scale"])
+            for k in ("primal", "stationarity", "dual_sign", "complementarity"):
+                worst[k] = max(worst.get(k, 0.0), c[k] / (1.0 if k == "primal" else scale))
+        us = nxt
+    print(system, M, "KKT residuals (relative to the multiplier scale):", {k: "%.1e" % v for k, v in worst.items()})
+    assert worst["primal"] < 1e-8 and worst["stationarity"] < 1e-8 and worst["dual_sign"] < 1e-8 \
+        and worst["complementarity"] < 1e-8

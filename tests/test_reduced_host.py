@@ -67,3 +67,38 @@ def test_recycled_cuts_do_not_change_the_iterates():
     b = scp.run_drone_reduced(m, num_scp_iters_max=10)
     np.testing.assert_allclose(a["us"], b["us"], rtol=0, atol=1e-8)
     assert a["cuts"].sum() <= b["cuts"].sum()
+
+
+@pytest.mark.parametrize("system,method,M,alpha", [("drone", "saa", 200, 0.1), ("drone", "saa", 1000, 0.05),
+                                                   ("drone", "baseline", 40, 0.1), ("driving", "saa", 200, 0.1),
+                                                   ("driving", "saa", 1000, 0.05), ("driving", "baseline", 40, 0.1)])
+def test_reduced_solution_satisfies_the_kkt_conditions_of_the_full_qp(system, method, M, alpha):
+    """At M = 200 .. 1000 the host ADMM + polish no longer identifies the active set of the (massively degenerate)
+    full QP reliably, so instead of comparing with its output the reduced solution is CERTIFIED against the full QP
+    itself: lifted to (u, y, slack, t) and with the master's multipliers spread over the rows of the reference's
+    layout, it satisfies primal feasibility, stationarity, dual signs and complementarity of
+    `l <= A z <= u`, `1/2 z'Pz + q'z` to 1e-9 -- it IS the optimum of the reference's QP (unique in u)."""
+    from tests._host_cuts import kkt_certificate
+    S = 20
+    if system == "drone":
+        o = _drone(M, S, alpha, method)
+        fq, ro, n_c, n_u, R, kappa, first = DroneOracleQP(o), DroneReducedOracle(o), 6, 3, 3, 0.01, 2
+    else:
+        o = _car(M, S, alpha, method)
+        fq, ro, n_c, n_u, R, kappa, first = DrivingOracleQP(o), DrivingReducedOracle(o), 4, 2, 1, 1.0, 1
+    P, q = fq.get_objective_coeffs()
+    us = o.initial_guess_us_mat()
+    checked = 0
+    for it in range(6):
+        nxt, _, info = ro.solve_reduced(us, it, tol=1e-11)
+        if it >= first:
+            A, l, u = fq.get_constraints_coeffs(us, it)
+            c = kkt_certificate(A, l, u, P, q, info, ro.cs.cuts, n_c=n_c, n_u=n_u, S=S, M=M, R=R, kappa=kappa,
+                                alphaM=ro.cs.alphaM, saa=(method == "saa"), u_max=None)
+            scale = max(1.0, c["multiplier_scale"])
+            assert c["primal"] < 1e-9 and c["dual_sign"] < 1e-9 * scale, (it, c["primal"], c["dual_sign"])
+            assert c["stationarity"] < 1e-9 * scale and c["complementarity"] < 1e-9 * scale, \
+                (it, c["stationarity"], c["complementarity"])
+            checked += 1
+        us = nxt
+    assert checked >= 4
