@@ -74,6 +74,8 @@ def parse():
                          "i+1 runs (two output slots).  Off by default: measured on one GPU it gains nothing (the step "
                          "is the dominant kernel + 7 us of partial sums + launch gaps; DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (BASELINE C2-C5 as whole steps after the metric configuration)")
     ap.add_argument("--cpu-samples", type=int, default=0)
     args = ap.parse_args()
     preset = {"metric": ("drone", 100000, 50), "C2": ("drone", 10000, 50), "C3": ("driving", 10000, 40),
@@ -169,22 +171,38 @@ class DroneWork:
         return eval_in - noise + M * B * (3 * S + jac) + nblk * (6 * S + 6) * B       # g_up, Jacobian | partials
 
     def cpu_baseline(self, n, alpha):
-        """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples; dense outputs in the
-        reference's shapes, buffers reused) on the same workload; -> step(nthreads) callable."""
+        """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples) on the same workload at the SAME M:
+        every sample's dense linearization is formed in the reference's shapes ((3,S,3S) Jacobian rows, g_up, the
+        final rows) in a per-thread buffer and reduced on the fly to what the SCP consumes (sample sums, Z) -- the
+        reference's (M,3,S,3S) array itself is 18 GB at M = 1e5.  -> step(nthreads) callable; ``step.numpy`` = the
+        NumPy restatement (1 process) on 2,000-sample chunks of the same batch."""
         from oracle import c_oracle, drone as od, stats as ostats
         rng = np.random.RandomState(0)
         DWs, masses, obs_Qs = od.sample_uncertain_parameters(rng, 'saa', M=n, S=self.S)
         us = graze_us(self.S, 3)
-        want = ("v_final_du", "val_final", "g_obs_du", "g_up", "Z") if self.mode == "linearize" else ("Z",)
-        out = c_oracle.drone(us, DWs, masses, obs_Qs, od.T / self.S, nthreads=0, want=want)   # first touch
+        dt = od.T / self.S
 
         def step(nthreads):
-            c = c_oracle.drone(us, DWs, masses, obs_Qs, od.T / self.S, nthreads=nthreads, want=want, out=out)
             if self.mode == "linearize":
-                c["v_final_du"].mean(0), c["val_final"].mean(0)
+                c = c_oracle.drone_stream(us, DWs, masses, obs_Qs, dt, nthreads=nthreads)
+                c["sum_final_du"] / n, c["sum_val_final"] / n
+            else:
+                c = c_oracle.drone(us, DWs, masses, obs_Qs, dt, nthreads=nthreads, want=("Z",))
             Z = c["Z"]
             return ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha), np.mean(Z <= 1e-6)
+
+        def numpy_chunk(k, chunk=2000):
+            """NumPy oracle (vectorised over the samples of one chunk, fp64, dense outputs) on chunk k"""
+            lo = (k * chunk) % max(n - chunk + 1, 1)
+            sl = slice(lo, min(lo + chunk, n))
+            o = od.Model(self.S, DWs[sl], masses[sl], obs_Qs[sl], 'saa', alpha)
+            if self.mode == "linearize":
+                fdu, flo, _, gdu, gup = o.get_all_constraints_coeffs(us)
+                fdu.mean(0), flo.mean(0)
+            o.monte_carlo_no_collisions_constraint_verification(us)
+            return sl.stop - sl.start
         step.threaded = True
+        step.numpy = numpy_chunk
         return step
 
 
@@ -323,7 +341,7 @@ class HopperWork:
 
 
 WORKLOADS = {"drone": DroneWork, "driving": DrivingWork, "hopper": HopperWork}
-CPU_SAMPLES = {"drone": 8000, "driving": 3000, "hopper": 50000}
+CPU_SAMPLES = {"drone": 0, "driving": 3000, "hopper": 50000}      # 0: the workload's own M (streaming C oracle)
 
 
 def pmc_traffic(workload, mode, M, S, jacobian=None):
@@ -400,7 +418,7 @@ def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
             "traffic_from_profile": pmc_traffic(workload, mode, M, S, jacobian)}
 
 
-def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
+def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, probe_clock=True):
     """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; -> dict."""
     M = work.M
     stats_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
@@ -504,7 +522,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch):
         ts = [a.elapsed_time(b) for a, b in ev]
         print("kernel ms per launch:", " ".join("%.4f" % t for t in ts), file=sys.stderr)
     sclk = None
-    if rank == 0:
+    if rank == 0 and probe_clock:
         # diagnostic, outside the timed region: the shader clock the device sustains WHILE the hot kernel runs (one wave
         # on a second stream reads the cycle counter against the 100 MHz counter; rato_device_clock_probe).  Boxes of the pool run this same
         # binary 5-10 % apart while their store-only ceilings agree to 2 %.
@@ -560,6 +578,43 @@ def scp_block(work, args):
             "cuts_median": float(np.median(out["cuts"])), "cuts_max": int(out["cuts"].max()),
             "L2_error_last": float(out["L2_error"][-1]),
             "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
+
+
+def configs_block(args, device, stats, rdist, dist, torch):
+    """BASELINE.json's other single-GPU configurations (C2 drone M=1e4 S=50, C3 driving M=1e4 S=40, C4 hopper M=5e4
+    S=60 / 40 contacts, C5's shard: driving 125,000 samples per GPU S=40) as whole steps, after and outside the timed
+    region of the metric configuration: per configuration the replayed (or eager, above 50,000 samples) step, the
+    dominant kernel by HIP events and its roofline fraction -- the protocol of the main line with K = a few hundred
+    steps each (the reference times its configurations the same way: drone_times.py:509-550)."""
+    import copy
+    out = {}
+    for name, (wl, M, S, K) in {"C2": ("drone", 10000, 50, 300), "C3": ("driving", 10000, 40, 300),
+                                "C4": ("hopper", 50000, 60, 300), "C5": ("driving", 125000, 40, 150)}.items():
+        a = copy.copy(args)
+        a.config, a.workload, a.M, a.S, a.steps, a.warmup = name, wl, M, S, K, 10
+        a.mode, a.philox, a.overlap, a.graph = "linearize", False, False, "auto"
+        a.packed_products, a.force_factored, a.cols_per_thread, a.samples_per_lane = True, False, 0, 0
+        try:
+            work = WORKLOADS[wl](a, device, seed=7)
+            res = timed_region(work, a, 1, 0, device, stats, rdist, dist, torch, probe_clock=False)
+            units = getattr(work, "C", work.S)
+            rb = roofline_block(work, res["kern_ms"], wl, "linearize", work.M, work.S,
+                                "products" if wl == "drone" else None, res["kern_src"])
+            ms = 1e3 * res["elapsed"] / K
+            out[name] = {"workload": f"{work.name} M={work.M} S={work.S}" + (f" ({work.C} contacts)" if wl == "hopper" else ""),
+                         "steps": K, "ms_per_step": ms, "value": work.M * units * K / res["elapsed"],
+                         "unit": "samples*steps/s" if wl != "hopper" else "samples*contacts/s",
+                         "kernel": rb["kernel"], "kernel_ms": res["kern_ms"], "step_over_kernel": ms / res["kern_ms"],
+                         "bound": "hbm" if wl != "hopper" else "valu (transcendental issue; HBM fraction for completeness)",
+                         "achieved_GBps": rb["achieved"], "frac": rb["frac"],
+                         "algorithmic_bytes_per_launch": rb["algorithmic_bytes_per_launch"],
+                         "traffic_from_profile": rb["traffic_from_profile"], "launch": res["launch"],
+                         "stats": {"VaR": res["stats"][0], "CVaR": res["stats"][1], "frac_satisfied": res["stats"][2]}}
+            del work
+            torch.cuda.empty_cache()
+        except Exception as e:                             # a side block must never take the bench line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def main():
@@ -653,8 +708,16 @@ def main():
             scp_work = next((r["work"] for r in reversed(results) if not r["work"].philox), None)
             if scp_work is not None:
                 line["scp"] = scp_block(scp_work, args)
+        if world == 1 and args.config == "metric" and is_drone_lin and not args.no_configs:
+            for r in results:                             # free the metric configuration's 3 GB output slots first
+                w = r["work"]
+                for attr in ("outs", "records"):
+                    if hasattr(w, attr):
+                        delattr(w, attr)
+            torch.cuda.empty_cache()
+            line["configs"] = configs_block(args, device, stats, rdist, dist, torch)
         if world == 1 and not args.no_cpu_baseline:
-            n = args.cpu_samples or CPU_SAMPLES[args.workload]
+            n = args.cpu_samples or CPU_SAMPLES[args.workload] or M
             cpu_step = work.cpu_baseline(n, args.alpha)
             threaded = getattr(cpu_step, "threaded", False)
             try:
@@ -676,14 +739,29 @@ def main():
             if threaded:
                 v1, r1, t1 = timed(lambda: cpu_step(1), 6.0, 40)
                 vp, rp, tp = timed(lambda: cpu_step(cores), 12.0, 200)
-                cpu_val, extra = vp, (f"C oracle (oracle/saa_oracle.c, fp64, dense outputs like the reference, "
-                                      f"OpenMP over samples), M={n}: {cores} threads {vp:.3e} ({rp} reps, {tp:.1f} s); "
+                cpu_val, extra = vp, (f"C oracle (oracle/saa_oracle.c, fp64, every sample's dense linearization formed "
+                                      f"in the reference's shapes and reduced on the fly, OpenMP over samples), M={n}: "
+                                      f"{cores} threads {vp:.3e} ({rp} reps, {tp:.1f} s); "
                                       f"1 thread {v1:.3e} ({r1} reps, {t1:.1f} s)")
+                numpy_1proc = None
+                if getattr(cpu_step, "numpy", None) is not None:      # the NumPy restatement, one process, in chunks
+                    cpu_step.numpy(0)
+                    done, t_np, k = 0, 0.0, 1
+                    while t_np < 6.0 and done < n:
+                        t1_ = time.perf_counter()
+                        done += cpu_step.numpy(k)
+                        t_np += time.perf_counter() - t1_
+                        k += 1
+                    numpy_1proc = done * unit_steps / t_np
+                    extra += (f"; NumPy fp64 oracle, 1 process, 2,000-sample chunks of the same batch: "
+                              f"{numpy_1proc:.3e} ({done} samples, {t_np:.1f} s)")
             else:
                 cpu_val, reps, t_cpu = timed(cpu_step, 10.0, 5)
                 extra = f"NumPy fp64 oracle, M={n}, {reps} rep(s), {t_cpu:.1f} s"
             line["cpu_baseline"] = {
                 "value": cpu_val, "unit": line["unit"], "cores": cores, "kind": "port",
+                "value_1_thread": (v1 if threaded else cpu_val),
+                "value_numpy_1_process": (numpy_1proc if threaded else cpu_val),
                 "sample": extra + f"; restatement of the reference's path (its JAX/XLA-CPU path is not installable "
                                   f"here); host reports {os.cpu_count()} cpus",
                 "gpu_over_cpu": value / cpu_val}

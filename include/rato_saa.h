@@ -253,7 +253,8 @@ int rato_car_linearize(const rato_car_params* p, const float* us, const float* d
  *   h      [C][M]                 fx - mu_i(px_c) fz
  *   dh_dfz [C][M]                 -mu_i(px_c)
  *   dh_dpx [C][M]                 -mu_i'(px_c) fz
- *   part_hess [nblocks][C][2]     per-block sums of lam*d2h/(dpx dfz), lam*d2h/dpx^2
+ *   part_hess [nblocks][C][2]     per-block sums of lam*d2h/(dpx dfz), lam*d2h/dpx^2  (needs 8 C bytes of LDS per
+ *                                 sample-wave: C <= 2032 contacts for M < 98,304 samples, 4064 above; RATO_EINVAL beyond)
  */
 int rato_hopper_nblocks(int32_t M);
 int rato_hopper_slip(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,

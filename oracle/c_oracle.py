@@ -19,6 +19,8 @@ def load(build=True):
         dp = C.POINTER(C.c_double)
         _lib.rato_oracle_drone.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 10 + [C.c_int]
         _lib.rato_oracle_drone.restype = None
+        _lib.rato_oracle_drone_stream.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 8 + [C.c_int]
+        _lib.rato_oracle_drone_stream.restype = None
         _lib.rato_oracle_max_threads.restype = C.c_int
     return _lib
 
@@ -45,6 +47,21 @@ def drone(us, DWs, masses, obs_Qs, dt, nthreads=0, want=("xs", "v_final_du", "va
     lib.rato_oracle_drone(M, S, float(dt), _p(us), _p(DWs), _p(masses), _p(obs_Qs), _p(out["xs"]),
                           _p(out["v_final_du"]), _p(out["val_final"]), _p(out["g_obs_du"]), _p(out["g_up"]),
                           _p(out["Z"]), int(nthreads))
+    return out
+
+
+def drone_stream(us, DWs, masses, obs_Qs, dt, nthreads=0):
+    """The same per-sample work with the dense outputs formed in per-thread buffers and reduced on the fly (batches
+    whose (M,3,S,3S) Jacobian does not fit the host) -> dict(sum_final_du (6,3S), sum_val_final (6,), Z (M,), checksum)."""
+    lib = load()
+    us = np.ascontiguousarray(us, dtype=np.float64)
+    DWs = np.ascontiguousarray(DWs, dtype=np.float64)
+    masses = np.ascontiguousarray(masses, dtype=np.float64)
+    obs_Qs = np.ascontiguousarray(obs_Qs, dtype=np.float64)
+    M, S = DWs.shape[0], DWs.shape[1]
+    out = {"sum_final_du": np.zeros((6, 3 * S)), "sum_val_final": np.zeros(6), "Z": np.empty(M), "checksum": np.zeros(1)}
+    lib.rato_oracle_drone_stream(M, S, float(dt), _p(us), _p(DWs), _p(masses), _p(obs_Qs), _p(out["sum_final_du"]),
+                                 _p(out["sum_val_final"]), _p(out["Z"]), _p(out["checksum"]), int(nthreads))
     return out
 
 

@@ -40,20 +40,14 @@ int rato_oracle_max_threads(void) {
 #endif
 }
 
-void rato_oracle_drone(int M, int S, double dt, const double* us, const double* DWs, const double* masses,
-                       const double* obs_Qs, double* xs_out, double* v_final_du, double* val_final,
-                       double* g_obs_du, double* g_up, double* Z, int nthreads) {
+/* One sample i.  ``slot`` is the index its dense outputs are written at: i itself (rato_oracle_drone: outputs of all M
+ * samples kept, the reference's vmap) or a per-thread slot that is reused (rato_oracle_drone_stream). */
+static void drone_sample(int i, size_t slot, int S, double dt, const double* us, const double* DWs,
+                         const double* masses, const double* obs_Qs, double* xs, double* Phi, double* xs_out,
+                         double* v_final_du, double* val_final, double* g_obs_du, double* g_up, double* Z) {
   const int nU = NU * S;
-#ifdef _OPENMP
-  if (nthreads > 0) omp_set_num_threads(nthreads);
-#endif
-#pragma omp parallel
   {
-    /* per-thread scratch: state trajectory and the forward sensitivities Phi[t][a][s][2] */
-    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * NX);
-    double* Phi = (double*)malloc(sizeof(double) * (size_t)(S + 1) * 3 * S * 2);
-#pragma omp for schedule(static)
-    for (int i = 0; i < M; ++i) {
+    {
       const double m = masses[i];
       const double* dW = DWs + (size_t)i * S * NX;
       const double* Q = obs_Qs + (size_t)i * NOBS * 9;
@@ -81,11 +75,11 @@ void rato_oracle_drone(int M, int S, double dt, const double* us, const double* 
           Pn[2 * t + 1] = dt / m;
         }
       }
-      if (xs_out) memcpy(xs_out + (size_t)i * (S + 1) * NX, xs, sizeof(double) * (size_t)(S + 1) * NX);
+      if (xs_out) memcpy(xs_out + slot * (S + 1) * NX, xs, sizeof(double) * (size_t)(S + 1) * NX);
       /* final constraints */
       const double* PhS = Phi + (size_t)S * 3 * S * 2;
       if (v_final_du) {
-        double* out = v_final_du + (size_t)i * NX * nU;
+        double* out = v_final_du + slot * NX * nU;
         memset(out, 0, sizeof(double) * NX * nU);
         for (int a = 0; a < 3; ++a)
           for (int s = 0; s < S; ++s) {
@@ -100,8 +94,8 @@ void rato_oracle_drone(int M, int S, double dt, const double* us, const double* 
             dp += PhS[((size_t)a * S + s) * 2] * us[s * NU + a];
             dv += PhS[((size_t)a * S + s) * 2 + 1] * us[s * NU + a];
           }
-          val_final[(size_t)i * NX + a] = -xs[(size_t)S * NX + a] + dp;          /* x_final = 0 */
-          val_final[(size_t)i * NX + 3 + a] = -xs[(size_t)S * NX + 3 + a] + dv;
+          val_final[slot * NX + a] = -xs[(size_t)S * NX + a] + dp;          /* x_final = 0 */
+          val_final[slot * NX + 3 + a] = -xs[(size_t)S * NX + 3 + a] + dv;
         }
       }
       /* obstacle constraints g = 1 - d^T Q[:2,:2] d, gradient -(Q+Q^T) d */
@@ -115,7 +109,7 @@ void rato_oracle_drone(int M, int S, double dt, const double* us, const double* 
           if (g > zmax) zmax = g;
           const double* Pt = Phi + (size_t)(t + 1) * 3 * S * 2;
           double dot = 0.0;
-          double* row = g_obs_du ? g_obs_du + (((size_t)i * NOBS + j) * S + t) * nU : NULL;
+          double* row = g_obs_du ? g_obs_du + ((slot * NOBS + j) * S + t) * nU : NULL;
           if (row) memset(row, 0, sizeof(double) * nU);
           for (int s = 0; s < t; ++s) {
             const double ex = wx * Pt[((size_t)0 * S + s) * 2], ey = wy * Pt[((size_t)1 * S + s) * 2];
@@ -125,12 +119,77 @@ void rato_oracle_drone(int M, int S, double dt, const double* us, const double* 
             }
             dot += ex * us[s * NU + 0] + ey * us[s * NU + 1];
           }
-          if (g_up) g_up[((size_t)i * NOBS + j) * S + t] = -g + dot;
+          if (g_up) g_up[(slot * NOBS + j) * S + t] = -g + dot;
         }
       }
       if (Z) Z[i] = zmax - OSQP_TOL;
     }
+  }
+}
+
+void rato_oracle_drone(int M, int S, double dt, const double* us, const double* DWs, const double* masses,
+                       const double* obs_Qs, double* xs_out, double* v_final_du, double* val_final,
+                       double* g_obs_du, double* g_up, double* Z, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    /* per-thread scratch: state trajectory and the forward sensitivities Phi[t][a][s][2] */
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * NX);
+    double* Phi = (double*)malloc(sizeof(double) * (size_t)(S + 1) * 3 * S * 2);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i)
+      drone_sample(i, (size_t)i, S, dt, us, DWs, masses, obs_Qs, xs, Phi, xs_out, v_final_du, val_final, g_obs_du, g_up,
+                   Z);
     free(xs);
     free(Phi);
   }
+}
+
+/* Streaming form for batches whose dense outputs do not fit the host (M = 1e5, S = 50: the reference's (M,3,S,3S)
+ * Jacobian alone is 18 GB): every sample's dense linearization is still FORMED, in the reference's shapes, but into a
+ * per-thread buffer that the next sample overwrites; what leaves the loop is what the SCP consumes downstream of it --
+ *   sum_final_du (6, 3S), sum_val_final (6)   sums over the samples (the sample mean, drone_risk.py:294-296)
+ *   Z (M)                                      max constraint value per sample (:656-662)
+ *   checksum[0]                                sum of every g_obs_du and g_up entry (keeps the dense rows observable)
+ * bench.py times this as the multi-core CPU baseline at the metric's own M. */
+void rato_oracle_drone_stream(int M, int S, double dt, const double* us, const double* DWs, const double* masses,
+                              const double* obs_Qs, double* sum_final_du, double* sum_val_final, double* Z,
+                              double* checksum, int nthreads) {
+  const int nU = NU * S;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  memset(sum_final_du, 0, sizeof(double) * NX * nU);
+  memset(sum_val_final, 0, sizeof(double) * NX);
+  double total = 0.0;
+#pragma omp parallel reduction(+ : total)
+  {
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * NX);
+    double* Phi = (double*)malloc(sizeof(double) * (size_t)(S + 1) * 3 * S * 2);
+    double* fdu = (double*)malloc(sizeof(double) * NX * nU);
+    double* vf = (double*)malloc(sizeof(double) * NX);
+    double* gdu = (double*)malloc(sizeof(double) * (size_t)NOBS * S * nU);
+    double* gup = (double*)malloc(sizeof(double) * NOBS * S);
+    double* acc_du = (double*)calloc((size_t)NX * nU, sizeof(double));
+    double acc_vf[NX] = {0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      drone_sample(i, 0, S, dt, us, DWs, masses, obs_Qs, xs, Phi, NULL, fdu, vf, gdu, gup, Z);
+      for (int k = 0; k < NX * nU; ++k) acc_du[k] += fdu[k];
+      for (int k = 0; k < NX; ++k) acc_vf[k] += vf[k];
+      double c = 0.0;
+      for (size_t k = 0; k < (size_t)NOBS * S * nU; ++k) c += gdu[k];
+      for (int k = 0; k < NOBS * S; ++k) c += gup[k];
+      total += c;
+    }
+#pragma omp critical
+    {
+      for (int k = 0; k < NX * nU; ++k) sum_final_du[k] += acc_du[k];
+      for (int k = 0; k < NX; ++k) sum_val_final[k] += acc_vf[k];
+    }
+    free(xs); free(Phi); free(fdu); free(vf); free(gdu); free(gup); free(acc_du);
+  }
+  if (checksum) checksum[0] = total;
 }

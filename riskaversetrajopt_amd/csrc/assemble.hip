@@ -61,12 +61,13 @@ extern "C" int rato_emit_csc_values(const float* G, const float* W, int64_t ld, 
   if (!G || !out || M <= 0 || S < 2 || n_g <= 0 || R <= 0 || (tile != 64 && tile != 256)) return RATO_EINVAL;
   const size_t lds = (size_t)64 * ((size_t)R * (S - 1) + 1) * sizeof(float);
   if (lds > 160 * 1024) return RATO_EINVAL;  // S <= 213 (drone, R = 3) / 639 (driving, R = 1): beyond, assemble on the host
-  static std::atomic<size_t> lds_attr_set{64 * 1024};
-  if (lds > lds_attr_set.load()) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emit_csc_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static rato::DynamicLdsLimit lds_limit;   // per device
+  {
+    const hipError_t e = lds_limit.ensure(lds, [](size_t) {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(emit_csc_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     if (e != hipSuccess) return RATO_EHIP - (int)e;
-    lds_attr_set.store(160 * 1024);
   }
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)(S - 1)), block(RATO_BLOCK);
   hipLaunchKernelGGL(emit_csc_kernel, grid, block, lds, rato::as_stream(stream), G, W, (long)ld, tile, n_g, R, S,

@@ -369,9 +369,9 @@ typedef float cfloat2_t __attribute__((ext_vector_type(2)));
 typedef float cfloat4_t __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t car_rows_lds_floats(int S) {
-  // KK float2 + QP float2 + K11 float per (k, lane) | EGOP float2[S+1] | EC float4[S] | US float2[S] | head (+pad)
+  // K4 float4 + QP float2 per (k, lane) | EGOP float2[S+1] | EC float4[S] | EC2 float4[S] | US float2[S] | head (+pad)
   // | ego v, phi [S+1] each | 8 x 4 reduction slots (final rows, workgroup 0) | fp64 v, cos, sin [S+1] each
-  return (size_t)S * CROWS_SAMPLES * 5 + (size_t)(S + 1) * 2 + (size_t)S * 4 + (size_t)S * 2 + 4 +
+  return (size_t)S * CROWS_SAMPLES * 6 + (size_t)(S + 1) * 2 + (size_t)S * 8 + (size_t)S * 2 + 4 +
          (size_t)(S + 1) * 2 + 32 + (size_t)(S + 1) * 6 + 2;
 }
 
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RATO_WAVE);   // scalar: wave-level branches stay scalar
   // (no __restrict__: QP[t] holds step t's noise until the rollout overwrites it with q_{t+1})
   cfloat4_t* EC = reinterpret_cast<cfloat4_t*>(car_lds_raw);                 // [S] (dt c, dt s, -dt v s, dt v c)
-  cfloat2_t* KK = reinterpret_cast<cfloat2_t*>(EC + S);                      // [S][64] (k00, k01)
-  cfloat2_t* QP = KK + (size_t)S * CROWS_SAMPLES;                            // [S][64] q_{k+1}
+  cfloat4_t* EC2 = EC + S;                                                   // [S] -dt (EC.x, EC.z | EC.y, EC.w): the row sweep's form
+  cfloat4_t* K4 = EC2 + S;                                                   // [S][64] (k00, k01 | k01, k11)
+  cfloat2_t* QP = reinterpret_cast<cfloat2_t*>(K4 + (size_t)S * CROWS_SAMPLES);   // [S][64] q_{k+1}
   cfloat2_t* EGOP = QP + (size_t)S * CROWS_SAMPLES;                          // [S+1] ego position
   cfloat2_t* US = EGOP + (S + 1);                                            // [S]
-  float* K11 = reinterpret_cast<float*>(US + S);                             // [S][64]
-  int* head = reinterpret_cast<int*>(K11 + (size_t)S * CROWS_SAMPLES);
+  int* head = reinterpret_cast<int*>(US + S);
   float* SV = reinterpret_cast<float*>(head + 4);                            // [S+1] ego speed
   float* SPH = SV + (S + 1);                                                 // [S+1] ego heading
   float* RED = SPH + (S + 1);                                                // [8][4]
@@ -454,6 +454,12 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         c.z = (float)(-dt * v * sn);
         c.w = (float)(dt * v * cs);
         EC[t] = c;
+        cfloat4_t c2;                       // the sweep propagates E = dt (eta_v, eta_phi) and eta_p_ego = -eta_q:
+        c2.x = (float)(-dt * dt * cs);      //   E -= dt (q_x (c.x, c.z) + q_y (c.y, c.w))
+        c2.y = (float)(dt * dt * v * sn);
+        c2.z = (float)(-dt * dt * sn);
+        c2.w = (float)(-dt * dt * v * cs);
+        EC2[t] = c2;
       }
     }
     __syncthreads();
@@ -603,11 +609,12 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       float n0, n1, rinv;
       ped_step(P, c, e.x, e.y, xi.x, xi.y, px, py, vx, vy, n0, n1, rinv);
       const float kr = P.dt * w_r * rinv;  // dt w_r (I - n n^T)/r at state t
-      cfloat2_t kk;
+      cfloat4_t kk;
       kk.x = kr * (1.0f - n0 * n0);
       kk.y = -kr * n0 * n1;
-      KK[slot] = kk;
-      K11[slot] = kr * (1.0f - n1 * n1);
+      kk.z = kk.y;
+      kk.w = kr * (1.0f - n1 * n1);
+      K4[slot] = kk;
       cfloat2_t q;
       q.x = px;
       q.y = py;
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   };
   constexpr int RT = CROWS_SAMPLES;
   const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * 2 * RT);
-  float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
+  float* __restrict__ Gt = G + (size_t)tile * tile_floats;   // wave-uniform: the stores take it as a scalar base + lane
   auto next_task = [&]() -> int {
     int v = 0;
     if (lane == 0) v = atomicAdd(head, 1);
@@ -653,37 +660,35 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       const float r = sqrtf(dx * dx + dy * dy);
       const float n0 = dx / r, n1 = dy / r;
       const float gt = -(r - P.d_min);                       // driving.py:223-230,269
-      float epx = -n0, epy = -n1, ev = 0.0f, eph = 0.0f;     // eta (ego part)
-      float qx = n0, qy = n1, qvx = 0.0f, qvy = 0.0f;        // eta (pedestrian part)
-      float acc = 0.0f;
+      // eta = (eta_p_ego, eta_v, eta_phi | eta_q, eta_qv); eta_p_ego = -eta_q throughout (both start at -+n and
+      // receive -+ the same increment), so only q = eta_q is carried; E = dt (eta_v, eta_phi) IS the Jacobian entry.
+      // Everything is kept in pairs: the compiler issues packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 /
+      // v_pk_add_f32), 9 vector instructions per step for the two stored numbers (the scalar form took 20).
+      cfloat2_t q2, qv2 = {0.0f, 0.0f}, E2 = {0.0f, 0.0f}, acc2 = {0.0f, 0.0f};
+      q2.x = n0;
+      q2.y = n1;
       float* __restrict__ Grow = Gt + (size_t)rato::pair_row_offset(t) * (2 * RT);
       for (int k = t; k >= 1; --k) {
         const int slot = k * CROWS_SAMPLES + lane;
-        const cfloat2_t kk = KK[slot];
-        const float k11 = K11[slot];
-        const cfloat4_t c = EC[k];
+        const cfloat4_t kk = K4[slot];
+        const cfloat4_t c = EC2[k];
         const cfloat2_t u2 = US[k - 1];
-        const float f0 = qvx * kk.x + qvy * kk.y, f1 = qvx * kk.y + qvy * k11;   // (eta_qv) K
-        const float nev = ev + epx * c.x + epy * c.y;
-        const float neph = eph + epx * c.z + epy * c.w;
-        const float nqvx = qvx + P.dt * qx;
-        const float nqvy = qvy + P.dt * qy - ks * (qvx + qvy);
-        epx -= f0;
-        epy -= f1;
-        qx += f0;
-        qy += f1;
-        ev = nev;
-        eph = neph;
-        qvx = nqvx;
-        qvy = nqvy;
-        const float o0 = P.dt * ev, o1 = P.dt * eph;         // d g_t / d u_{k-1, 0|1}
-        acc += o0 * u2.x + o1 * u2.y;
+        cfloat2_t f2 = qv2.y * kk.zw;                                   // (eta_qv) K
+        f2 = qv2.x * kk.xy + f2;
+        E2 = q2.y * c.zw + E2;                                          // uses eta_q BEFORE its update
+        E2 = q2.x * c.xy + E2;
+        cfloat2_t nqv2 = P.dt * q2 + qv2;
+        nqv2.y -= ks * (qv2.x + qv2.y);
+        q2 += f2;
+        qv2 = nqv2;
+        acc2 = E2 * u2 + acc2;                                          // d g_t / d u_{k-1, 0|1} = E2
         if (valid) {
           float* __restrict__ o = Grow + (k - 1) * (2 * RT);
-          o[0] = o0;
-          o[RT] = o1;
+          o[lane] = E2.x;
+          o[RT + lane] = E2.y;
         }
       }
+      const float acc = acc2.x + acc2.y;
       if (valid) g_up[(size_t)t * M + m] = P.rows_out ? gt : (-gt + acc);        // driving.py:295; rows_out = 1: g itself
     }
     task = next_task();
@@ -764,7 +769,13 @@ extern "C" int rato_car_separation_distances(const rato_car_params* p, const flo
 }
 
 namespace {
-__device__ unsigned g_car_tile_queues[64 * 2];   // {next tile, workgroups gone} per queue; every launch leaves its queue zeroed
+__device__ unsigned g_car_tile_queues[RATO_QUEUES_TOTAL * 2];   // {next tile, workgroups gone} per queue; every launch leaves
+                                                               // its queue zeroed (rato::TileQueuePool hands them out)
+unsigned* resolve_car_tile_queues() {
+  void* sym = nullptr;
+  return hipGetSymbolAddress(&sym, HIP_SYMBOL(g_car_tile_queues)) == hipSuccess ? static_cast<unsigned*>(sym) : nullptr;
+}
+rato::TileQueuePool g_car_queue_pool;
 constexpr size_t CAR_ROWS_LDS_MAX = 160 * 1024;
 size_t car_rows_lds_bytes(int S) { return car_rows_lds_floats(S) * sizeof(float); }
 }  // namespace
@@ -812,28 +823,23 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
                        final_du, final_rhs, 1);
   if (spt == -1) {
     const size_t lds = car_rows_lds_bytes(p->S);
-    static std::atomic<size_t> lds_attr_set{64 * 1024};   // cached: capture-safe after the first call
-    if (lds > lds_attr_set.load()) {
-      hipError_t e = hipSuccess;
-      const void* kernels[4] = {reinterpret_cast<const void*>(car_linearize_rows_kernel<false, false>),
-                                reinterpret_cast<const void*>(car_linearize_rows_kernel<true, false>),
-                                reinterpret_cast<const void*>(car_linearize_rows_kernel<false, true>),
-                                reinterpret_cast<const void*>(car_linearize_rows_kernel<true, true>)};
-      for (int i = 0; i < 4 && e == hipSuccess; ++i)
-        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static rato::DynamicLdsLimit lds_limit;   // per device; cached: capture-safe after the first call
+    {
+      const hipError_t e = lds_limit.ensure(lds, [](size_t bytes) {
+        hipError_t err = hipSuccess;
+        const void* kernels[4] = {reinterpret_cast<const void*>(car_linearize_rows_kernel<false, false>),
+                                  reinterpret_cast<const void*>(car_linearize_rows_kernel<true, false>),
+                                  reinterpret_cast<const void*>(car_linearize_rows_kernel<false, true>),
+                                  reinterpret_cast<const void*>(car_linearize_rows_kernel<true, true>)};
+        for (int i = 0; i < 4 && err == hipSuccess; ++i)
+          err = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        return err;
+      });
       if (e != hipSuccess) return RATO_EHIP - (int)e;
-      lds_attr_set.store(lds);
     }
     const int n_tiles = (p->M + CROWS_SAMPLES - 1) / CROWS_SAMPLES;
     // large batches: one workgroup per slot + a global tile queue (XCD load balance, see the kernel)
-    static std::atomic<int> cu_count{0};
-    int cus = cu_count.load();
-    if (cus == 0) {
-      int dev = 0;
-      cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      cu_count.store(cus);
-    }
+    const int cus = g_car_queue_pool.cus();
     int per_cu = (int)(CAR_ROWS_LDS_MAX / lds);
     if (per_cu > 32 / CROWS_NW) per_cu = 32 / CROWS_NW;
     if (per_cu < 1) per_cu = 1;
@@ -843,16 +849,8 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
     static const int dynamic_env = [] { const char* e = getenv("RATO_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
     unsigned* queue = nullptr;
     int grid_x = n_tiles;
-    if (dynamic_env && n_tiles > slots) {
-      static unsigned* queues = nullptr;
-      if (!queues) {
-        void* sym = nullptr;
-        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_car_tile_queues)) != hipSuccess) return RATO_EHIP;
-        queues = static_cast<unsigned*>(sym);
-      }
-      const int slot = rato::tile_queue_slot(st);      // one queue per stream; none left: static form
-      if (slot >= 0) queue = queues + 2 * slot;
-    }
+    if (dynamic_env && n_tiles > slots)
+      queue = g_car_queue_pool.take(st, resolve_car_tile_queues);   // per stream / per captured launch; none left: static form
     // Two queue workgroups per CU, not the three the LDS allows: same box, alternating (tools/ab_car_slots.sh), 3 -> 2:
     // C5 shard (M = 125,000) 0.1923-0.1938 -> 0.1846-0.1877 ms (noise read), 0.1768-0.1771 -> 0.1728-0.1734 (regenerated);
     // M = 1e6 1.162-1.175 -> 1.158-1.163 / 1.105-1.108 -> 1.102-1.111; one per CU: +17 %.  RATO_CAR_SLOTS_PER_CU overrides.

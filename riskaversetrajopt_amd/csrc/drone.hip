@@ -21,8 +21,8 @@ namespace {
 constexpr int NOBS = RATO_DRONE_NOBS;
 
 // work queues of the dynamic launch forms (row-parallel linearize, eval): {next tile, workgroups gone}; zero at load,
-// every launch leaves its queue zeroed again; 64 of them, one per stream (rato::tile_queue_slot)
-__device__ unsigned g_tile_queues[64 * 2];
+// every launch leaves its queue zeroed again; handed out by rato::TileQueuePool (per stream / per captured launch)
+__device__ unsigned g_tile_queues[RATO_QUEUES_TOTAL * 2];
 
 struct SampleConsts {
   float inv_m, a21, cn, dtm;
@@ -958,28 +958,15 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 }
 
 
-unsigned* take_tile_queue(hipStream_t stream) {   // this stream's queue (NULL: none left); address looked up once
-  static unsigned* queues = nullptr;
-  if (!queues) {
-    void* sym = nullptr;
-    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) != hipSuccess) return nullptr;
-    queues = static_cast<unsigned*>(sym);
-  }
-  const int slot = rato::tile_queue_slot(stream);
-  return slot < 0 ? nullptr : queues + 2 * slot;
+unsigned* resolve_tile_queues() {
+  void* sym = nullptr;
+  return hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queues)) == hipSuccess ? static_cast<unsigned*>(sym) : nullptr;
 }
+rato::TileQueuePool g_queue_pool;
 
-int device_cus() {
-  static std::atomic<int> cu_count{0};
-  int cus = cu_count.load();
-  if (cus == 0) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    cu_count.store(cus);
-  }
-  return cus;
-}
+unsigned* take_tile_queue(hipStream_t stream) { return g_queue_pool.take(stream, resolve_tile_queues); }
+
+int device_cus() { return g_queue_pool.cus(); }
 
 bool params_ok(const rato_drone_params* p) {
   return p && p->M > 0 && p->ld >= p->M && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
@@ -1113,30 +1100,25 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     const size_t lds = rows_lds_bytes(p->S);
     // Device properties are cached so that a launch inside a hipGraph capture makes no non-stream
     // runtime call (the first, uncaptured call sets them).
-    static std::atomic<size_t> lds_attr_set{64 * 1024};
-    static std::atomic<int> cu_count{0};
-    if (lds > lds_attr_set.load()) {
-      hipError_t e = hipSuccess;
-      const void* kernels[4] = {reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, false>),
-                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, false>),
-                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, true>),
-                                reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, true>)};
-      for (int i = 0; i < 4 && e == hipSuccess; ++i)
-        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static rato::DynamicLdsLimit lds_limit;   // per device
+    {
+      const hipError_t e = lds_limit.ensure(lds, [](size_t bytes) {
+        hipError_t err = hipSuccess;
+        const void* kernels[4] = {reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, false>),
+                                  reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, false>),
+                                  reinterpret_cast<const void*>(drone_linearize_rows_kernel<true, true>),
+                                  reinterpret_cast<const void*>(drone_linearize_rows_kernel<false, true>)};
+        for (int i = 0; i < 4 && err == hipSuccess; ++i)
+          err = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        return err;
+      });
       if (e != hipSuccess) return RATO_EHIP - (int)e;
-      lds_attr_set.store(lds);
     }
     // Small batches (fewer tiles than resident workgroup slots) deal each tile's row tasks out to
     // row_split workgroups so that the chip is filled (M = 1e4, S = 50: 81 -> 72 us).  Splitting only
     // the tiles of an incomplete last round of a large batch was measured and does not pay
     // (M = 1e5: 0.627 -> 0.648 ms), so large batches use one workgroup per tile.
-    int cus = cu_count.load();
-    if (cus == 0) {
-      int dev = 0;
-      cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      cu_count.store(cus);
-    }
+    const int cus = device_cus();
     int per_cu = (int)(ROWS_LDS_MAX / lds);
     if (per_cu > 32 / ROWS_NW) per_cu = 32 / ROWS_NW;
     if (per_cu < 1) per_cu = 1;

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
   }
 }
 
+constexpr size_t RATO_HOPPER_LDS_MAX = 160 * 1024;
+
 // contact-waves per sample-wave for a batch of M samples: ~3000 waves or more whenever the batch allows it
 inline int hopper_nw_log2(int32_t M) {
   // RATO_HOPPER_NW_LOG2=0|1|2: diagnostic override (A/B runs of the launch shape)
@@ -187,6 +189,22 @@ int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, con
   const bool deriv = dh_dfz || dh_dpx || part_hess;
   const int SW = (RATO_BLOCK / RATO_WAVE) >> nw_log2;
   const size_t lds = (size_t)(RATO_BLOCK + (part_hess ? SW * C * 2 : 0)) * sizeof(float);
+  // the Hessian sums keep 2 C floats per sample-wave in LDS: C <= 4064 (two sample-waves) / 2032 (four) contacts; the
+  // reference's hopper has 2 S / 3 contacts (hopper.py:306-311).  Beyond the 64 KB default the kernels are raised (per
+  // device) up to the 160 KB of a CU; past that the call is refused instead of failing inside the launch.
+  if (lds > RATO_HOPPER_LDS_MAX) return RATO_EINVAL;
+  static rato::DynamicLdsLimit lds_limit;
+  {
+    const hipError_t e = lds_limit.ensure(lds, [](size_t) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(hopper_slip_kernel<true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)RATO_HOPPER_LDS_MAX);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(hopper_slip_kernel<true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)RATO_HOPPER_LDS_MAX);
+      return err;
+    });
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
   HopperContacts hc;
   if (host_inputs) {
     ::memcpy(hc.px, px, sizeof(float) * C);

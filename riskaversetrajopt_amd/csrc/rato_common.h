@@ -140,20 +140,89 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline int nblocks_for(int32_t M) { return (M + RATO_BLOCK - 1) / RATO_BLOCK; }
 
-// Work queues of the dynamic launch forms (row-parallel linearize kernels): each queue is two device words
-// {next tile, workgroups gone}, zero at load, and every launch leaves its queue zeroed.  A queue is bound to a STREAM:
-// launches on one stream are ordered and may share it, launches on different streams never share one.  Up to 64 streams
-// get a queue; a 65th stream gets none (-1) and its launches use the static form.
-static inline int tile_queue_slot(hipStream_t stream) {
-  static std::mutex mu;
-  static hipStream_t owner[64];
-  static int used = 0;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < used; ++i)
-    if (owner[i] == stream) return i;
-  if (used == 64) return -1;
-  owner[used] = stream;
-  return used++;
-}
+// Work queues of the dynamic launch forms (row-parallel linearize kernels, eval): each queue is two device words
+// {next tile, workgroups gone}, zero at load, and every launch leaves its queue zeroed.  One pool per kernel file and
+// per DEVICE (a __device__ array has its own copy -- and its own address -- on every device of the process):
+//   * an eager launch takes the queue bound to its STREAM: launches on one stream are ordered and may share it,
+//     launches on different streams never share one (up to RATO_QUEUES_EAGER streams; a further stream gets none and
+//     its launches use the static form);
+//   * a launch recorded into a hipGraph (the stream is capturing) takes a queue of its OWN from the rest of the pool:
+//     torch.cuda.graph captures every graph on one shared side stream, so a stream-keyed queue would be shared by
+//     graphs that are later replayed concurrently on different streams -- two launches on one queue skip tiles.  A
+//     graph exec cannot run concurrently with itself, so one queue per captured launch is enough.  The queues of
+//     destroyed graphs are not reclaimed; when the pool is used up (RATO_QUEUES_TOTAL - RATO_QUEUES_EAGER captured
+//     launches in one process) further captured launches get none and use the static form.
+// The CU count is cached per device here too (no device query inside a capture after the first, uncaptured call).
+#define RATO_QUEUES_EAGER 64
+#define RATO_QUEUES_TOTAL 256
+class TileQueuePool {
+ public:
+  // resolve(): device address of the CURRENT device's copy of the file's queue array (RATO_QUEUES_TOTAL * 2 words)
+  unsigned* take(hipStream_t stream, unsigned* (*resolve)()) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lock(mu_);
+    PerDev& d = dev_[dev];
+    if (!d.base) {
+      d.base = resolve();
+      if (!d.base) return nullptr;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+      if (d.next_captured >= RATO_QUEUES_TOTAL) return nullptr;
+      return d.base + 2 * d.next_captured++;
+    }
+    for (int i = 0; i < d.used; ++i)
+      if (d.owner[i] == stream) return d.base + 2 * i;
+    if (d.used == RATO_QUEUES_EAGER) return nullptr;
+    d.owner[d.used] = stream;
+    return d.base + 2 * d.used++;
+  }
+  int cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    std::lock_guard<std::mutex> lock(mu_);
+    PerDev& d = dev_[dev];
+    if (d.cus == 0) {
+      int n = 256;
+      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      d.cus = n > 0 ? n : 256;
+    }
+    return d.cus;
+  }
+
+ private:
+  static constexpr int kMaxDev = 32;
+  struct PerDev {
+    unsigned* base = nullptr;
+    hipStream_t owner[RATO_QUEUES_EAGER] = {};
+    int used = 0, next_captured = RATO_QUEUES_EAGER, cus = 0;
+  };
+  std::mutex mu_;
+  PerDev dev_[kMaxDev];
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember, per device, the largest size a
+// launch site has raised its kernels to (the first, uncaptured call of a shape makes the runtime call; later calls --
+// including those recorded into a hipGraph -- make none).
+class DynamicLdsLimit {
+ public:
+  template <class Apply>   // apply(bytes) -> hipError_t: raises every kernel of the launch site
+  hipError_t ensure(size_t bytes, Apply&& apply) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu_);
+    if (bytes <= set_[dev]) return hipSuccess;
+    const hipError_t e = apply(bytes);
+    if (e == hipSuccess) set_[dev] = bytes;
+    return e;
+  }
+
+ private:
+  static constexpr int kMaxDev = 32;
+  std::mutex mu_;
+  size_t set_[kMaxDev] = {};
+};
 
 }  // namespace rato

@@ -240,7 +240,7 @@ class CvarCutSolver:
         with ctl.limit(limits=4):
             return self._solve(*args, **kwargs)
 
-    def _solve(self, G, W, tile, base, final_du, final_rhs, *, u_lin=None, with_cvar=True, tol=1e-9, max_cuts=400,
+    def _solve(self, G, W, tile, base, final_du, final_rhs, *, u_lin=None, with_cvar=True, tol=1e-8, max_cuts=400,
                verbose=False):
         """``base``: g_up [R][S][ld] of the linearize call (reference form), or -- with ``u_lin`` = the controls the
         linearization was taken at -- its g output (delta form, params.rows_out = 1)."""

@@ -389,7 +389,7 @@ class Model:
         self._cut_solver = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-9, verbose=False, delta=True):
+    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-8, verbose=False, delta=True):
         """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
         scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint.
         ``method='baseline'`` (driving.py:320-329): the rows (G_i u)_t <= g_up_{i,t} of every sample as the one

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--reduced", action="store_true",
                     help="solve every subproblem in (u, slack) with device CVaR cuts (scales to M = 1e6)")
+    ap.add_argument("--tol", type=float, default=None, help="--reduced: violation at which the cutting-plane loop stops")
     ap.add_argument("--define-only-M", type=int, default=100000,
                     help="also time linearize+means+statistics alone at this M (0 = skip)")
     args = ap.parse_args()
@@ -40,6 +41,9 @@ def main():
         if world > 1:
             model.shard()
         model.solve_reduced(model.initial_guess_us_mat(), 2)             # warm-up (allocations, first launches)
+        if args.tol is not None:
+            solve = model.solve_reduced
+            model.solve_reduced = lambda us, it, **kw: solve(us, it, tol=args.tol, **kw)
         t_all = time.perf_counter()
         out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=(rank == 0))
         line = {"system": "drone", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",

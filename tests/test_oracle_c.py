@@ -23,3 +23,19 @@ def test_c_oracle_matches_numpy_oracle(S, M):
     assert np.array_equal(c["g_obs_du"] == 0, gdu == 0)
     one = c_oracle.drone(us, DWs, masses, Q, o.dt, nthreads=1)
     assert np.array_equal(one["g_obs_du"], c["g_obs_du"])       # thread count does not change results
+
+
+def test_c_oracle_streaming_form_equals_the_dense_form():
+    """rato_oracle_drone_stream (bench.py's CPU baseline at M = 1e5: dense rows formed per thread, reduced on the fly)"""
+    from oracle import c_oracle, drone as od
+    S, M = 20, 300
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(3), 'saa', M=M, S=S)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)])
+    dense = c_oracle.drone(us, DWs, masses, Q, od.T / S, nthreads=2)
+    for nt in (1, 3):
+        st = c_oracle.drone_stream(us, DWs, masses, Q, od.T / S, nthreads=nt)
+        np.testing.assert_allclose(st["sum_final_du"], dense["v_final_du"].sum(0), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(st["sum_val_final"], dense["val_final"].sum(0), rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(st["Z"], dense["Z"])
+        np.testing.assert_allclose(st["checksum"][0], dense["g_obs_du"].sum() + dense["g_up"].sum(), rtol=1e-11)
