@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-scp", action="store_true", help="skip the SCP wall-clock block (drone, N=1)")
     ap.add_argument("--scp-iters", type=int, default=60)
     ap.add_argument("--dry-run", action="store_true", help="rank start-up + barrier only (no GPU work)")
+    ap.add_argument("--strict-comm", action="store_true",
+                    help="N > 1: exit non-zero if the library's own RCCL communicator (rato_comm_init) cannot be created "
+                         "on every rank, instead of falling back to torch.distributed's collective with a warning")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as ONE captured hipGraph (kernel time then comes from an eager pre-pass "
                          "with HIP events, since events cannot bracket a node inside a graph).  auto = on for "
@@ -631,13 +634,22 @@ def main():
     import torch.distributed as dist
     from riskaversetrajopt_amd import dist as rdist, stats
 
+    if args.strict_comm:
+        os.environ["RATO_STRICT_COMM"] = "1"
     rank, world, local = rdist.init_from_env()
     if args.dry_run:                                     # launch plumbing only (CPU test of the spawn path)
+        devices = [None] * world
         if dist.is_initialized():
+            dist.all_gather_object(devices, {"rank": rank, "local_rank": local, "device": f"cuda:{local}"})
             dist.barrier()
+        else:
+            devices = [{"rank": 0, "local_rank": 0, "device": "cuda:0"}]
         if rank == 0:
             print(json.dumps({"metric": "SAA constraint-eval throughput", "value": None, "n_gpus": world,
-                              "dry_run": True}))
+                              "dry_run": True, "scaling": "weak",
+                              "config": {"baseline_config": args.config, "workload": args.workload,
+                                         "M_per_gpu": args.M, "S": args.S, "M_total": world * args.M,
+                                         "ranks": devices, "strict_comm": bool(args.strict_comm)}}))
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -687,8 +699,8 @@ def main():
                                         "(3S(S-1) numbers per sample)" if jacobian in ("products", "regenerated") else
                                         ("the factored Jacobian (Phi, W): S(S-1)+6S numbers per sample"
                                          if jacobian == "factored" else "the whole step")),
-                       "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step "
-                                      f"(RCCL behind the C ABI: rato_comm_exchange)",
+                       "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step",
+                       "transport": rdist.transport(),
                        "launch": head["launch"]},
             "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
                                        head["kern_src"]),

@@ -89,6 +89,11 @@ size_t rato_packed_buffer_floats(size_t n_tiles, size_t payload_floats);
  * percent apart). */
 int rato_device_clock_probe(double* out3, int32_t us, void* stream);
 
+/* Diagnostic (tests): `blocks` workgroups of 1024 threads hold their wave slots for `us` microseconds (<= 5 s); 512 of
+ * them occupy every wave slot of an MI355X.  Used to show that the one-launch statistics, which wait inside the
+ * launch for their own workgroups, survive a chip that another stream owns. */
+int rato_device_occupy(int32_t blocks, int64_t us, void* stream);
+
 /* ------------------------------------------------------------------ drone */
 
 /* Constants of drone_params.py:1-45 / Model.__init__ drone_risk.py:71-93. */
@@ -454,6 +459,10 @@ int rato_unpack_records(const void* all, int32_t world, int32_t n_sums, int64_t 
  */
 #define RATO_COMM_ID_BYTES 128
 typedef struct rato_comm rato_comm;
+/* RATO_OK if librccl can be bound in this process, RATO_ENOCOMM otherwise: local and cheap, no communication.  Ranks
+ * agree on it BEFORE any of them enters the collective rato_comm_init (a rank that cannot bind the library would
+ * return at once and leave the others blocked inside ncclCommInitRank). */
+int rato_comm_available(void);
 int rato_comm_unique_id(void* id_out /* host, RATO_COMM_ID_BYTES */);
 int rato_comm_init(rato_comm** comm, const void* id_bytes /* host */, int32_t rank, int32_t world);
 int rato_comm_world(const rato_comm* comm);

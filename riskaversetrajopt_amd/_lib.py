@@ -31,6 +31,7 @@ SIGNATURES = {
     "rato_packed_tile_stride": (C.c_size_t, [C.c_size_t]),
     "rato_packed_buffer_floats": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "rato_device_clock_probe": (C.c_int, [c_float_p, C.c_int32, c_stream]),
+    "rato_device_occupy": (C.c_int, [C.c_int32, C.c_int64, c_stream]),
     "rato_drone_eval": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "rato_sum_partials_f64": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
     "rato_count_nonfinite_acc": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),
+    "rato_comm_available": (C.c_int, []),
     "rato_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rato_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32]),
     "rato_comm_world": (C.c_int, [C.c_void_p]),

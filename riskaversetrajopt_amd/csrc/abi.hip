@@ -29,7 +29,23 @@ __global__ void clock_probe_kernel(double* out, unsigned ticks) {
   out[1] = us;
   out[2] = 0.0;
 }
+// Diagnostic: `blocks` workgroups of 1024 threads that each hold their wave slots for `us` microseconds of the constant
+// 100 MHz clock (512 of them fill every wave slot of the 256 CUs).  Tests use it to put the one-launch statistics
+// (rs_coop: waits inside the launch for its own workgroups) behind / beside a kernel that owns the chip.
+__global__ __launch_bounds__(1024) void occupy_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 }  // namespace
+
+extern "C" int rato_device_occupy(int32_t blocks, int64_t us, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (blocks < 1 || blocks > 65535 || us < 1 || us > 5000000) return RATO_EINVAL;
+  hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)blocks), dim3(1024), 0, rato::as_stream(stream),
+                     (unsigned long long)us * 100ull);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
 
 extern "C" int rato_device_clock_probe(double* out3, int32_t us, void* stream) {
   RATO_CLEAR_ERROR();

@@ -57,6 +57,8 @@ struct rato_comm {
   int rank, world;
 };
 
+extern "C" int rato_comm_available(void) { return rccl().ok ? RATO_OK : RATO_ENOCOMM; }
+
 extern "C" int rato_comm_unique_id(void* id_out) {
   if (!id_out) return RATO_EINVAL;
   RcclApi& a = rccl();

@@ -88,8 +88,13 @@ struct Workspace {
 constexpr unsigned RS_MAGIC = 0x52A70517u;
 
 // order-preserving map float -> uint32 (ascending)
+// order-preserving key of a float.  -0.0 takes the key of +0.0, so that comparing keys (the one-launch forms) and
+// comparing values (rs_tail, the tail-row kernels of cvar.hip: m > t, m == t) give the same counts and tail weights
+// when the threshold is a zero of either sign.  (NaN has no place in a sorted order: callers check finiteness --
+// rato_count_nonfinite -- before the statistics mean anything.)
 __device__ __forceinline__ unsigned key_of(float f) {
-  const unsigned u = __float_as_uint(f);
+  unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float value_of(unsigned k) {
@@ -475,8 +480,13 @@ constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 1
 // the counters add up to `expected` (the number of keys this pass distributes: M, then the count of the chosen bin).
 // Every counter only grows during a pass, so total == expected means every add has landed -- the histogram itself is
 // the barrier, with no arrival counter and no fence (one memory round trip per try instead of three per barrier).
-// Returns false after RS_COOP_TRIES tries (a workspace that was not left clean): the caller fails loudly, never hangs.
-constexpr int RS_COOP_TRIES = 1 << 18;   // ~0.5 s
+// Two ways out without a result, both loud (NaN statistics, workspace un-tagged), neither a hang:
+//   * the counters EXCEED `expected`: they only grow, so the workspace was not clean when the launch started -- at once;
+//   * the counters stay short for RS_COOP_WAIT_S seconds of the constant 100 MHz clock.  A launch whose workgroups are
+//     not all resident yet (another stream holds the CUs) is NOT a failure: its waiting workgroups keep polling until
+//     the rest has been scheduled and has added its keys, however long the other stream's kernel takes (the first
+//     version gave up after 2^18 polls ~ 0.5 s and poisoned the statistics of a merely delayed launch).
+constexpr unsigned long long RS_COOP_WAIT_TICKS = 10ull * 100000000ull;   // 10 s of s_memrealtime (100 MHz)
 template <int NB, int NT>
 __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, unsigned expected, unsigned& bin,
                               unsigned& krem, unsigned& bincount) {
@@ -485,7 +495,8 @@ __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, uns
   __shared__ unsigned wsum[NT / RATO_WAVE];
   __shared__ unsigned res[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int tries = 0; tries < RS_COOP_TRIES; ++tries) {
+  const unsigned long long t_start = wall_clock64();
+  for (unsigned tries = 0;; ++tries) {
     unsigned local[PER], tot = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -522,10 +533,18 @@ __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, uns
       __syncthreads();
       return true;
     }
+    // uniform over the workgroup: every thread summed the same LDS words / thread 0's clock is published through LDS
+    if (grand > expected) return false;                                   // unclean workspace
+    if ((tries & 1023u) == 1023u) {
+      if (tid == 0) res[0] = (wall_clock64() - t_start > RS_COOP_WAIT_TICKS) ? 1u : 0u;
+      __syncthreads();
+      const unsigned expired = res[0];
+      __syncthreads();
+      if (expired) return false;
+    }
     __syncthreads();                // wsum is rewritten by the next try
-    __builtin_amdgcn_s_sleep(4);
+    if (tries < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
   }
-  return false;
 }
 
 __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, long M, double alpha, unsigned k,

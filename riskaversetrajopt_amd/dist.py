@@ -97,31 +97,55 @@ def device_comm(group=None):
         from . import _lib
         lib = _lib.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = (C.c_uint8 * 128)()
-        status = lib.rato_comm_unique_id(ident) if rank == 0 else 0
-        box = [bytes(ident) if (rank == 0 and status == 0) else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        handle = C.c_void_p()
-        if box[0] is not None:
-            status = lib.rato_comm_init(C.byref(handle), box[0], rank, world)
-        else:
-            status = -3
-        ok = torch.tensor([1 if status == 0 else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            comm = handle
-        else:
-            if status == 0:
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def agree(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+
+        status = lib.rato_comm_available()
+        # every rank must be able to bind librccl BEFORE any of them enters the collective rato_comm_init: a rank that
+        # cannot would return at once and leave the others blocked inside ncclCommInitRank
+        if agree(status == 0):
+            ident = (C.c_uint8 * 128)()
+            status = lib.rato_comm_unique_id(ident) if rank == 0 else 0
+            box = [bytes(ident) if (rank == 0 and status == 0) else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            handle = C.c_void_p()
+            if box[0] is not None:          # the same on every rank (broadcast): all enter the collective init, or none
+                status = lib.rato_comm_init(C.byref(handle), box[0], rank, world)
+            else:
+                status = -3
+            if agree(status == 0):
+                comm = handle
+            elif status == 0:
                 lib.rato_comm_destroy(handle)
+        if comm is None:
+            msg = (f"rato_comm_init failed (status {status} on rank {rank}): the library's RCCL communicator is not "
+                   f"available")
+            if os.environ.get("RATO_STRICT_COMM") == "1":
+                # bench.py --strict-comm: a scaling run must not silently report another transport
+                raise RuntimeError(msg + " and RATO_STRICT_COMM=1 forbids the torch.distributed fallback")
             if rank == 0:
-                print(f"warning: rato_comm_init failed (status {status} on rank 0): falling back to torch.distributed's "
-                      "RCCL collective", file=sys.stderr)
+                print("warning: " + msg + ": falling back to torch.distributed's RCCL collective", file=sys.stderr)
     _COMMS[group] = comm
     return comm
 
 
+def transport(group=None):
+    """What carries the exchange of ``group``: 'rato_comm (RCCL behind the C ABI)', 'torch.distributed (nccl)',
+    'torch.distributed (gloo)' or 'none (single process)' -- reported in bench.py's line."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return "none (single process)"
+    if _COMMS.get(group) is not None:
+        return "rato_comm (RCCL behind the C ABI)"
+    return f"torch.distributed ({dist.get_backend(group)})"
+
+
 def destroy_comms():
     from . import _lib
+    _EQUAL_CHECKED.clear()
     for comm in _COMMS.values():
         if comm is not None:
             _lib.load().rato_comm_destroy(comm)
@@ -236,10 +260,19 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+_EQUAL_CHECKED = set()
+
+
 def gather_concat(t, group=None):
-    """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank)."""
+    """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank).  The equal length
+    is verified once per (group, length, dtype) with one tiny collective (``check_equal_shards``): a mismatched RCCL
+    all-gather hangs or corrupts silently."""
     world = dist.get_world_size(group)
     src = t.contiguous()
+    key = (id(group), src.numel(), src.dtype)
+    if key not in _EQUAL_CHECKED:
+        check_equal_shards(src.numel(), group)
+        _EQUAL_CHECKED.add(key)
     comm = device_comm(group) if src.is_cuda else None
     if comm is not None:
         from . import _lib

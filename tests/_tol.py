@@ -4,8 +4,8 @@ fp32 on fp32-rounded inputs.  SURVEY.md §7 hard part 2."""
 import numpy as np
 
 STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the car)
-G_RTOL, G_ATOL = 2e-5, 1e-4                # constraint values (drone g reaches ~ -90)
-JAC_REL_ROWMAX = 1e-4                      # Jacobian entries, relative to the row's max |entry|
+G_RTOL, G_ATOL = 2e-5, 3e-5                # constraint values (drone g reaches ~ -90; measured max 1e-5 abs)
+JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (measured 1.2e-5)
 MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
 RISK_ATOL = 1e-4                           # VaR / CVaR
 NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this

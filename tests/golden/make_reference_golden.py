@@ -50,10 +50,34 @@ class _Override(ast.NodeTransformer):
         return node
 
 
+REF_SHA256 = {}           # reference file (relative path) -> sha256 of the bytes that were executed
+
+
+def _assert_standin_covers(nodes, path):
+    """The stand-in's ``vmap`` maps the LEADING axis of every positional argument and nothing else: refuse reference
+    text that calls it any other way (in_axes / out_axes / axis_name / several functions), instead of silently
+    computing something else."""
+    for top in nodes:
+        for node in ast.walk(top):
+            if not isinstance(node, ast.Call):
+                continue
+            f = node.func
+            name = f.id if isinstance(f, ast.Name) else (f.attr if isinstance(f, ast.Attribute) else None)
+            if name == "vmap":
+                kws = {k.arg for k in node.keywords}
+                assert not kws and len(node.args) == 1, (path, node.lineno, "vmap called with", kws or node.args)
+            if name in ("jacfwd", "jacrev", "hessian", "grad"):
+                kws = {k.arg for k in node.keywords}
+                assert kws <= {"argnums"} and len(node.args) <= 2, (path, node.lineno, name, kws)
+
+
 def load_reference(path, ns, overrides=(), nested=()):
     """exec the reference's constants + ``class Model`` + top-level defs from ``path`` into ``ns``; returns a
     callable that execs the named nested closures (found anywhere in the file) once ``ns`` holds their globals."""
-    src = Path(path).read_text()
+    import hashlib
+    raw = Path(path).read_bytes()
+    REF_SHA256[os.path.relpath(path, REF)] = hashlib.sha256(raw).digest()
+    src = raw.decode()
     tree = ast.parse(src, filename=path)
     keep, seen_model = [], False
     for node in tree.body:
@@ -65,6 +89,7 @@ def load_reference(path, ns, overrides=(), nested=()):
         elif isinstance(node, ast.Assign) and not seen_model and all(isinstance(t, ast.Name) for t in node.targets):
             keep.append(_Override(dict(overrides)).visit(node))
     assert seen_model, path
+    _assert_standin_covers(keep, path)
     mod = ast.Module(body=keep, type_ignores=[])
     ast.fix_missing_locations(mod)
     exec(compile(mod, path, "exec"), ns)
@@ -73,6 +98,7 @@ def load_reference(path, ns, overrides=(), nested=()):
     closures = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name in nested and id(n) not in top]
     found = {n.name for n in closures}
     assert found == set(nested), (path, set(nested) - found)
+    _assert_standin_covers(closures, path)
 
     def define_closures():
         seen = set()
@@ -87,6 +113,16 @@ def base_namespace(jax):
     return {"np": np, "sp": sp, "jnp": jax.numpy, "jit": jax.jit, "vmap": jax.vmap, "jacfwd": jax.jacfwd,
             "jacrev": jax.jacrev, "hessian": jax.hessian, "grad": jax.grad, "partial": partial,
             "warn": warnings.warn, "time": time.time, "Path": Path, "print": lambda *a, **k: None}
+
+
+def with_hashes(out, *rel_paths):
+    """+ sha256 (uint8[32]) of every reference file this fixture was generated from, and of the modules imported for
+    real: tests/test_reference_pin.py re-hashes /root/reference where it exists, so a changed reference is noticed."""
+    import hashlib
+    for rel in rel_paths:
+        digest = REF_SHA256.get(rel) or hashlib.sha256(Path(os.path.join(REF, rel)).read_bytes()).digest()
+        out["ref_sha256__" + rel.replace("/", "__").replace(".", "_")] = np.frombuffer(digest, dtype=np.uint8).copy()
+    return out
 
 
 def npy(x):
@@ -176,7 +212,9 @@ def make_drone(jax, S, M, alpha=0.1):
     out["graze_us_vec"] = npy(vec)
     out["graze_us_roundtrip"] = npy(model.convert_us_vec_to_us_mat(vec))
     out["L2_error"] = float(ns["L2_error_us"](out["graze_us"], out["init_us"]))
-    np.savez_compressed(os.path.join(HERE, f"ref_drone_S{S}_M{M}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"ref_drone_S{S}_M{M}.npz"),
+                        **with_hashes(out, "drone/drone_risk.py", "drone/drone_main_plot.py", "drone/drone_params.py",
+                                      "drone/drone_utils.py"))
     sys.path.pop(0)
 
 
@@ -232,7 +270,8 @@ def make_driving(jax, S, M, alpha=0.05):
             A, low, up = base.get_all_constraints_coeffs_all(us)
             out.update(csc_triplet(npy(A), f"{kind}_base_A"))
             out.update({f"{kind}_base_low": npy(low), f"{kind}_base_up": npy(up)})
-    np.savez_compressed(os.path.join(HERE, f"ref_driving_S{S}_M{M}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"ref_driving_S{S}_M{M}.npz"),
+                        **with_hashes(out, "car/driving.py", "car/driving_params.py"))
     sys.path.pop(0)
 
 
@@ -293,7 +332,7 @@ def make_hopper(jax, S, M, alpha=0.2):
                ee=npy(vmap(model.end_effector_position)(xs_mat)), initial_guess=model.initial_guess())
     out.update(csc_triplet(Jn, "J"))
     out.update(csc_triplet(Hn, "H"))
-    np.savez_compressed(os.path.join(HERE, f"ref_hopper_S{S}_M{M}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"ref_hopper_S{S}_M{M}.npz"), **with_hashes(out, "hopper/hopper.py"))
 
 
 # ---------------------------------------------------------------- drone, Gaussian-linearization baseline (config C1)
@@ -315,7 +354,7 @@ def make_gaussian(jax, S, M_unused, alpha=0.1):
                Sigmas=npy(model.us_to_covariance_trajectory(jnp.array(us))),
                b_dx=npy(model.b_dx(jnp.array(drone_params.x_init) + 0.3, jnp.array(us[3]))),
                b_dmass=npy(model.b_dmass(jnp.array(drone_params.x_init) + 0.3, jnp.array(us[3]))))
-    np.savez_compressed(os.path.join(HERE, f"ref_gaussian_S{S}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"ref_gaussian_S{S}.npz"), **with_hashes(out, "drone/drone_gaussian.py"))
     sys.path.pop(0)
 
 

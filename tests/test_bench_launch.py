@@ -49,3 +49,19 @@ def test_config_presets():
         assert (a.workload, a.M, a.S) == ("driving", 1000, 40)
     finally:
         sys.argv = argv
+
+
+def test_bench_eight_ranks_dry_run_c5():
+    """the launch path of `bench.py --gpus 8 --config C5` (BASELINE C5: driving, M = 1e6 over 8 GPUs): eight ranks come
+    up (gloo here), LOCAL_RANK -> device, 125,000 samples per GPU, M_total = 1,000,000, ONE line from rank 0"""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--config", "C5", "--dry-run", "--strict-comm"],
+                         env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert (cfg["workload"], cfg["M_per_gpu"], cfg["S"], cfg["M_total"]) == ("driving", 125000, 40, 1000000)
+    assert [r["device"] for r in sorted(cfg["ranks"], key=lambda r: r["rank"])] == [f"cuda:{i}" for i in range(8)]
+    assert cfg["strict_comm"] is True

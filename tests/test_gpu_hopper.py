@@ -122,6 +122,19 @@ def test_full_size_C4_properties():
     st = d.monte_carlo_statistics(px, forces, alpha=0.1)
     assert abs(st["var"] - ostats.monte_carlo_var(Z_o, 0.1)) < 5e-5
     assert abs(st["cvar"] - ostats.monte_carlo_avar(Z_o, 0.1)) < 5e-5
+    # the Jacobian slices IPOPT consumes (hopper.py:569, :577-580) at full size: h, dh/dfz, dh/dpx for every 997th sample
+    # and all 40 contacts against the oracle, and the lambda-weighted Hessian sums over ALL samples (hopper.py:300-367)
+    h_o, dfz_o, dpx_o = o.slip_partials(px, forces)                      # (M, C) each
+    idx = np.arange(0, M, 997)
+    tidx = torch.as_tensor(idx, device=r["h"].device)
+    np.testing.assert_allclose(r["h"][:, tidx].t().cpu().numpy(), h_o[idx], rtol=0, atol=H_ATOL)
+    np.testing.assert_allclose(r["dh_dfz"][:, tidx].t().cpu().numpy(), dfz_o[idx], rtol=0, atol=MU_ATOL)
+    np.testing.assert_allclose(r["dh_dpx"][:, tidx].t().cpu().numpy(), dpx_o[idx], rtol=1e-5, atol=2e-5)
+    lam = np.random.RandomState(2).rand(*h_o.shape)
+    D1_o, D2_o = o.slip_hessian_sums(px, forces, lam)
+    D1, D2 = d.slip_hessian_sums(px, forces, lam)
+    np.testing.assert_allclose(D1, D1_o, rtol=2e-5, atol=1e-5 * np.sqrt(M))
+    np.testing.assert_allclose(D2, D2_o, rtol=2e-5, atol=1e-4 * np.sqrt(M))
 
 
 @pytest.mark.parametrize("M", [300, 50000])

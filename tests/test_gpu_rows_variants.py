@@ -1,8 +1,7 @@
 """GPU: the launch-structure variants of the drone row kernel compute the same thing.  The dynamic tile queue (the
-default for large batches) and the static balanced grid are the SAME kernel code and must reproduce the
-one-tile-per-workgroup launch bit for bit, whatever order the tiles are taken in; the persistent double-buffered kernel (off by default, kept for A/B runs) is
-separate code, where the compiler contracts multiply-adds differently: equal to a few fp32 ulps.  The variant is
-chosen by an environment variable that the library reads once, hence one subprocess per variant."""
+default for large batches), with or without part tiles at its end, is the SAME kernel code as the
+one-tile-per-workgroup launch and must reproduce it bit for bit, whatever order the tiles are taken in.  The variant
+is chosen by an environment variable that the library reads once, hence one subprocess per variant."""
 import os
 import subprocess
 import sys
@@ -48,18 +47,56 @@ def run_variant(tmp_path, name, env, S, M):
 
 @pytest.mark.parametrize("S,M", [(50, 100000), (20, 70000)])
 def test_launch_structure_variants_are_bit_identical(tmp_path, S, M):
-    off = {"RATO_ROWS_DYNAMIC": "0", "RATO_ROWS_BALANCED": "0", "RATO_ROWS_PERSISTENT": "0", "RATO_DYN_TAIL_SPLIT": "1"}
+    off = {"RATO_ROWS_DYNAMIC": "0", "RATO_DYN_TAIL_SPLIT": "1"}
     base = run_variant(tmp_path, "base", off, S, M)                                  # one tile per workgroup
     for name, env in (("dynamic", dict(off, RATO_ROWS_DYNAMIC="1")),                 # global tile queue, whole tiles
                       ("dynamic_tail", dict(off, RATO_ROWS_DYNAMIC="1", RATO_DYN_TAIL_SPLIT="4")),   # + quarter tiles last
                       ("dynamic_halves", dict(off, RATO_ROWS_DYNAMIC="2", RATO_DYN_TAIL_SPLIT="2", RATO_DYN_TAIL_TILES="700")),
-                      ("balanced", dict(off, RATO_ROWS_BALANCED="1")),               # static several tiles per workgroup
-                      ("persistent", dict(off, RATO_ROWS_PERSISTENT="1")),           # double-buffered (A/B only)
                       ("default", {})):
         v = run_variant(tmp_path, name, env, S, M)
         for k in base.files:
-            if name == "persistent":
-                scale = np.abs(base[k]).max()
-                np.testing.assert_allclose(v[k], base[k], rtol=2e-5, atol=2e-6 * scale, err_msg=f"{name} {k}")
-            else:
-                assert np.array_equal(base[k], v[k]), (name, k)
+            assert np.array_equal(base[k], v[k]), (name, k)
+
+
+def test_two_captured_graphs_replayed_concurrently_do_not_share_a_tile_queue():
+    """torch.cuda.graph captures every graph on one shared side stream; a tile queue keyed by the launch stream would be
+    shared by both captured launches, and replaying the graphs concurrently on two streams would then skip tiles
+    (stale rows survive silently).  A launch recorded into a graph takes a queue of its own (rato::TileQueuePool)."""
+    import torch
+    from riskaversetrajopt_amd import drone_risk, drone_utils
+    from riskaversetrajopt_amd.drone_risk import untile
+    S, M = 20, 70000                                        # 1094 tiles >= 1024 resident slots: the queue form
+    t = np.arange(S)[:, None]
+    us_np = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)])
+    models, refs, graphs, outs = [], [], [], []
+    for seed in (3, 4):
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(M, S, seed=seed)
+        d = drone_risk.Model.from_device(S, dW, mass, Qsym, 'saa', 0.1, M=M)
+        us = d._us_device(us_np * (1.0 + 0.1 * seed))
+        r = d.linearize_device(us)
+        refs.append({k: r[k].clone() for k in ("g_up", "Z", "part")} | {"G": untile(r["G"], M).clone()})
+        out = d.linearize_device(us)                       # the buffers the captured launch writes
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            d.linearize_device(us, out=out, reduce=False)
+        models.append((d, us)); graphs.append(g); outs.append(out)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(15):
+        for out in outs:
+            out["G"].zero_(); out["_g_up"].zero_(); out["part"].zero_()
+        torch.cuda.synchronize()
+        for g, st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g.replay()
+        torch.cuda.synchronize()
+        for out, ref in zip(outs, refs):
+            assert torch.equal(untile(out["G"], M), ref["G"]), rep
+            assert torch.equal(out["g_up"], ref["g_up"]) and torch.equal(out["part"], ref["part"]), rep
+    # an eager launch on the capture-time stream beside a replay does not share a queue with it either
+    d, us = models[0]
+    with torch.cuda.stream(streams[1]):
+        graphs[1].replay()
+    r = d.linearize_device(us)
+    torch.cuda.synchronize()
+    assert torch.equal(untile(r["G"], M), refs[0]["G"]) and torch.equal(untile(outs[1]["G"], M), refs[1]["G"])

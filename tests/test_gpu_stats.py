@@ -109,7 +109,8 @@ def test_unpack_records_matches_host_layout():
     from riskaversetrajopt_amd import _lib, dist as rdist
     lib = _lib.load()
     rng = np.random.RandomState(3)
-    for world, n_sums, M_local, z_row in ((1, 5, 7, 7), (3, 306, 1000, 1000), (8, 6, 1237, 1240), (2, 0, 64, 64)):
+    for world, n_sums, M_local, z_row in ((1, 5, 7, 7), (3, 306, 1000, 1000), (8, 6, 1237, 1240), (2, 0, 64, 64),
+                                           (4, 906, 999, 1001), (8, 0, 125000, 125000)):   # odd row stride; C5: 8 x 125,000
         recs = [rdist.Record(n_sums, M_local, "cuda:0", z_row=z_row) for _ in range(world)]
         for r in recs:
             if n_sums:
@@ -255,3 +256,59 @@ def test_one_launch_selection_on_concurrent_streams():
     torch.cuda.synchronize()
     for out, ref in zip(outs, refs):
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M", [10000, 50000, 2000000])
+def test_signed_zeros_at_the_threshold(M):
+    """+0.0 and -0.0 around the VaR threshold: the three launch forms (one workgroup / one launch / five launches: the
+    sizes above pick one each) count #{Z > t}, #{Z == t} like the float comparisons of the consumers (cvar.hip: m > t,
+    m == t) -- -0.0 and +0.0 are the same value."""
+    from riskaversetrajopt_amd import stats
+    rng = np.random.RandomState(M)
+    Z = rng.randn(M).astype(np.float32)
+    k = int(0.1 * M)                                       # alpha M samples strictly above zero, then a band of zeros
+    order = np.argsort(-Z)
+    Z[order[:k - 5]] = np.abs(Z[order[:k - 5]]) + 1.0
+    zeros = order[k - 5:k + 6]
+    Z[zeros] = np.where(np.arange(zeros.size) % 2 == 0, 0.0, -0.0).astype(np.float32)
+    Z[order[k + 6:]] = -np.abs(Z[order[k + 6:]]) - 1.0
+    st = stats.risk_stats(Z, 0.1)
+    assert st["var"] == 0.0 and st["t_star"] == 0.0
+    assert st["count_above_var"] == float(np.sum(Z > 0.0)) == k - 5
+    assert st["count_at_var"] == float(np.sum(Z == 0.0)) == 11
+    tail = np.sort(Z.astype(np.float64))[::-1][:k]
+    np.testing.assert_allclose(st["cvar"], tail.mean(), rtol=1e-12, atol=1e-12)
+
+
+def test_one_launch_selection_waits_out_a_chip_owned_by_another_stream():
+    """rs_coop's workgroups wait inside the launch for each other.  With 480 of the 512 wave-slot pairs of the chip held
+    for 0.8 s by another stream (rato_device_occupy), only part of the 64 workgroups of a selection over M = 1e6 can be
+    resident; they keep polling until the rest has been scheduled -- the exact np.sort answer, late, instead of the
+    NaN statistics the first version produced after ~0.5 s of polling."""
+    import time
+    import torch
+    from riskaversetrajopt_amd import stats, _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    M = 1000000
+    Zh = (0.9 + 0.05 * np.random.RandomState(5).randn(M)).astype(np.float32)
+    Z = torch.from_numpy(Zh).to(dev)
+    ws = stats.new_workspace(M, dev)
+    out = torch.empty(stats.N_STATS, dtype=torch.float64, device=dev)
+    hog, sel = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(hog):
+        _lib.check(lib.rato_device_occupy(480, 800000, _lib.current_stream()), "rato_device_occupy")
+    time.sleep(0.02)                                            # the hog is resident before the selection is queued
+    with torch.cuda.stream(sel):
+        stats.risk_stats_device(Z, 0.1, workspace=ws, out=out, stream=_lib.current_stream())
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 > 0.7                       # the selection really sat behind / beside the hog
+    st = out.cpu().numpy()
+    srt = np.sort(Zh)
+    assert st[0] == float(srt[M - int(np.floor(0.1 * M)) - 1])  # VaR: bit-identical to np.sort
+    k = int(np.floor(0.1 * M))
+    np.testing.assert_allclose(st[1], srt[::-1][:k].astype(np.float64).mean(), rtol=1e-12)
+    again = stats.risk_stats_device(Z, 0.1, workspace=ws)       # and the workspace was left clean
+    assert torch.equal(again, out)

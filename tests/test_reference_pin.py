@@ -232,3 +232,28 @@ def test_gaussian_recursion_matches_reference_execution():
     assert f["b_dmass"].shape == (6,)                                  # 1-D: hence the inner product
     rank_one = og.covariance_trajectory(us, S, outer_product=True)
     assert np.abs(rank_one - f["Sigmas"]).max() > 0.1 * np.abs(f["Sigmas"]).max()      # the two forms really differ
+
+
+def test_fixtures_were_generated_from_this_reference():
+    """Every ref_*.npz records the sha256 of the reference files it was generated from (make_reference_golden.py);
+    where /root/reference exists (the build container) the files must still hash to that -- a changed reference means
+    the fixtures have to be regenerated, not trusted.  (On the GPU box there is no reference: the stored digests are
+    only checked for presence.)"""
+    import glob
+    import hashlib
+    ref = os.environ.get("RATO_REFERENCE", "/root/reference")
+    names = {"drone__drone_risk_py": "drone/drone_risk.py", "drone__drone_main_plot_py": "drone/drone_main_plot.py",
+             "drone__drone_params_py": "drone/drone_params.py", "drone__drone_utils_py": "drone/drone_utils.py",
+             "car__driving_py": "car/driving.py", "car__driving_params_py": "car/driving_params.py",
+             "hopper__hopper_py": "hopper/hopper.py", "drone__drone_gaussian_py": "drone/drone_gaussian.py"}
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_*.npz")))
+    assert len(files) >= 7
+    for f in files:
+        z = np.load(f)
+        keys = [k for k in z.files if k.startswith("ref_sha256__")]
+        assert keys, f
+        for k in keys:
+            assert z[k].dtype == np.uint8 and z[k].shape == (32,)
+            path = os.path.join(ref, names[k[len("ref_sha256__"):]])
+            if os.path.exists(path):
+                assert hashlib.sha256(open(path, "rb").read()).digest() == z[k].tobytes(), (f, path)
