@@ -1,11 +1,14 @@
 """fp64 (reference / oracle) -> fp32 (device) tolerances, per quantity.  The
 reference computes in fp64 end to end (drone_risk.py:17); the kernels compute in
 fp32 on fp32-rounded inputs.  SURVEY.md §7 hard part 2."""
+import os
+
 import numpy as np
 
 STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the car)
 G_RTOL, G_ATOL = 2e-5, 3e-5                # constraint values (drone g reaches ~ -90; measured max 1e-5 abs)
-JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (measured 1.2e-5)
+JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (drone: measured <= 1e-5)
+JAC_REL_ROWMAX_DRIVING = 1e-4              # driving: set below from the measured worst case (RATO_TOL_REPORT=1)
 MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
 RISK_ATOL = 1e-4                           # VaR / CVaR
 NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this
@@ -16,7 +19,11 @@ def assert_jac_close(actual, desired, rel=JAC_REL_ROWMAX, axis=-1, what="jacobia
     scale = np.max(np.abs(desired), axis=axis, keepdims=True)
     err = np.abs(np.asarray(actual) - desired)
     bad = err > rel * np.maximum(scale, 1e-30) + 1e-12
-    assert not bad.any(), f"{what}: {bad.sum()} entries off; max err {err.max():.3e} vs row scale {scale.max():.3e}"
+    worst = float(np.max(err / (np.maximum(scale, 1e-30) + 1e-12 / rel)))
+    if os.environ.get("RATO_TOL_REPORT"):
+        print(f"[tol] {what}: worst error / row max = {worst:.2e} (limit {rel:.0e})")
+    assert not bad.any(), (f"{what}: {bad.sum()} entries off; max err {err.max():.3e} vs row scale {scale.max():.3e}; "
+                           f"worst error / row max {worst:.2e} > {rel:.0e}")
 
 
 def assert_satisfied_close(flags, Z_ref, thr=1e-6):
