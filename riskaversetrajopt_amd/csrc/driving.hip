@@ -362,7 +362,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
 //            accumulating the row's dot product with u for g_up (driving.py:295).
 // The forward/column kernel above re-rolls the pedestrian once per column group and carries
 // 8 registers per control step; it stays as the fallback when the LDS tables do not fit.
-constexpr int CROWS_NW = 8;
+#ifndef RATO_CROWS_NW
+#define RATO_CROWS_NW 8          // waves per workgroup (A/B builds: tools/ab.sh ... -DRATO_CROWS_NW=16)
+#endif
+constexpr int CROWS_NW = RATO_CROWS_NW;
 constexpr int CROWS_SAMPLES = 64;
 
 typedef float cfloat2_t __attribute__((ext_vector_type(2)));
@@ -372,7 +375,7 @@ __host__ __device__ inline size_t car_rows_lds_floats(int S) {
   // K4 float4 + QP float2 per (k, lane) | EGOP float2[S+1] | EC float4[S] | EC2 float4[S] | US float2[S] | head (+pad)
   // | ego v, phi [S+1] each | 8 x 4 reduction slots (final rows, workgroup 0) | fp64 v, cos, sin [S+1] each
   return (size_t)S * CROWS_SAMPLES * 6 + (size_t)(S + 1) * 2 + (size_t)S * 8 + (size_t)S * 2 + 4 +
-         (size_t)(S + 1) * 2 + 32 + (size_t)(S + 1) * 6 + 2;
+         (size_t)(S + 1) * 2 + CROWS_NW * 4 + (size_t)(S + 1) * 6 + 2;
 }
 
 // LOOP: several tiles per workgroup through the global tile queue (large batches).
@@ -400,8 +403,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   int* head = reinterpret_cast<int*>(US + S);
   float* SV = reinterpret_cast<float*>(head + 4);                            // [S+1] ego speed
   float* SPH = SV + (S + 1);                                                 // [S+1] ego heading
-  float* RED = SPH + (S + 1);                                                // [8][4]
-  double* DV = reinterpret_cast<double*>(car_lds_raw + (((reinterpret_cast<unsigned char*>(RED + 32) - car_lds_raw) + 7) & ~size_t(7)));
+  float* RED = SPH + (S + 1);                                                // [CROWS_NW][4]
+  double* DV = reinterpret_cast<double*>(car_lds_raw + (((reinterpret_cast<unsigned char*>(RED + CROWS_NW * 4) - car_lds_raw) + 7) & ~size_t(7)));
   double* DCS = DV + (S + 1);                                                // fp64 speed | cos | sin of the ego
   double* DSN = DCS + (S + 1);
 

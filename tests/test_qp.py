@@ -122,3 +122,46 @@ def test_reduced_linear_system_equals_kkt_form():
     np.testing.assert_allclose(out["kkt"].x, out["reduced"].x, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(out["kkt"].y, out["reduced"].y, rtol=1e-6, atol=1e-8)
     assert out["kkt"].info.iter == out["reduced"].info.iter
+
+
+@pytest.mark.parametrize("system", ["drone", "driving"])
+def test_saa_qp_against_an_independent_exact_solver(system):
+    """The host QP on the reference's OWN problem class (the SAA subproblem in the reference's layout: SURVEY appendix
+    A), against a solver that shares no code with it: the (u, slack) reduction solved by cutting planes with an exact
+    active-set master (cvar_cuts + dense_qp: least-distance programming through NNLS; tests/_host_cuts.py), whose
+    solution is itself certified against the KKT conditions of the full QP (tests/test_reduced_host.py).  Polished
+    solutions agree to 1e-6 in every control and in the objective -- osqp itself is not installable here, so this is
+    the cross-check the restated ADMM + polish gets instead."""
+    from oracle import drone as od, driving as ocar
+    from tests._host_cuts import DroneReducedOracle, DrivingReducedOracle
+    from tests._oracle_qp import DroneOracleQP, DrivingOracleQP
+    S = 20
+    if system == "drone":
+        DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(4), 'saa', M=24, S=S)
+        o = od.Model(S, DWs, masses, Q, 'saa', 0.2)
+        full, red, nU, first = DroneOracleQP(o), DroneReducedOracle(o), 3 * S, 2
+    else:
+        o = ocar.Model(*ocar.sample_uncertain_parameters(np.random.RandomState(4), 24, 'saa', S), method='saa', alpha=0.15)
+        full, red, nU, first = DrivingOracleQP(o), DrivingReducedOracle(o), 2 * S, 1
+    us = o.initial_guess_us_mat()
+    full.define_problem(us)
+    polished = 0
+    for it in range(6):
+        if system == "drone":
+            full.update_problem(us, it)
+        else:
+            full.define_problem(us, it)
+        uf, tf = full.solve()
+        ur, tr, info = red.solve_reduced(us, it, tol=1e-11)
+        res = full.res
+        assert res.info.status == 'solved'
+        if res.info.status_polish == 1:
+            polished += 1
+            np.testing.assert_allclose(uf, ur, rtol=0, atol=2e-6)
+            z = np.concatenate([ur.reshape(-1), [info["slack"]]])
+            obj_red = 0.5 * z @ (red.cs.P @ z) + red.cs.q @ z
+            assert abs(res.info.obj_val - obj_red) < 2e-3 * max(1.0, abs(obj_red)) * 1e-3 + 2e-4   # delta = 1e-6 of polish
+            if it >= first:
+                assert abs(tf - tr) < 2e-6
+        us = ur
+    assert polished >= 4
