@@ -7,8 +7,8 @@ import numpy as np
 
 STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the car)
 G_RTOL, G_ATOL = 2e-5, 3e-5                # constraint values (drone g reaches ~ -90; measured max 1e-5 abs)
-JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (drone: measured <= 1e-5)
-JAC_REL_ROWMAX_DRIVING = 1e-4              # driving: set below from the measured worst case (RATO_TOL_REPORT=1)
+JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (drone: measured <= 1.8e-5, RATO_TOL_REPORT=1)
+JAC_REL_ROWMAX_DRIVING = 1e-4              # driving: measured <= 3.7e-5 (the 1/r repulsion amplifies the fp32 rollout)
 MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
 RISK_ATOL = 1e-4                           # VaR / CVaR
 NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this
