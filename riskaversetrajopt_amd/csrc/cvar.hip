@@ -35,6 +35,50 @@ __device__ __forceinline__ void tail_rule(const double* __restrict__ st, double 
   lambda = (float)fmin(fmax(l, 0.0), 1.0);
 }
 
+// Block-wide, order-preserving compaction of the tail samples.  Only ~alpha of the samples carry a weight; left where
+// they are, every wave of the block would run the whole sweep (and its fp64 wave sums) for a handful of active lanes.
+// The samples with w != 0 are moved, in sample order (deterministic sums), to lanes [0, n) of the block: afterwards
+// lane L < n holds (sample index, weight, row) of the L-th tail sample and only ceil(n / 64) waves have work.
+struct TailLane {
+  long m;     // sample index (clamped to a valid one for idle lanes)
+  float w;    // tail weight, 0 for idle lanes
+  int t, r;   // arg-max row (step, row group)
+};
+__device__ __forceinline__ int compact_tail(float w, int t, int r, long block_base, long M, TailLane& out) {
+  __shared__ int s_cnt[RATO_BLOCK / RATO_WAVE];
+  __shared__ int s_src[RATO_BLOCK];
+  __shared__ float s_w[RATO_BLOCK];
+  __shared__ int s_tr[RATO_BLOCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool act = (w != 0.0f);
+  const unsigned long long bal = __ballot(act);
+  const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < RATO_BLOCK / RATO_WAVE; ++i) {
+    const int c = s_cnt[i];
+    if (i < wave) base += c;
+    total += c;
+  }
+  if (act) {
+    s_src[base + pre] = threadIdx.x;
+    s_w[base + pre] = w;
+    s_tr[base + pre] = t | (r << 20);
+  }
+  __syncthreads();
+  const bool work = (int)threadIdx.x < total;
+  const int src = work ? s_src[threadIdx.x] : 0;
+  const long m = block_base + src;
+  out.m = (m < M) ? m : M - 1;
+  out.w = work ? s_w[threadIdx.x] : 0.0f;
+  const int tr = work ? s_tr[threadIdx.x] : 0;
+  out.t = tr & 0xfffff;
+  out.r = tr >> 20;
+  return total;
+}
+
 // grid = ceil(M/64) workgroups; rows t are pulled from an LDS queue, longest first.
 template <int R, bool FACT>
 __global__ __launch_bounds__(RM_NW* RATO_WAVE) void rowmax_kernel(const float* __restrict__ G,
@@ -156,16 +200,24 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
   float tstar, lambda;
   tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
-  const bool valid = m < M;
   float w = 0.0f;
   int t = 0, r = 0;
-  if (valid) {
-    w = tail_weight(mvals[m], tstar, lambda);
-    const int a = arg[m];
-    r = a / S;
-    t = a - r * S;
+  {
+    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+    if (m0 < M) {
+      w = tail_weight(mvals[m0], tstar, lambda);
+      const int a = arg[m0];
+      r = a / S;
+      t = a - r * S;
+    }
   }
+  TailLane tl;
+  const int n_tail = compact_tail(w, t, r, (long)blockIdx.x * RATO_BLOCK, M, tl);   // tail samples -> lanes [0, n_tail)
+  const int work_waves = (n_tail + RATO_WAVE - 1) / RATO_WAVE;
+  const long m = tl.m;
+  w = tl.w;
+  t = tl.t;
+  r = tl.r;
   const size_t n_pairs = (size_t)S * (S - 1) / 2;
   const bool fact = (W != nullptr);
   const int RR = fact ? 1 : R;
@@ -182,7 +234,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
   const int rsel = fact ? 0 : r;
   const int nw = 2 * (S - 1), nc = nw + 1;
   constexpr int SB = 8;   // columns per batch: 16 gathers in flight, then 16 wave reductions
-  for (int sb = 0; sb < S - 1; sb += SB) {
+  for (int sb = 0; sb < S - 1 && wave < work_waves; sb += SB) {
     float g0[SB], g1[SB];
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
@@ -208,13 +260,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void tail_rows_batch_kernel(
       }
     }
   }
-  const double sg = rato::wave_sum_dpp(wg);
-  if (lane == 0) trb_lds[wave * nc + nw] = sg;
+  if (wave < work_waves) {
+    const double sg = rato::wave_sum_dpp(wg);
+    if (lane == 0) trb_lds[wave * nc + nw] = sg;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
     double acc = 0.0;
-#pragma unroll
-    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += trb_lds[wv * nc + i];
+    for (int wv = 0; wv < work_waves; ++wv) acc += trb_lds[wv * nc + i];   // fixed order
     part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
   }
 }
@@ -238,17 +291,24 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
   float tstar, lambda;
   tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long m_raw = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
-  const bool valid = m_raw < M;
-  const long m = valid ? m_raw : M - 1;
   float w = 0.0f;
   int t = 0, r = 0;
-  if (valid) {
-    w = tail_weight(mvals[m], tstar, lambda);
-    const int a = arg[m];
-    r = a / S;
-    t = a - r * S;
+  {
+    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+    if (m0 < M) {
+      w = tail_weight(mvals[m0], tstar, lambda);
+      const int a = arg[m0];
+      r = a / S;
+      t = a - r * S;
+    }
   }
+  TailLane tl;
+  const int n_tail = compact_tail(w, t, r, (long)blockIdx.x * RATO_BLOCK, M, tl);   // tail samples -> lanes [0, n_tail)
+  const int work_waves = (n_tail + RATO_WAVE - 1) / RATO_WAVE;
+  const long m = tl.m;
+  w = tl.w;
+  t = tl.t;
+  r = tl.r;
   const double dt = (double)P.dt;
   double w0 = 0.0, w1 = 0.0, wg = 0.0, a21 = 0.0;
   if (w != 0.0f) {
@@ -262,7 +322,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
   const int nw = 2 * (S - 1), nc = nw + 1;
   double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
   constexpr int SB = 8;
-  for (int kb = S - 1; kb >= 1; kb -= SB) {
+  for (int kb = S - 1; kb >= 1 && wave < work_waves; kb -= SB) {
     float ax[SB], ay[SB];
 #pragma unroll
     for (int i = 0; i < SB; ++i) {   // the a22 of the batch for the lanes that are in the sweep at that step
@@ -296,13 +356,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
       }
     }
   }
-  const double sg = rato::wave_sum_dpp(wg);
-  if (lane == 0) tri_lds[wave * nc + nw] = sg;
+  if (wave < work_waves) {
+    const double sg = rato::wave_sum_dpp(wg);
+    if (lane == 0) tri_lds[wave * nc + nw] = sg;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) {
     double acc = 0.0;
-#pragma unroll
-    for (int wv = 0; wv < RATO_BLOCK / 64; ++wv) acc += tri_lds[wv * nc + i];
+    for (int wv = 0; wv < work_waves; ++wv) acc += tri_lds[wv * nc + i];   // fixed order
     part[((size_t)blockIdx.x * K + kk) * nc + i] = acc;
   }
 }

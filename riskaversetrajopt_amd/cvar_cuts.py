@@ -194,12 +194,35 @@ class CvarCutSolver:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
 
+    def enqueue_relinearize(self, G, W, tile, base):
+        """Stream-ordered half of ``relinearize_kept_cuts`` (launches + the read-back into pinned memory, NO
+        synchronisation): called right behind the linearize launch, so that the caller's own read-back of the sample
+        sums waits for both at once instead of paying a second round trip."""
+        self._relin_pending = self._relin_launch(G, W, tile, base)
+
     def relinearize_kept_cuts(self, G, W, tile, base):
         """The kept cuts under the current linearization -> (rows (K, nU), rhs (K,)):  rows[k].u - c_s s <= rhs[k].
-        One batched launch + one partial-sum launch + one read-back."""
-        K, S, M, n_u = len(self.keep), self.S, self.M, self.n_u
-        if K == 0 or S < 2:
+        One batched launch + one partial-sum launch + one read-back (already in flight after ``enqueue_relinearize``)."""
+        K = getattr(self, "_relin_pending", None)
+        self._relin_pending = None
+        if K is None:
+            K = self._relin_launch(G, W, tile, base)
+        if K == 0:
             return np.zeros((0, self.nU)), np.zeros(0)
+        S, n_u = self.S, self.n_u
+        torch.cuda.current_stream().synchronize()
+        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / self.alphaM
+        rows = np.zeros((K, self.nU))
+        rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
+        # cut k:  rows[k].(u - x0) + sign c0_k - c_s s <= rhs0
+        sign, x0 = self._form()
+        return rows, self.rhs0 + rows @ x0 - sign * r[:, self.nc - 1]
+
+    def _relin_launch(self, G, W, tile, base):
+        """-> number of kept cuts whose sums are on their way to ``sums_b_host`` (0: nothing to do)"""
+        K, S, M, n_u = len(self.keep), self.S, self.M, self.n_u
+        if K == 0 or S < 2 or not self.recycle:
+            return 0
         self.slots_host[:K] = torch.as_tensor(self.keep, dtype=torch.int32)
         self.slots_dev.copy_(self.slots_host, non_blocking=True)
         part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
@@ -219,13 +242,7 @@ class CvarCutSolver:
         if self.world > 1:
             self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
         self.sums_b_host.copy_(self.sums_b, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / self.alphaM
-        rows = np.zeros((K, self.nU))
-        rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
-        # cut k:  rows[k].(u - x0) + sign c0_k - c_s s <= rhs0
-        sign, x0 = self._form()
-        return rows, self.rhs0 + rows @ x0 - sign * r[:, self.nc - 1]
+        return K
 
     # ---- master QP (host, exact: dense_qp) -----------------------------------------
     def solve(self, *args, **kwargs):
@@ -263,6 +280,8 @@ class CvarCutSolver:
             n_rows = 1
         cut_rows = []                                   # (row of the master, ring slot) of every CVaR cut
         kept = list(self.keep) if (self.recycle and with_cvar) else []
+        if not kept:
+            self._relin_pending = None                  # (an enqueued batch for a relaxed iteration is simply not read)
         info["master_s"] += time.perf_counter() - t0
         if kept:
             t0 = time.perf_counter()

@@ -406,6 +406,8 @@ class Model:
                                          group=getattr(self, "_group", None), world=getattr(self, "_world", 1),
                                          mode=self.method, rhs0=0.0)
             self._cut_solver = cs
+        if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
+            cs.enqueue_relinearize(r["G"], None, r["tile"], r["g_up"])      # one device round trip with the read-backs below
         info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
                         r["final_rhs"].double().cpu().numpy(),
                         u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),

@@ -599,6 +599,14 @@ class Model:
                                          group=getattr(self, "_group", None), world=world, mode=self.method,
                                          rhs0=-1e-3 / self.MULTIPLIER)
             self._cut_solver = cs
+        cs.implicit = None
+        if implicit:
+            dW, mass, Qsym, _ = self._inputs(None)
+            cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
+        if scp_iter >= 2 and world == 1:
+            # the kept cuts against this linearization: launched now, so that the read-back of the sample sums below
+            # waits for both (one device round trip instead of two)
+            cs.enqueue_relinearize(r["G"], r["_W"], r["tile"], r["_g_up"])
         sums = r["sums"]
         if world > 1:                                     # sample means over ALL shards, summed in rank order
             from . import dist as rdist
@@ -606,10 +614,6 @@ class Model:
         sums = sums.cpu().numpy()
         final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / (M * world))
         final_rhs = sums[6 * S:] / (M * world)
-        cs.implicit = None
-        if implicit:
-            dW, mass, Qsym, _ = self._inputs(None)
-            cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs,
                         u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
                         with_cvar=(scp_iter >= 2), tol=tol, verbose=verbose)
