@@ -166,20 +166,35 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ A22,
     float* __restrict__ W, float* __restrict__ g_up, float* __restrict__ Z, float* __restrict__ part) {
+  // Arithmetic in fp64, outputs rounded ONCE to fp32 (round 3).  The kernel is bound by the latency of its loads, one
+  // lane per sample: ~100 flops per step cost nothing in double precision, and the tables then carry 6e-8 of rounding
+  // instead of the ~1e-6 that 50 fp32 Euler steps accumulate -- which the cutting-plane solve of an SCP subproblem whose
+  // step from the linearization point is O(1) (the iteration where the CVaR rows switch on) amplified to 4e-5 in u
+  // (profiles/r03_k_parity_sweep.txt).  Inputs are the same fp32 arrays as everywhere else.
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const size_t m_raw = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
   const bool valid = m_raw < M;
   const size_t m = valid ? m_raw : M - 1;
   const int S = P.S;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const SampleConsts c = load_consts(P, mass, Qsym, ld, m);
-  float p[3], v[3], dp[2] = {0.0f, 0.0f}, dv[2] = {0.0f, 0.0f};   // state | response of the linearized x, y axes to u_bar
+  const double dt = (double)P.dt, kp = (double)P.kp, kd = (double)P.kd, drag = (double)P.drag;
+  const double inv_m = 1.0 / (double)mass[m];
+  const double a21 = -kp * dt * inv_m, dtm = dt * inv_m;
+  const double cn = sqrt(dt) * (double)P.beta * inv_m;   // sqrt(dt) * (beta/m): drone_risk.py:136,151
+  double q00[NOBS], qs[NOBS], q11[NOBS];
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    q00[j] = (double)Qsym[(size_t)(j * 3 + 0) * ld + m];
+    qs[j] = (double)Qsym[(size_t)(j * 3 + 1) * ld + m];
+    q11[j] = (double)Qsym[(size_t)(j * 3 + 2) * ld + m];
+  }
+  double p[3], v[3], dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};   // state | response of the linearized x, y axes to u_bar
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    p[a] = P.x_init[a];
-    v[a] = P.x_init[3 + a];
+    p[a] = (double)P.x_init[a];
+    v[a] = (double)P.x_init[3 + a];
   }
-  float zmax = -INFINITY;
+  double zmax = -INFINITY;
   float xi[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
@@ -188,62 +203,68 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
 #pragma unroll
     for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
-    float a22[3];
+    double a22[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      a22[a] = 1.0f - P.dt * (P.kd + 2.0f * P.drag * fabsf(v[a])) * c.inv_m;   // A_t[1,1] at the state BEFORE the step
-      if (valid) A22[((size_t)t * 3 + a) * ld + m] = a22[a];
+      a22[a] = 1.0 - dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m;   // A_t[1,1] at the state BEFORE the step
+      if (valid) A22[((size_t)t * 3 + a) * ld + m] = (float)a22[a];
     }
     // d x_{t+1} = A_t d x_t + B u_t  (x, y): the forward form of the adjoint row sweep; d p(t+1) = (Phi u_bar)[t]
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const float ndp = dp[a] + P.dt * dv[a];
-      const float ndv = c.a21 * dp[a] + a22[a] * dv[a] + c.dtm * us[t * 3 + a];
+      const double ndp = dp[a] + dt * dv[a];
+      const double ndv = a21 * dp[a] + a22[a] * dv[a] + dtm * (double)us[t * 3 + a];
       dp[a] = ndp;
       dv[a] = ndv;
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
+    for (int a = 0; a < 3; ++a) {   // one Euler-Maruyama step of one axis (drone_risk.py:122-131,148-153)
+      const double acc = ((double)us[t * 3 + a] - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
+      const double pn = p[a] + dt * v[a];
+      v[a] = v[a] + dt * acc + cn * (double)xi[a];
+      p[a] = pn;
+    }
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
-      const float dx = p[0] - P.obs_xy[j][0], dy = p[1] - P.obs_xy[j][1];
-      const float gj = 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
-      const float wx = -(2.0f * c.q00[j] * dx + c.qs[j] * dy), wy = -(c.qs[j] * dx + 2.0f * c.q11[j] * dy);
-      zmax = fmaxf(zmax, gj);
+      const double dx = p[0] - (double)P.obs_xy[j][0], dy = p[1] - (double)P.obs_xy[j][1];
+      const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
+      const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
+      zmax = fmax(zmax, gj);
       if (valid) {
-        W[(((size_t)j * S + t) * 2 + 0) * ld + m] = wx;
-        W[(((size_t)j * S + t) * 2 + 1) * ld + m] = wy;
+        W[(((size_t)j * S + t) * 2 + 0) * ld + m] = (float)wx;
+        W[(((size_t)j * S + t) * 2 + 1) * ld + m] = (float)wy;
         // -g + (grad g) . u   (drone_risk.py:278), or -- rows_out = 1 -- the constraint value g itself
-        g_up[((size_t)j * S + t) * ld + m] = P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]);
+        g_up[((size_t)j * S + t) * ld + m] = (float)(P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]));
       }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
   }
-  if (Z && valid) Z[m] = zmax - P.tol;
+  if (Z && valid) Z[m] = (float)(zmax - (double)P.tol);
   // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
-  // (drone_risk.py:271): adjoint from S over the a22 this lane wrote above (same thread: program order)
-  extern __shared__ float gen_red[];   // [waves][S + 1][6]: per-wave sums, combined once after the sweep
+  // (drone_risk.py:271): adjoint from S over the a22 (recomputed from the fp32 table this lane wrote: the consumers of
+  // the table see the same numbers)
+  extern __shared__ double gen_red[];   // [waves][S + 1][6]: per-wave sums, combined once after the sweep
   constexpr int NWV = RATO_BLOCK / RATO_WAVE;
-  float mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
+  double mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    mP0[a] = 1.0f; mP1[a] = 0.0f; mV0[a] = 0.0f; mV1[a] = 1.0f; dP[a] = 0.0f; dV[a] = 0.0f;
+    mP0[a] = 1.0; mP1[a] = 0.0; mV0[a] = 0.0; mV1[a] = 1.0; dP[a] = 0.0; dV[a] = 0.0;
   }
   for (int s2 = S - 1; s2 >= 0; --s2) {
-    float eP[3], eV[3];
+    double eP[3], eV[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      eP[a] = mP1[a] * c.dtm;
-      eV[a] = mV1[a] * c.dtm;
-      const float ua = us[s2 * 3 + a];
+      eP[a] = mP1[a] * dtm;
+      eV[a] = mV1[a] * dtm;
+      const double ua = (double)us[s2 * 3 + a];
       dP[a] += eP[a] * ua;
       dV[a] += eV[a] * ua;
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float sp = rato::wave_sum_dpp(valid ? eP[a] : 0.0f);
-      const float sv = rato::wave_sum_dpp(valid ? eV[a] : 0.0f);
+      const double sp = rato::wave_sum_dpp(valid ? eP[a] : 0.0);
+      const double sv = rato::wave_sum_dpp(valid ? eV[a] : 0.0);
       if (lane == 0) {
         gen_red[(wave * (S + 1) + s2) * 6 + a] = sp;
         gen_red[(wave * (S + 1) + s2) * 6 + 3 + a] = sv;
@@ -252,17 +273,17 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     if (s2 > 0) {  // mu_s = mu_{s+1} A_s
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float a22 = A22[((size_t)s2 * 3 + a) * ld + m];
-        const float nP0 = mP0[a] + mP1[a] * c.a21, nP1 = mP0[a] * P.dt + mP1[a] * a22;
-        const float nV0 = mV0[a] + mV1[a] * c.a21, nV1 = mV0[a] * P.dt + mV1[a] * a22;
+        const double a22 = (double)A22[((size_t)s2 * 3 + a) * ld + m];
+        const double nP0 = mP0[a] + mP1[a] * a21, nP1 = mP0[a] * dt + mP1[a] * a22;
+        const double nV0 = mV0[a] + mV1[a] * a21, nV1 = mV0[a] * dt + mV1[a] * a22;
         mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
       }
     }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float rp = rato::wave_sum_dpp(valid ? (-(p[a] - P.x_final[a]) + dP[a]) : 0.0f);
-    const float rv = rato::wave_sum_dpp(valid ? (-(v[a] - P.x_final[3 + a]) + dV[a]) : 0.0f);
+    const double rp = rato::wave_sum_dpp(valid ? (-(p[a] - (double)P.x_final[a]) + dP[a]) : 0.0);
+    const double rv = rato::wave_sum_dpp(valid ? (-(v[a] - (double)P.x_final[3 + a]) + dV[a]) : 0.0);
     if (lane == 0) {
       gen_red[(wave * (S + 1) + S) * 6 + a] = rp;
       gen_red[(wave * (S + 1) + S) * 6 + 3 + a] = rv;
@@ -270,10 +291,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 6 * S + 6; i += RATO_BLOCK) {   // [s*6 + e] and, last, the 6 rhs entries
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) acc += gen_red[w * (S + 1) * 6 + i];   // fixed order
-    part[(size_t)blockIdx.x * (6 * S + 6) + i] = acc;
+    part[(size_t)blockIdx.x * (6 * S + 6) + i] = (float)acc;
   }
 }
 
@@ -1066,8 +1087,8 @@ extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym || !A22 || !W || !g_up || !part) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(float);
-  if (lds > 64 * 1024) return RATO_EINVAL;
+  const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(double);
+  if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 340
   hipLaunchKernelGGL(drone_linearize_generators_kernel, grid, block, lds, rato::as_stream(stream), *p, us, dW, mass,
                      Qsym, A22, W, g_up, Z, part);
   RATO_LAUNCH_CHECK();

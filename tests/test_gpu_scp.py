@@ -353,6 +353,16 @@ def test_generators_only_linearization_matches_the_jacobian_kernel(S, M):
     np.testing.assert_allclose(gen["sums"].cpu().numpy(), full["sums"].cpu().numpy(), rtol=2e-5, atol=2e-3)
     _, _, _, _, gup_o = o.get_all_constraints_coeffs(us)
     np.testing.assert_allclose(gen["g_up"].permute(2, 0, 1).cpu().numpy(), gup_o, rtol=5e-5, atol=2e-4)
+    # the generators kernel computes in fp64 and rounds its outputs once: against the fp64 oracle its constraint values
+    # carry the rounding of the fp32 INPUTS (noise, masses, Q) and of the output, not 50 fp32 Euler steps
+    xs_o = o.us_to_state_trajectories(us)
+    g_o = o.obstacle_avoidance_constraints(xs_o, np.asarray(o.obs_Qs))                             # (M, 3, S)
+    g_gen = d.linearize_generators_device(us, rows_out=1)["g_up"].permute(2, 0, 1).cpu().numpy().astype(np.float64)
+    g_row = d.linearize_device(us, rows_out=1)["g_up"].permute(2, 0, 1).cpu().numpy().astype(np.float64)
+    e_gen, e_row = np.abs(g_gen - g_o).max(), np.abs(g_row - g_o).max()
+    print(f"S={S} M={M}: max |g - g_oracle|: generators kernel (fp64 arithmetic) {e_gen:.2e}, row kernel (fp32) {e_row:.2e}, "
+          f"max |g| {np.abs(g_o).max():.1f}")
+    np.testing.assert_allclose(g_gen, g_o, rtol=1e-6, atol=5e-6)
     if S < 2:
         return
     # rows of tail samples: implicit (from A22) vs explicit (from Phi), K = 3 synthetic cuts
