@@ -409,6 +409,7 @@ def board_info():
 def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
     alg = work.algorithmic_bytes()
     achieved = alg / (kern_ms * 1e-3) / 1e9
+    tr = pmc_traffic(workload, mode, M, S, jacobian)
     return {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "frac_of_measured_copy_6290": achieved / 6290.0,
@@ -417,8 +418,11 @@ def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
             "frac_of_store_only_replay_5700": (achieved / 5700.0) if mode == "linearize" else None,
             "algorithmic_bytes_per_launch": alg, "bytes_per_sample_step": alg / (M * S),
             "kernel_ms": kern_ms, "kernel_ms_source": kern_src,
-            "traffic": None,
-            "traffic_from_profile": pmc_traffic(workload, mode, M, S, jacobian)}
+            # HBM bytes per launch from the PMC counters: they cannot be collected inside this run (rocprofv3 --pmc is
+            # a separate pass of the same command), so this is the committed pass for this workload, or null
+            "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+            "traffic_over_algorithmic": ((tr["hbm_bytes_per_launch"] / alg) if tr else None),
+            "traffic_from_profile": tr}
 
 
 def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, probe_clock=True):
