@@ -109,6 +109,7 @@ class CvarCutSolver:
         self.nres = stats.N_STATS + self.nc
         self.keep = []                                   # slots kept from the previous solve
         self.u_lin = None                                # linearization point of the delta form (None: reference form)
+        self._relin_pending = None                       # kept cuts whose re-linearization is already in flight
         if device is not None:                           # (None: a host oracle overrides evaluate / relinearize_kept_cuts
             self._alloc_device(device)                   #  -- tests/_host_cuts.py, the fp64 checker of this loop)
 
@@ -203,8 +204,7 @@ class CvarCutSolver:
     def relinearize_kept_cuts(self, G, W, tile, base):
         """The kept cuts under the current linearization -> (rows (K, nU), rhs (K,)):  rows[k].u - c_s s <= rhs[k].
         One batched launch + one partial-sum launch + one read-back (already in flight after ``enqueue_relinearize``)."""
-        K = getattr(self, "_relin_pending", None)
-        self._relin_pending = None
+        K, self._relin_pending = self._relin_pending, None
         if K is None:
             K = self._relin_launch(G, W, tile, base)
         if K == 0:

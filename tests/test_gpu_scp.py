@@ -458,22 +458,22 @@ def test_reduced_baseline_scp_matches_full_qp_scp(system, M):
     assert np.all(Au[fin] <= u[fin] + 2e-5)
 
 
-@pytest.mark.parametrize("system,M,alpha", [("drone", 200, 0.1), ("drone", 10000, 0.05), ("driving", 200, 0.1),
-                                            ("driving", 10000, 0.05)])
-def test_reduced_subproblems_device_vs_fp64_host_oracle(system, M, alpha):
+@pytest.mark.parametrize("system,M,alpha,S", [("drone", 200, 0.1, 20), ("drone", 10000, 0.05, 20), ("driving", 200, 0.1, 20),
+                                              ("driving", 10000, 0.05, 20), ("drone", 3000, 0.1, 50), ("driving", 3000, 0.05, 40)])
+def test_reduced_subproblems_device_vs_fp64_host_oracle(system, M, alpha, S):
     """The benchmarked path (device linearization in fp32, device cut oracle) against the SAME algorithm run entirely
     in fp64 on the fp64 oracle's linearization (tests/_host_cuts.py; its equality with the reference's full QP is a CPU
     test, tests/test_reduced_host.py) -- at batch sizes beyond what a host QP solves reliably.  Every subproblem of the
     SCP path is solved by both from the SAME iterate (the fp64 leg's), so that each comparison is one subproblem, not
     the accumulated drift of two sequences."""
     from tests._host_cuts import DroneReducedOracle, DrivingReducedOracle
-    S = 20
+    # (S = 50 / 40: the horizons of the BASELINE configurations, at the largest M whose dense fp64 rows the host holds)
     if system == "drone":
         o, d = _drone(M, S, alpha=alpha, seed=11)
-        h, iters = DroneReducedOracle(o), 12
+        h, iters = DroneReducedOracle(o), (12 if S == 20 else 8)
     else:
         o, d = _car(M, S, alpha=alpha, seed=11)
-        h, iters = DrivingReducedOracle(o), 8
+        h, iters = DrivingReducedOracle(o), (8 if S == 20 else 6)
     us = h.initial_guess_us_mat()
     du, dt_ = [], []
     for k in range(iters):
@@ -484,7 +484,15 @@ def test_reduced_subproblems_device_vs_fp64_host_oracle(system, M, alpha):
         us = uh
     print(system, M, "per-subproblem max |du|:", " ".join("%.1e" % v for v in du), "| |dt_risk|:",
           " ".join("%.1e" % v for v in dt_))
-    assert max(du) < 1e-5 and max(dt_) < 1e-5
+    first = 2 if system == "drone" else 1                # the subproblem where the CVaR rows switch on
+    if S == 20:
+        assert max(du) < 1e-5 and max(dt_) < 1e-5
+    else:
+        # longer horizons: the step from the linearization point is O(1) at the switch-on iteration, and the fp32
+        # ROUNDING OF THE STORED TABLES (W: 6e-8 of |W| ~ 1e2-1e3; Phi: up to S products of a22) reaches the rows at
+        # ~1e-5 there (measured 2.4e-5 in u at S = 50 for this seed, 9e-7 ... 6e-6 for others: tools/parity_sweep.py);
+        # every later subproblem is asserted at 1e-5 (measured <= 2e-6, 2e-8 at the end)
+        assert du[first] < 1e-4 and max(du[:first] + du[first + 1:]) < 1e-5 and max(dt_) < 1e-5
 
 
 @pytest.mark.parametrize("system,M,alpha,iters", [("drone", 200, 0.1, 40), ("driving", 200, 0.1, 10)])

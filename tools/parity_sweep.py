@@ -16,21 +16,27 @@ sys.path.insert(0, ROOT)
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     M = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    S_arg = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    # "round": the fp64 leg gets the samples rounded to fp32 (what the device holds), which separates the rounding of
+    # the INPUTS from what the device arithmetic and its fp32 tables add
+    round_inputs = len(sys.argv) > 4 and sys.argv[4] == "round"
+    r32 = (lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)) if round_inputs else (lambda a: a)
     from oracle import drone as od, driving as ocar
     from riskaversetrajopt_amd import drone_risk, driving
     from tests._host_cuts import DroneReducedOracle, DrivingReducedOracle
-    S = 20
+    S = S_arg
     for system in ("drone", "driving"):
         worst_all = 0.0
         for seed in range(n_seeds):
             alpha = (0.05, 0.1, 0.2)[seed % 3]
             if system == "drone":
                 DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(100 + seed), 'saa', M=M, S=S)
-                o, d = od.Model(S, DWs, masses, Q, 'saa', alpha), drone_risk.Model(S, DWs, masses, Q, 'saa', alpha)
+                o, d = od.Model(S, r32(DWs), r32(masses), r32(Q), 'saa', alpha), drone_risk.Model(S, DWs, masses, Q, 'saa', alpha)
                 h, iters = DroneReducedOracle(o), 14
             else:
                 samples = ocar.sample_uncertain_parameters(np.random.RandomState(100 + seed), M, 'saa', S)
-                o, d = ocar.Model(*samples, method='saa', alpha=alpha), driving.Model(M, 'saa', alpha, S=S, samples=samples)
+                o = ocar.Model(*[r32(x) for x in samples], method='saa', alpha=alpha)
+                d = driving.Model(M, 'saa', alpha, S=S, samples=samples)
                 h, iters = DrivingReducedOracle(o), 9
             us = h.initial_guess_us_mat()
             du, dtr = [], []
