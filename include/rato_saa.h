@@ -332,13 +332,15 @@ int rato_saa_rowmax(const float* G, const float* W /* NULL, or the factor of a f
  * p supplies M, ld, S, dt, kp.
  */
 int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
-                               int32_t a22_axes /* 2: [S][2][ld] of rato_drone_linearize; 3: [S][3][ld] of
-                                                   rato_drone_linearize_generators */,
+                               int32_t a22_axes /* 2: [S][2][ld] of rato_drone_linearize (a22); 3: [S][3][ld] of
+                                                   rato_drone_linearize_generators (1 - a22) */,
                                const float* W, const float* base, double sign, const double* xs,
                                float* m_out, int32_t* arg_out, void* stream);
 
 /*
- * Generators-only linearization (drone): A22 [S][3 axes][ld], W [3 obs][S][2][ld], g_up [3 obs][S][ld] (or g:
+ * Generators-only linearization (drone): A22 [S][3 axes][ld] -- holding the COMPLEMENT 1 - a22 = dt (k_d + 2 c_d |v|) / m
+ * (~1e-3: as an fp32 number it is exact to 1e-10 of a22; the consumers below rebuild a22 in fp64; the [S][2][ld] table
+ * of rato_drone_linearize holds a22 itself, and a22_axes tells the two apart) --, W [3 obs][S][2][ld], g_up [3 obs][S][ld] (or g:
  * p->rows_out), Z [M] or NULL, part [ceil(M/256)][6S+6] (per-block sums, layout of rato_drone_linearize) -- the whole
  * linearization in 12 S numbers per sample and NO Jacobian entries: Phi[t,s,a] = e_0' A_t ... A_{s+1} B is
  * regenerated from A22 by the consumers (rato_drone_rowmax_implicit for G.x, rato_drone_tail_rows_implicit for rows

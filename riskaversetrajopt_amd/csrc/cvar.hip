@@ -35,6 +35,13 @@ __device__ __forceinline__ void tail_rule(const double* __restrict__ st, double 
   lambda = (float)fmin(fmax(l, 0.0), 1.0);
 }
 
+// The step-Jacobian table comes in two forms, told apart by its axis count: [S][2][ld] from the row-parallel linearize
+// kernel holds a22 itself (its fp32 LDS table); [S][3][ld] from the generators-only linearization holds the complement
+// e22 = 1 - a22 ~ 1e-3, which an fp32 number represents to 1e-10 of a22 (drone.hip).  Either way a22 in fp64:
+__device__ __forceinline__ double a22_value(float stored, bool complement) {
+  return complement ? 1.0 - (double)stored : (double)stored;
+}
+
 // Block-wide, order-preserving compaction of the tail samples.  Only ~alpha of the samples carry a weight; left where
 // they are, every wave of the block would run the whole sweep (and its fp64 wave sums) for a handful of active lanes.
 // The samples with w != 0 are moved, in sample order (deterministic sums), to lanes [0, n) of the block: afterwards
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
       ax[i] = on ? A22[((size_t)k * a22_axes + 0) * ld + m] : 0.0f;
       ay[i] = on ? A22[((size_t)k * a22_axes + 1) * ld + m] : 0.0f;
     }
+    const bool compl22 = (a22_axes == 3);   // the generators' table holds 1 - a22 (see a22_value)
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
       const int k = kb - i;
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
         }
         double cx = 0.0, cy = 0.0;
         if (on) {
-          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * (double)ax[i];
-          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * (double)ay[i];
+          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * a22_value(ax[i], compl22);
+          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * a22_value(ay[i], compl22);
           m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
           cx = w0 * m1x;
           cy = w1 * m1y;
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
   const double dt = (double)P.dt;
   const double inv_m = 1.0 / (double)mass[m];
   const double a21 = -(double)P.kp * dt * inv_m, dtm = dt * inv_m;
+  const bool compl22 = (a22_axes == 3);            // the generators' table holds 1 - a22 (see a22_value)
   double px = 0.0, vx = 0.0, py = 0.0, vy = 0.0;   // d x_t (t = 0)
   double best = -INFINITY;
   int best_idx = 0;
@@ -408,7 +417,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
       if (t < S) {
         const double ux = xs[t * 3 + 0], uy = xs[t * 3 + 1];
         const double npx = px + dt * vx, npy = py + dt * vy;
-        const double nvx = a21 * px + (double)a2[i][0] * vx + dtm * ux, nvy = a21 * py + (double)a2[i][1] * vy + dtm * uy;
+        const double nvx = a21 * px + a22_value(a2[i][0], compl22) * vx + dtm * ux;
+        const double nvy = a21 * py + a22_value(a2[i][1], compl22) * vy + dtm * uy;
         px = npx; py = npy; vx = nvx; vy = nvy;             // d x_{t+1}
 #pragma unroll
         for (int j = 0; j < 3; ++j) {

@@ -206,8 +206,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     double a22[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      a22[a] = 1.0 - dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m;   // A_t[1,1] at the state BEFORE the step
-      if (valid) A22[((size_t)t * 3 + a) * ld + m] = (float)a22[a];
+      // A_t[1,1] = 1 - e22 at the state BEFORE the step.  The table stores e22 = dt (k_d + 2 c_d |v|) / m ~ 1e-3, not a22
+      // itself: rounded to fp32 it is exact to 1e-10 of a22, where a22 ~ 1 would carry 6e-8 -- and a row of Phi is a
+      // product of up to S of them.  The consumers rebuild a22 = 1 - e22 in fp64 from the SAME fp32 number.
+      const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
+      a22[a] = 1.0 - (double)e22;
+      if (valid) A22[((size_t)t * 3 + a) * ld + m] = e22;
     }
     // d x_{t+1} = A_t d x_t + B u_t  (x, y): the forward form of the adjoint row sweep; d p(t+1) = (Phi u_bar)[t]
 #pragma unroll
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     if (s2 > 0) {  // mu_s = mu_{s+1} A_s
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const double a22 = (double)A22[((size_t)s2 * 3 + a) * ld + m];
+        const double a22 = 1.0 - (double)A22[((size_t)s2 * 3 + a) * ld + m];
         const double nP0 = mP0[a] + mP1[a] * a21, nP1 = mP0[a] * dt + mP1[a] * a22;
         const double nV0 = mV0[a] + mV1[a] * a21, nV1 = mV0[a] * dt + mV1[a] * a22;
         mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;

@@ -318,7 +318,7 @@ class Model:
                 "A22": (A22[..., :M] if A22 is not None else None), "_A22": A22}
 
     def linearize_generators_device(self, us_mat, inputs=None, out=None, rows_out=0):
-        """Generators-only linearization (rato_drone_linearize_generators): A22 [S][3][M], W [n_obs][S][2][M],
+        """Generators-only linearization (rato_drone_linearize_generators): A22 [S][3][M] (holding 1 - a22), W [n_obs][S][2][M],
         g_up [n_obs][S][M], Z [M] and the sample sums -- everything ``solve_reduced`` needs -- without the S(S-1)
         Jacobian entries per sample (60 B instead of 245 B of HBM traffic per sample-step).  Same dict keys as
         ``linearize_device`` with G = None."""
