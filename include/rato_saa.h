@@ -72,7 +72,8 @@ extern "C" {
  * 5: rato_*_linearize_philox, rato_hopper_slip_host_inputs; 6: packed tile stride (rato_packed_tile_stride /
  * rato_packed_buffer_floats), rato_sums_and_risk_stats; 7: fp64 CVaR-cut oracle -- rato_saa_rowmax /
  * rato_drone_rowmax_implicit take (base, sign, double xs), the tail-row entry points write double partials
- * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out).
+ * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
+ * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy).
  * The Python binding refuses a library that reports another version. */
 #define RATO_ABI_VERSION 7
 int rato_abi_version(void);
@@ -114,6 +115,14 @@ typedef struct rato_drone_params {
   int32_t rows_out;     /* what the linearize entry points write into their g_up buffer: 0 = the reference's
                            g_up = -g + (grad g).u_k (drone_risk.py:278); 1 = the constraint value g at u_k itself
                            (the base of the oracle's delta form: rows(u) = g + G (u - u_k), see rato_saa_rowmax) */
+  /* The same constants in fp64, for the entry points that compute in double precision (the generators-only
+   * linearization and the CVaR-cut oracle): the reference's constants are Python floats, and 0.05f is 1.5e-8 away from
+   * 0.05, -1.4f is 2.4e-8 away from -1.4 -- which an obstacle row sees as 5e-7 of d = p - o where the drone grazes the
+   * obstacle.  The fp32 kernels keep reading the float fields above; fill both from the same numbers. */
+  double dt64, beta64, drag64, kp64, kd64, tol64;
+  double x_init64[6];
+  double x_final64[6];
+  double obs_xy64[RATO_DRONE_NOBS][2];
 } rato_drone_params;
 
 /*
@@ -379,6 +388,22 @@ int rato_drone_tail_rows_implicit(const rato_drone_params* p, const float* mass,
                                   const float* m_base, const int32_t* arg_base, const double* stats_base,
                                   int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
                                   double* part, void* stream);
+
+/*
+ * Table-free ("rollout") form of the drone oracle, delta form only:  rows(u) = g(u_k) + grad g(u_k) . (u - u_k).
+ * Instead of reading what a linearize call stored of the rollout at u_k in fp32 (A22, W, g: 44 S bytes per sample, each
+ * number rounded to 6e-8 of its own magnitude), these two calls RE-RUN that rollout in fp64 from the samples themselves
+ * (dW rows of the two horizontal axes, mass, Qsym: 8 S + 40 bytes per sample) while they propagate the response to
+ * xs = u - u_k (rowmax) / the adjoint of the arg-max rows (tail rows): 5 x less HBM traffic, and nothing of the fp32
+ * device path is left in the rows but the rounding of its inputs.  uk, xs: doubles [S][3].  Outputs as
+ * rato_drone_rowmax_implicit / rato_drone_tail_rows_implicit (the offset sum is sum_i w_i g_{i,r_i}: sign = +1).
+ */
+int rato_drone_rowmax_rollout(const rato_drone_params* p, const double* uk, const float* dW, const float* mass,
+                              const float* Qsym, const double* xs, float* m_out, int32_t* arg_out, void* stream);
+int rato_drone_tail_rows_rollout(const rato_drone_params* p, const double* uk, const float* dW, const float* mass,
+                                 const float* Qsym, const float* m_base, const int32_t* arg_base,
+                                 const double* stats_base, int64_t stats_stride, const int32_t* slots, int32_t K,
+                                 double alphaM, double* part, void* stream);
 
 /* ------------------------------------------------------------ device sampler */
 

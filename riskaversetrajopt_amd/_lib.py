@@ -16,7 +16,10 @@ class DroneParams(C.Structure):
     _fields_ = [("M", C.c_int32), ("ld", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
                 ("drag", C.c_float), ("kp", C.c_float), ("kd", C.c_float), ("tol", C.c_float),
                 ("x_init", C.c_float * 6), ("x_final", C.c_float * 6),
-                ("obs_xy", (C.c_float * 2) * 3), ("rows_out", C.c_int32)]
+                ("obs_xy", (C.c_float * 2) * 3), ("rows_out", C.c_int32),      # 28 words: the doubles start 8-byte aligned
+                ("dt64", C.c_double), ("beta64", C.c_double), ("drag64", C.c_double), ("kp64", C.c_double),
+                ("kd64", C.c_double), ("tol64", C.c_double), ("x_init64", C.c_double * 6),
+                ("x_final64", C.c_double * 6), ("obs_xy64", (C.c_double * 2) * 3)]
 
 
 class CarParams(C.Structure):
@@ -42,6 +45,9 @@ SIGNATURES = {
     "rato_drone_tail_rows_implicit": (C.c_int, [C.POINTER(DroneParams), c_float_p, c_float_p, C.c_int32] +
                                       [c_float_p] * 5 + [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p,
                                                          c_stream]),
+    "rato_drone_rowmax_rollout": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
+    "rato_drone_tail_rows_rollout": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 +
+                                     [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -51,11 +51,22 @@ struct TailLane {
   float w;    // tail weight, 0 for idle lanes
   int t, r;   // arg-max row (step, row group)
 };
-__device__ __forceinline__ int compact_tail(float w, int t, int r, long block_base, long M, TailLane& out) {
+struct TailLists {   // the compacted lists themselves (LDS), for kernels that walk them in chunks of one wave
+  int* src;
+  float* w;
+  int* tr;
+};
+__device__ __forceinline__ int compact_tail(float w, int t, int r, long block_base, long M, TailLane& out,
+                                            TailLists* lists = nullptr) {
   __shared__ int s_cnt[RATO_BLOCK / RATO_WAVE];
   __shared__ int s_src[RATO_BLOCK];
   __shared__ float s_w[RATO_BLOCK];
   __shared__ int s_tr[RATO_BLOCK];
+  if (lists) {
+    lists->src = s_src;
+    lists->w = s_w;
+    lists->tr = s_tr;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool act = (w != 0.0f);
   const unsigned long long bal = __ballot(act);
@@ -316,11 +327,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_implicit_kernel(
   w = tl.w;
   t = tl.t;
   r = tl.r;
-  const double dt = (double)P.dt;
+  const double dt = P.dt64;
   double w0 = 0.0, w1 = 0.0, wg = 0.0, a21 = 0.0;
   if (w != 0.0f) {
     const double inv_m = 1.0 / (double)mass[m];
-    a21 = -(double)P.kp * dt * inv_m;
+    a21 = -P.kp64 * dt * inv_m;
     const double dtm = dt * inv_m;
     w0 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 0) * ld + m] * dtm;
     w1 = (double)w * (double)W[(((size_t)r * S + t) * 2 + 1) * ld + m] * dtm;
@@ -388,9 +399,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
   if (m >= P.M) return;
   const size_t ld = (size_t)P.ld;
   const int S = P.S;
-  const double dt = (double)P.dt;
+  const double dt = P.dt64;
   const double inv_m = 1.0 / (double)mass[m];
-  const double a21 = -(double)P.kp * dt * inv_m, dtm = dt * inv_m;
+  const double a21 = -P.kp64 * dt * inv_m, dtm = dt * inv_m;
   const bool compl22 = (a22_axes == 3);            // the generators' table holds 1 - a22 (see a22_value)
   double px = 0.0, vx = 0.0, py = 0.0, vy = 0.0;   // d x_t (t = 0)
   double best = -INFINITY;
@@ -436,13 +447,210 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
   arg_out[m] = best_idx;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Table-free form of the drone oracle ("rollout" form).  rows(u) = g(u_k) + grad g(u_k) . (u - u_k) needs, per sample,
+// the rollout at the linearization point u_k; instead of reading what a linearize kernel stored of it in fp32 (A22, W,
+// g: 44 S bytes per sample, each number carrying 6e-8 of ITS magnitude -- 6e-6 absolute on rows with |g| ~ 1e2, which
+// is what an SCP subproblem with an O(1) step saw as 1e-5 in u), the oracle RE-RUNS that rollout in fp64 from the
+// samples themselves (noise of the two horizontal axes, mass, Q: 8 S + 40 bytes per sample) while it propagates the
+// response to x = u - u_k.  5 x less HBM traffic than the tables, and no stored intermediate at all: what is left of the
+// fp32 device path in the rows is the rounding of its INPUTS.  u_k and x are doubles ([S][3]).
+__global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
+    rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
+    const float* __restrict__ Qsym, const double* __restrict__ xs, float* __restrict__ m_out,
+    int* __restrict__ arg_out) {
+  const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  if (m >= P.M) return;
+  const size_t ld = (size_t)P.ld;
+  const int S = P.S;
+  const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
+  const double inv_m = 1.0 / (double)mass[m];
+  const double a21 = -kp * dt * inv_m, dtm = dt * inv_m, cn = sqrt(dt) * P.beta64 * inv_m;
+  double q00[3], qs[3], q11[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    q00[j] = (double)Qsym[(size_t)(j * 3 + 0) * ld + m];
+    qs[j] = (double)Qsym[(size_t)(j * 3 + 1) * ld + m];
+    q11[j] = (double)Qsym[(size_t)(j * 3 + 2) * ld + m];
+  }
+  double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
+  double dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};
+  double best = -INFINITY;
+  int best_idx = 0;
+  constexpr int TB = 8;   // noise of 8 steps in flight before their dependent steps
+  for (int t0 = 0; t0 < S; t0 += TB) {
+    float xi[TB][2];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = (t0 + i < S) ? t0 + i : S - 1;
+      xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
+      xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = t0 + i;
+      if (t < S) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const double a22 = 1.0 - dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m;   // at the state BEFORE the step
+          const double ndp = dp[a] + dt * dv[a];
+          dv[a] = a21 * dp[a] + a22 * dv[a] + dtm * xs[t * 3 + a];
+          dp[a] = ndp;
+          const double u = uk[t * 3 + a];
+          const double acc = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
+          const double pn = p[a] + dt * v[a];
+          v[a] = v[a] + dt * acc + cn * (double)xi[i][a];
+          p[a] = pn;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double dx = p[0] - P.obs_xy64[j][0], dy = p[1] - P.obs_xy64[j][1];
+          const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
+          const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
+          const double val = gj + wx * dp[0] + wy * dp[1];
+          const int r = j * S + t;
+          if (val > best || (val == best && r < best_idx)) {   // smallest row index among equal values
+            best = val;
+            best_idx = r;
+          }
+        }
+      }
+    }
+  }
+  m_out[m] = (float)best;
+  arg_out[m] = best_idx;
+}
+
+// The cut of the rollout form: the tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
+// rollout in fp64 up to their own t*, leaving e22 = 1 - a22 of both axes in LDS ([S][2][64] floats: exact to 1e-10 of
+// a22), pick up W and g of their arg-max row on the way, and then run the adjoint sweep from t* down, exactly as
+// drone_tail_rows_implicit_kernel does from its table.  Output layout of tail_rows_batch_kernel (offset sum = sum w g).
+__global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
+    rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
+    const float* __restrict__ Qsym, const float* __restrict__ m_base, const int* __restrict__ arg_base,
+    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
+    double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char trr_lds[];
+  const int S = P.S;
+  const long M = P.M, ld = P.ld;
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  double* acc = reinterpret_cast<double*>(trr_lds);                   // [nc] column sums of the block
+  float* E = reinterpret_cast<float*>(acc + nc);                      // [S][2][64] e22 of the current chunk
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots ? slots[kk] : 0;
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  float tstar, lambda;
+  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w0f = 0.0f;
+  int t0 = 0, r0 = 0;
+  {
+    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+    if (m0 < M) {
+      w0f = tail_weight(mvals[m0], tstar, lambda);
+      const int a = arg[m0];
+      r0 = a / S;
+      t0 = a - r0 * S;
+    }
+  }
+  TailLane unused;
+  TailLists lists;
+  const int n_tail = compact_tail(w0f, t0, r0, (long)blockIdx.x * RATO_BLOCK, M, unused, &lists);
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) acc[i] = 0.0;
+  __syncthreads();
+  if (wave == 0) {
+    const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
+    for (int c0 = 0; c0 < n_tail; c0 += RATO_WAVE) {   // chunks of 64 tail samples, in sample order
+      const bool on = c0 + lane < n_tail;
+      const long m = on ? (long)blockIdx.x * RATO_BLOCK + lists.src[c0 + lane] : 0;
+      const double w = on ? (double)lists.w[c0 + lane] : 0.0;
+      const int tr = on ? lists.tr[c0 + lane] : 0;
+      const int ts = tr & 0xfffff, rs = tr >> 20;
+      const double inv_m = 1.0 / (double)mass[m];
+      const double a21 = -kp * dt * inv_m, dtm = dt * inv_m, cn = sqrt(dt) * P.beta64 * inv_m;
+      const double q00 = (double)Qsym[(size_t)(rs * 3 + 0) * ld + m], qss = (double)Qsym[(size_t)(rs * 3 + 1) * ld + m],
+                   q11 = (double)Qsym[(size_t)(rs * 3 + 2) * ld + m];
+      double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
+      double wx = 0.0, wy = 0.0, gval = 0.0;
+      int t_hi = 0;   // wave-uniform: the forward pass only has to reach the largest t* of the chunk
+      {
+        int tm = on ? ts : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
+        t_hi = __builtin_amdgcn_readfirstlane(tm);
+      }
+      constexpr int TB = 8;
+      for (int tb = 0; tb <= t_hi; tb += TB) {
+        float xi[TB][2];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = (tb + i <= t_hi) ? tb + i : t_hi;
+          xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
+          xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
+        }
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = tb + i;
+          if (t <= t_hi) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
+              E[(t * 2 + a) * RATO_WAVE + lane] = e22;
+              const double u = uk[t * 3 + a];
+              const double ac = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
+              const double pn = p[a] + dt * v[a];
+              v[a] = v[a] + dt * ac + cn * (double)xi[i][a];
+              p[a] = pn;
+            }
+            if (on && t == ts) {   // the arg-max row of this sample: g and grad_p g at p_{t*+1}
+              const double dx = p[0] - P.obs_xy64[rs][0], dy = p[1] - P.obs_xy64[rs][1];
+              gval = 1.0 - (q00 * dx * dx + qss * dx * dy + q11 * dy * dy);
+              wx = -(2.0 * q00 * dx + qss * dy);
+              wy = -(qss * dx + 2.0 * q11 * dy);
+            }
+          }
+        }
+      }
+      // adjoint sweep: mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
+      const double w0 = w * wx * dtm, w1 = w * wy * dtm;
+      double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
+      for (int k = t_hi; k >= 1; --k) {   // wave-uniform
+        const bool in = on && k <= ts;
+        if (in && k == ts) {
+          m0x = 1.0; m1x = 0.0; m0y = 1.0; m1y = 0.0;
+        }
+        double cx = 0.0, cy = 0.0;
+        if (in) {
+          const double ax = 1.0 - (double)E[(k * 2 + 0) * RATO_WAVE + lane], ay = 1.0 - (double)E[(k * 2 + 1) * RATO_WAVE + lane];
+          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * ax;
+          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * ay;
+          m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
+          cx = w0 * m1x;
+          cy = w1 * m1y;
+        }
+        const double s0 = rato::wave_sum_dpp(cx);
+        const double s1 = rato::wave_sum_dpp(cy);
+        if (lane == 0) {
+          acc[(k - 1) * 2 + 0] += s0;
+          acc[(k - 1) * 2 + 1] += s1;
+        }
+      }
+      const double sg = rato::wave_sum_dpp(w * gval);
+      if (lane == 0) acc[nw] += sg;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
+}
+
 }  // namespace
 
 extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
                                           int32_t a22_axes, const float* W, const float* base, double sign,
                                           const double* xs, float* m_out, int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !base || !xs ||
+  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !mass || !A22 || !W || !base || !xs ||
       !m_out || !arg_out || (a22_axes != 2 && a22_axes != 3) || (sign != 1.0 && sign != -1.0))
     return RATO_EINVAL;
   dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
@@ -484,7 +692,7 @@ extern "C" int rato_drone_tail_rows_implicit(const rato_drone_params* p, const f
                                              int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
                                              double* part, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!p || p->M <= 0 || p->S < 2 || p->ld < p->M || !(p->dt > 0.0f) || !mass || !A22 || !W || !base || !m_base ||
+  if (!p || p->M <= 0 || p->S < 2 || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !mass || !A22 || !W || !base || !m_base ||
       !arg_base || !stats_base || !part || K < 1 || K > 65535 || (!slots && K != 1) || stats_stride < 11 ||
       (a22_axes != 2 && a22_axes != 3))
     return RATO_EINVAL;
@@ -513,6 +721,47 @@ extern "C" int rato_saa_tail_rows_batch(const float* G, const float* W, int64_t 
   else
     hipLaunchKernelGGL(tail_rows_batch_kernel<1>, grid, block, lds, st, G, W, (long)ld, tile, S, (long)M, base, m_base,
                        arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_drone_rowmax_rollout(const rato_drone_params* p, const double* uk, const float* dW,
+                                         const float* mass, const float* Qsym, const double* xs, float* m_out,
+                                         int32_t* arg_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !uk || !dW || !mass || !Qsym || !xs || !m_out ||
+      !arg_out)
+    return RATO_EINVAL;
+  dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  hipLaunchKernelGGL(drone_rowmax_rollout_kernel, grid, block, 0, rato::as_stream(stream), *p, uk, dW, mass, Qsym, xs,
+                     m_out, arg_out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const double* uk, const float* dW,
+                                            const float* mass, const float* Qsym, const float* m_base,
+                                            const int32_t* arg_base, const double* stats_base, int64_t stats_stride,
+                                            const int32_t* slots, int32_t K, double alphaM, double* part,
+                                            void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!p || p->M <= 0 || p->S < 2 || p->S >= (1 << 20) || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !uk || !dW || !mass ||
+      !Qsym || !m_base || !arg_base || !stats_base || !part || K < 1 || K > 65535 || (!slots && K != 1) ||
+      stats_stride < 11)
+    return RATO_EINVAL;
+  const size_t lds = (size_t)(2 * (p->S - 1) + 1) * sizeof(double) + (size_t)p->S * 2 * RATO_WAVE * sizeof(float);
+  if (lds + 4096 > 160 * 1024) return RATO_EINVAL;   // S <= 300 (4 KB: the static lists of the tail compaction)
+  static rato::DynamicLdsLimit lds_limit;
+  {
+    const hipError_t e = lds_limit.ensure(lds, [](size_t bytes) {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(drone_tail_rows_rollout_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    });
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
+  hipLaunchKernelGGL(drone_tail_rows_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, mass, Qsym,
+                     m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

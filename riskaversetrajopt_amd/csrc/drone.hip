@@ -177,10 +177,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   const size_t m = valid ? m_raw : M - 1;
   const int S = P.S;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double dt = (double)P.dt, kp = (double)P.kp, kd = (double)P.kd, drag = (double)P.drag;
+  const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;   // the fp64 constants (rato_saa.h)
   const double inv_m = 1.0 / (double)mass[m];
   const double a21 = -kp * dt * inv_m, dtm = dt * inv_m;
-  const double cn = sqrt(dt) * (double)P.beta * inv_m;   // sqrt(dt) * (beta/m): drone_risk.py:136,151
+  const double cn = sqrt(dt) * P.beta64 * inv_m;   // sqrt(dt) * (beta/m): drone_risk.py:136,151
   double q00[NOBS], qs[NOBS], q11[NOBS];
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   double p[3], v[3], dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};   // state | response of the linearized x, y axes to u_bar
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    p[a] = (double)P.x_init[a];
-    v[a] = (double)P.x_init[3 + a];
+    p[a] = P.x_init64[a];
+    v[a] = P.x_init64[3 + a];
   }
   double zmax = -INFINITY;
   float xi[3];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     }
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
-      const double dx = p[0] - (double)P.obs_xy[j][0], dy = p[1] - (double)P.obs_xy[j][1];
+      const double dx = p[0] - P.obs_xy64[j][0], dy = p[1] - P.obs_xy64[j][1];
       const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
       const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
       zmax = fmax(zmax, gj);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
   }
-  if (Z && valid) Z[m] = (float)(zmax - (double)P.tol);
+  if (Z && valid) Z[m] = (float)(zmax - P.tol64);
   // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
   // (drone_risk.py:271): adjoint from S over the a22 (recomputed from the fp32 table this lane wrote: the consumers of
   // the table see the same numbers)
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const double rp = rato::wave_sum_dpp(valid ? (-(p[a] - (double)P.x_final[a]) + dP[a]) : 0.0);
-    const double rv = rato::wave_sum_dpp(valid ? (-(v[a] - (double)P.x_final[3 + a]) + dV[a]) : 0.0);
+    const double rp = rato::wave_sum_dpp(valid ? (-(p[a] - P.x_final64[a]) + dP[a]) : 0.0);
+    const double rv = rato::wave_sum_dpp(valid ? (-(v[a] - P.x_final64[3 + a]) + dV[a]) : 0.0);
     if (lane == 0) {
       gen_red[(wave * (S + 1) + S) * 6 + a] = rp;
       gen_red[(wave * (S + 1) + S) * 6 + 3 + a] = rv;
@@ -996,6 +996,10 @@ int device_cus() { return g_queue_pool.cus(); }
 bool params_ok(const rato_drone_params* p) {
   return p && p->M > 0 && p->ld >= p->M && p->S > 0 && p->S <= 4096 && p->dt > 0.0f;
 }
+// the entry points that compute in fp64 read the double constants: they must have been filled (consistently)
+bool params64_ok(const rato_drone_params* p) {
+  return p->dt64 > 0.0 && fabs(p->dt64 - (double)p->dt) <= 1e-6 * p->dt64 && fabs(p->kp64 - (double)p->kp) <= 1e-6 * fabs(p->kp64) + 1e-30;
+}
 
 }  // namespace
 
@@ -1089,7 +1093,7 @@ extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const
                                                const float* mass, const float* Qsym, float* A22, float* W,
                                                float* g_up, float* Z, float* part, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!params_ok(p) || !us || !dW || !mass || !Qsym || !A22 || !W || !g_up || !part) return RATO_EINVAL;
+  if (!params_ok(p) || !params64_ok(p) || !us || !dW || !mass || !Qsym || !A22 || !W || !g_up || !part) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
   const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(double);
   if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 340

@@ -84,6 +84,9 @@ class CvarCutSolver:
         # drone: (rato_drone_params, mass, A22, a22_axes) -> Jacobian-free evaluation of m(u); with G = None in
         # evaluate / relinearize_kept_cuts the tail rows are regenerated from A22 as well (generators-only mode)
         self.implicit = None
+        # drone, table-free: (rato_drone_params, dW, mass, Qsym) -> the oracle re-runs the rollout at u_lin in fp64 from
+        # the samples (rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout); needs the delta form (u_lin)
+        self.rollout = None
         n = self.nU + 1
         Pu = sp.kron(sp.eye(S), sp.csc_matrix(2.0 * dt * np.asarray(Rcost, dtype=np.float64)))
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
@@ -133,6 +136,7 @@ class CvarCutSolver:
         self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
         self.x_host = torch.zeros((S, n_u), dtype=torch.float64).pin_memory()
         self.x_dev = e(S, n_u, dt=torch.float64)
+        self.uk_dev = e(S, n_u, dt=torch.float64)        # the linearization point, for the rollout form of the oracle
 
     # ---- the two forms of the rows ------------------------------------------
     def _form(self):
@@ -156,7 +160,13 @@ class CvarCutSolver:
         x = np.ascontiguousarray(np.asarray(u_vec, dtype=np.float64) - x0)
         self.x_host.copy_(torch.from_numpy(x.reshape(S, n_u)))
         self.x_dev.copy_(self.x_host, non_blocking=True)
-        if self.implicit is not None:
+        if self.rollout is not None:
+            p, dW, mass, Qsym = self.rollout
+            _lib.check(self.lib.rato_drone_rowmax_rollout(_lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW),
+                                                          _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(self.x_dev),
+                                                          _lib.ptr(m_buf), _lib.ptr(arg_buf), st),
+                       "rato_drone_rowmax_rollout")
+        elif self.implicit is not None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes,
                                                            _lib.ptr(W), _lib.ptr(base), sign, _lib.ptr(self.x_dev),
@@ -169,7 +179,13 @@ class CvarCutSolver:
         m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
         stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
-            if G is None:                # generators-only linearization: rows regenerated from A22
+            if self.rollout is not None:
+                p, dW, mass, Qsym = self.rollout
+                _lib.check(self.lib.rato_drone_tail_rows_rollout(
+                    _lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
+                    _lib.ptr(m_buf), _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alphaM),
+                    _lib.ptr(self.part), st), "rato_drone_tail_rows_rollout")
+            elif G is None:              # generators-only linearization: rows regenerated from A22
                 p, mass, A22, axes = self.implicit
                 _lib.check(self.lib.rato_drone_tail_rows_implicit(
                     _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(base),
@@ -194,6 +210,15 @@ class CvarCutSolver:
         else:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
+
+    def set_linearization_point(self, u_lin):
+        """The controls the current linearization was taken at (delta form of the rows; None: reference form).  For the
+        rollout form of the oracle they also go to the device, in fp64."""
+        self.u_lin = None if u_lin is None else np.asarray(u_lin, dtype=np.float64).reshape(-1).copy()
+        if self.rollout is not None:
+            if self.u_lin is None:
+                raise ValueError("the rollout form of the oracle needs the linearization point (delta form)")
+            self.uk_dev.copy_(torch.from_numpy(self.u_lin.reshape(self.S, self.n_u)), non_blocking=False)
 
     def enqueue_relinearize(self, G, W, tile, base):
         """Stream-ordered half of ``relinearize_kept_cuts`` (launches + the read-back into pinned memory, NO
@@ -226,7 +251,14 @@ class CvarCutSolver:
         self.slots_host[:K] = torch.as_tensor(self.keep, dtype=torch.int32)
         self.slots_dev.copy_(self.slots_host, non_blocking=True)
         part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
-        if G is None:
+        if self.rollout is not None:
+            p, dW, mass, Qsym = self.rollout
+            _lib.check(self.lib.rato_drone_tail_rows_rollout(
+                _lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
+                _lib.ptr(self.ring_m), _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres,
+                _lib.ptr(self.slots_dev), K, float(self.alphaM), _lib.ptr(part), _lib.current_stream()),
+                "rato_drone_tail_rows_rollout")
+        elif G is None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_tail_rows_implicit(
                 _lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes, _lib.ptr(W), _lib.ptr(base),
@@ -258,11 +290,13 @@ class CvarCutSolver:
             return self._solve(*args, **kwargs)
 
     def _solve(self, G, W, tile, base, final_du, final_rhs, *, u_lin=None, with_cvar=True, tol=1e-8, max_cuts=400,
-               verbose=False):
+               verbose=False, final_cut_above=1e-11):
         """``base``: g_up [R][S][ld] of the linearize call (reference form), or -- with ``u_lin`` = the controls the
         linearization was taken at -- its g output (delta form, params.rows_out = 1)."""
         nU, n = self.nU, self.nU + 1
-        self.u_lin = None if u_lin is None else np.asarray(u_lin, dtype=np.float64).reshape(-1).copy()
+        new_lin = None if u_lin is None else np.asarray(u_lin, dtype=np.float64).reshape(-1)
+        if (new_lin is None) != (self.u_lin is None) or (new_lin is not None and not np.array_equal(new_lin, self.u_lin)):
+            self.set_linearization_point(new_lin)       # (solve_reduced has usually done this before enqueueing work)
         F = np.hstack([np.asarray(final_du, dtype=np.float64), np.zeros((np.shape(final_du)[0], 1))])
         f = np.asarray(final_rhs, dtype=np.float64)
         Pd = self.P.toarray()
@@ -296,8 +330,9 @@ class CvarCutSolver:
         in_master = np.zeros(2 * nU, dtype=bool)        # control bounds enter lazily: only the violated ones
         bound_rows = []                                 # (first master row, variable indices, +1 upper / -1 lower)
         lam = np.zeros(0)
-        for it in range(max_cuts + 1):
-            t0 = time.perf_counter()
+        def solve_master():
+            """the master with the control bounds entering lazily -> (z, multipliers)"""
+            nonlocal n_rows
             while True:
                 z, lam = master.solve()
                 hi = (z[:nU] > self.u_max + 1e-9) & ~in_master[:nU]
@@ -316,6 +351,11 @@ class CvarCutSolver:
                     in_master[nU:] |= lo
             if self.world > 1:                      # every rank solved the same master; keep them bit-identical
                 z = rdist.broadcast_from_rank0(z, self.device, self.group)
+            return z, lam
+
+        for it in range(max_cuts + 1):
+            t0 = time.perf_counter()
+            z, lam = solve_master()
             info["master_s"] += time.perf_counter() - t0
             u_vec, s = z[:nU], z[nU]
             if not with_cvar:
@@ -328,6 +368,22 @@ class CvarCutSolver:
             if verbose:
                 print(f"   cut {it:3d}: CVaR {phi:+.6e} slack {s:.3e} violation {viol:+.3e}")
             if viol <= tol:
+                # The loop stops on a violation it can resolve (the device selects the tail on fp32-rounded m: cuts are
+                # exact as cuts, optimal as subgradients only to ~1e-9 at M = 1e5, so tol cannot go far below 1e-8 there).
+                # The cut just evaluated is already paid for: where it still bites (0 < violation <= tol) it joins the
+                # master and the master is solved ONCE more, without another oracle call -- at the subproblem where the
+                # CVaR rows switch on that last cut is worth 2.4e-5 -> 2.4e-7 in u; at convergence the recycled cuts
+                # leave no violation and nothing is added.
+                if viol > final_cut_above and it < max_cuts:
+                    t0 = time.perf_counter()
+                    master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + float(g @ u_vec - phi)])
+                    if slot is not None:
+                        cut_rows.append((n_rows, slot))
+                    n_rows += 1
+                    n_cuts += 1
+                    z, lam = solve_master()
+                    u_vec, s = z[:nU], z[nU]
+                    info["master_s"] += time.perf_counter() - t0
                 break
             if it == max_cuts:
                 status = "maximum cuts reached"

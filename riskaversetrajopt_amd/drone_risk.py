@@ -133,7 +133,8 @@ class Model:
         p.M, p.ld, p.S = M, ld, self.S
         p.rows_out = int(rows_out)      # 1: the linearize kernels write g (not g_up = -g + G u_k) into their g_up buffer
         p.dt, p.beta, p.drag = self.dt, self.beta, self.drag_coefficient
-        p.kp, p.kd = -float(P.feedback_gain[0, 0]), -float(P.feedback_gain[0, 3])
+        p_kp, p_kd = -float(P.feedback_gain[0, 0]), -float(P.feedback_gain[0, 3])
+        p.kp, p.kd = p_kp, p_kd
         p.tol = OSQP_TOL
         for i in range(6):
             p.x_init[i] = float(P.x_init[i])
@@ -141,6 +142,14 @@ class Model:
         for j in range(n_obs):
             p.obs_xy[j][0] = float(P.obs_positions[j, 0])
             p.obs_xy[j][1] = float(P.obs_positions[j, 1])
+        # the same constants in fp64 (the entry points that compute in double precision read these)
+        p.dt64, p.beta64, p.drag64, p.kp64, p.kd64, p.tol64 = self.dt, self.beta, self.drag_coefficient, p_kp, p_kd, OSQP_TOL
+        for i in range(6):
+            p.x_init64[i] = float(P.x_init[i])
+            p.x_final64[i] = float(P.x_final[i])
+        for j in range(n_obs):
+            p.obs_xy64[j][0] = float(P.obs_positions[j, 0])
+            p.obs_xy64[j][1] = float(P.obs_positions[j, 1])
         return p
 
     def _us_device(self, us_mat):
@@ -563,7 +572,7 @@ class Model:
         return self
 
     def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-8, verbose=False, implicit=True, generators_only=None,
-                      delta=True, factored=None):
+                      delta=True, factored=None, rollout=None):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
         planes (cvar_cuts.py): host master QP with 3S+1 variables, device oracle for the CVaR constraint.
@@ -576,7 +585,10 @@ class Model:
         ``generators_only`` (default: same as ``implicit``): do not even write the Jacobian -- linearize to
         (A22, W, g) only and regenerate the few rows the subgradients need (rato_drone_tail_rows_implicit).
         ``delta``: rows as g + G (u - u_k) (the kernels write g) instead of G u - g_up (they write g_up).
-        ``factored`` (with the Jacobian written): its representation, see ``linearize_device``."""
+        ``factored`` (with the Jacobian written): its representation, see ``linearize_device``.
+        ``rollout`` (default: on whenever it applies -- implicit, generators-only, delta form, materialised noise): the
+        oracle reads no linearization table at all; it re-runs the rollout at ``us_mat_p`` in fp64 from the samples
+        (rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout): less traffic, and no fp32 intermediate in the rows."""
         if generators_only is None:
             generators_only = implicit
         if generators_only and not implicit:
@@ -599,10 +611,17 @@ class Model:
                                          group=getattr(self, "_group", None), world=world, mode=self.method,
                                          rhs0=-1e-3 / self.MULTIPLIER)
             self._cut_solver = cs
-        cs.implicit = None
+        cs.implicit = cs.rollout = None
+        dW, mass, Qsym, _ = self._inputs(None)
+        if rollout is None:
+            rollout = bool(implicit and generators_only and delta and dW is not None)
+        if rollout and not (implicit and delta and dW is not None):
+            raise ValueError("the rollout form of the oracle needs implicit=True, delta=True and a materialised dW")
         if implicit:
-            dW, mass, Qsym, _ = self._inputs(None)
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
+        if rollout:
+            cs.rollout = (self._params(M, mass.numel()), dW, mass, Qsym)
+        cs.set_linearization_point(np.asarray(us_mat_p, dtype=np.float64) if delta else None)
         if scp_iter >= 2 and world == 1:
             # the kept cuts against this linearization: launched now, so that the read-back of the sample sums below
             # waits for both (one device round trip instead of two)

@@ -313,7 +313,8 @@ def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
     assert abs(best_at_solution) < 1e-8                  # ... and tight at the point they were generated around
     # a different linearization point, the reference's form of the rows (g_up, no u_k): still valid
     r2 = d.linearize_device(start * 0.9, want_A22=True)
-    cs.u_lin = None
+    cs.rollout = None                                    # (the table-free form has no reference form: tables from here on)
+    cs.set_linearization_point(None)
     rows2, rhs2 = cs.relinearize_kept_cuts(r2["G"], r2["_W"], r2["tile"], r2["_g_up"])
     cs.implicit = (d._params(M, r2["_g_up"].shape[-1]), d._inputs(None)[1], r2["_A22"], 2)
     for trial in range(4):
@@ -486,15 +487,10 @@ def test_reduced_subproblems_device_vs_fp64_host_oracle(system, M, alpha, S):
         us = uh
     print(system, M, "per-subproblem max |du|:", " ".join("%.1e" % v for v in du), "| |dt_risk|:",
           " ".join("%.1e" % v for v in dt_))
-    first = 2 if system == "drone" else 1                # the subproblem where the CVaR rows switch on
-    if S == 20:
-        assert max(du) < 1e-5 and max(dt_) < 1e-5
-    else:
-        # longer horizons: the step from the linearization point is O(1) at the switch-on iteration, and the fp32
-        # STORAGE of g and W (6e-8 of |g| ~ 1e2 = 6e-6 absolute on rows that only become tail rows after that step)
-        # reaches u at ~1e-5 there (measured 2.4e-5 at S = 50 for this seed, 1e-6 ... 4e-6 for others:
-        # tools/parity_sweep.py); every later subproblem is asserted at 1e-5 (measured <= 1.4e-6, 2e-8 at the end)
-        assert du[first] < 1e-4 and max(du[:first] + du[first + 1:]) < 1e-5 and max(dt_) < 1e-5
+    # every subproblem, the one where the CVaR rows switch on included (its step from the linearization point is O(1):
+    # with fp32 linearization tables in the rows it reached 2.4e-5 in u at S = 50; the drone oracle now re-runs the
+    # rollout in fp64 from the samples, and the last evaluated cut joins the master before it returns)
+    assert max(du) < 1e-5 and max(dt_) < 1e-5
 
 
 @pytest.mark.parametrize("system,M,alpha,iters", [("drone", 200, 0.1, 40), ("driving", 200, 0.1, 10)])
@@ -577,3 +573,79 @@ def test_device_reduced_solution_satisfies_the_kkt_conditions_of_the_full_qp(sys
     print(system, M, "KKT residuals (relative to the multiplier scale):", {k: "%.1e" % v for k, v in worst.items()})
     assert worst["primal"] < 1e-7 and worst["stationarity"] < 1e-8 and worst["dual_sign"] < 1e-8 \
         and worst["complementarity"] < 1e-8
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (50, 1000), (2, 5), (125, 70)])
+def test_rollout_form_of_the_oracle(S, M):
+    """rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout (the oracle re-runs the rollout at u_k in fp64 from the
+    samples, no linearization table) against (a) the fp64 oracle's dense rows g + G (u - u_k) on the SAME fp32-rounded
+    samples -- what is left is fp64 rounding -- and (b) the table form (generators + rato_drone_*_implicit)."""
+    import ctypes as C
+    import torch
+    from oracle import drone as od
+    from riskaversetrajopt_amd import _lib, drone_risk, stats
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(0), 'saa', M=M, S=S)
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    DWs, masses, Q = r32(DWs), r32(masses), r32(Q)       # the device holds fp32 samples: give the oracle the same numbers
+    o = od.Model(S, DWs, masses, Q, 'saa', 0.2)
+    d = drone_risk.Model(S, DWs, masses, Q, 'saa', 0.2)
+    uk = graze(S)
+    rng = np.random.RandomState(4)
+    x = 0.3 * rng.randn(S, 3)
+    dev = d.device
+    lib = d._lib
+    dW, mass, Qsym, _ = d._inputs(None)
+    ld = mass.numel()
+    p = d._params(M, ld)
+    uk_d = torch.as_tensor(uk, dtype=torch.float64, device=dev).contiguous()
+    x_d = torch.as_tensor(x, dtype=torch.float64, device=dev).contiguous()
+    m = torch.empty(M, dtype=torch.float32, device=dev)
+    a = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(lib.rato_drone_rowmax_rollout(C.byref(p), _lib.ptr(uk_d), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
+                                             _lib.ptr(x_d), _lib.ptr(m), _lib.ptr(a), _lib.current_stream()), "rowmax_rollout")
+    # (a) fp64 oracle: rows = g + G x
+    _, _, _, gdu_o, gup_o = o.get_all_constraints_coeffs(uk)
+    G = gdu_o.reshape(M, 3 * S, 3 * S)
+    g = -(gup_o.reshape(M, 3 * S) - G @ uk.reshape(-1))
+    rows = g + G @ x.reshape(-1)
+    m_o, a_o = rows.max(axis=1), rows.argmax(axis=1)
+    scale = max(1.0, np.abs(rows).max())
+    md = m.double().cpu().numpy()
+    print(f"S={S} M={M}: rollout oracle vs fp64 rows: max |dm| {np.abs(md - m_o).max():.2e} (rows up to {scale:.1f}; "
+          f"fp32 rounding of the OUTPUT alone is {np.abs(m_o.astype(np.float32).astype(np.float64) - m_o).max():.2e})")
+    # the constants of rato_drone_params are floats (k_p = 0.05f is 1.5e-8 away from 0.05): 1e-9 of the rows' scale on
+    # top of the final rounding of m to fp32
+    assert np.all(np.abs(md - m_o) <= 6.0e-8 * np.abs(m_o) + 2e-9 * scale)             # exact up to the final rounding ...
+    srt = np.sort(rows, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-8 * scale if 3 * S > 1 else np.ones(M, bool)
+    assert np.array_equal(a.cpu().numpy()[clear], a_o[clear])                        # ... and the same arg-max rows
+    if S < 2:
+        return
+    # the cut: tail weights from the statistics of m, sums of the arg-max rows and of their offsets
+    st = torch.zeros(stats.N_STATS, dtype=torch.float64, device=dev)
+    stats.risk_stats_device(m, 0.2, out=st)
+    nblk, nc = (M + 255) // 256, 2 * (S - 1) + 1
+    part = torch.zeros((nblk, nc), dtype=torch.float64, device=dev)
+    _lib.check(lib.rato_drone_tail_rows_rollout(C.byref(p), _lib.ptr(uk_d), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
+                                                _lib.ptr(m), _lib.ptr(a), _lib.ptr(st), stats.N_STATS, None, 1, 0.2 * M,
+                                                _lib.ptr(part), _lib.current_stream()), "tail_rows_rollout")
+    sums = part.sum(0).cpu().numpy()
+    sth = st.cpu().numpy()
+    t, n_gt, n_eq = np.float32(sth[10]), sth[8], sth[9]
+    lam = min(max((0.2 * M - n_gt) / n_eq, 0.0), 1.0) if n_eq > 0 else 0.0
+    m32 = md.astype(np.float32)
+    w = (m32 > t) * 1.0 + (m32 == t) * lam
+    arg_h = a.cpu().numpy()
+    idx = np.arange(M)
+    grad_o = (w[:, None] * G[idx, arg_h]).sum(axis=0).reshape(S, 3)[:S - 1, :2].reshape(-1)
+    off_o = float(w @ g[idx, arg_h])
+    np.testing.assert_allclose(sums[:nc - 1], grad_o, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(grad_o).max()))
+    np.testing.assert_allclose(sums[nc - 1], off_o, rtol=1e-7, atol=1e-8 * float(w @ np.abs(g[idx, arg_h]) + 1.0))
+    # (b) the table form on the same linearization: equal to the rounding of its fp32 tables
+    gen = d.linearize_generators_device(uk, rows_out=1)
+    m_t = torch.empty(M, dtype=torch.float32, device=dev)
+    a_t = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(lib.rato_drone_rowmax_implicit(C.byref(p), _lib.ptr(mass), _lib.ptr(gen["_A22"]), 3, _lib.ptr(gen["_W"]),
+                                              _lib.ptr(gen["_g_up"]), 1.0, _lib.ptr(x_d), _lib.ptr(m_t), _lib.ptr(a_t),
+                                              _lib.current_stream()), "rowmax_implicit")
+    np.testing.assert_allclose(m_t.double().cpu().numpy(), md, rtol=0, atol=2e-6 * scale)
