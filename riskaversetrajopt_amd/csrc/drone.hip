@@ -195,14 +195,21 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     v[a] = P.x_init64[3 + a];
   }
   double zmax = -INFINITY;
-  float xi[3];
+  constexpr int TB = 8;   // the noise of 8 steps (24 loads) in flight before their dependent steps: the kernel is bound by
+                          // load latency (one lane per sample, 50 sequential steps), not by bandwidth or flops
+  for (int t0 = 0; t0 < S; t0 += TB) {
+    float xib[TB][3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) xi[a] = dW[(size_t)a * ld + m];
-  for (int t = 0; t < S; ++t) {
-    float nxt[3];
-    const int tn = (t + 1 < S) ? t + 1 : t;  // prefetch next step's noise
+    for (int i = 0; i < TB; ++i) {
+      const int tt = (t0 + i < S) ? t0 + i : S - 1;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
+      for (int a = 0; a < 3; ++a) xib[i][a] = dW[(size_t)(tt * 3 + a) * ld + m];
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+    const int t = t0 + i;
+    if (t >= S) break;
+    const float* xi = xib[i];
     double a22[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -241,8 +248,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
         g_up[((size_t)j * S + t) * ld + m] = (float)(P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]));
       }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) xi[a] = nxt[a];
+    }   // step t of the batch
   }
   if (Z && valid) Z[m] = (float)(zmax - P.tol64);
   // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
@@ -255,7 +261,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   for (int a = 0; a < 3; ++a) {
     mP0[a] = 1.0; mP1[a] = 0.0; mV0[a] = 0.0; mV1[a] = 1.0; dP[a] = 0.0; dV[a] = 0.0;
   }
-  for (int s2 = S - 1; s2 >= 0; --s2) {
+  for (int sb = S - 1; sb >= 0; sb -= TB) {
+    float e22b[TB][3];   // the table entries of 8 steps in flight (same lane wrote them: program order)
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int k = (sb - i > 0) ? sb - i : 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) e22b[i][a] = A22[((size_t)k * 3 + a) * ld + m];
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+    const int s2 = sb - i;
+    if (s2 < 0) break;
     double eP[3], eV[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -277,12 +294,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     if (s2 > 0) {  // mu_s = mu_{s+1} A_s
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const double a22 = 1.0 - (double)A22[((size_t)s2 * 3 + a) * ld + m];
+        const double a22 = 1.0 - (double)e22b[i][a];
         const double nP0 = mP0[a] + mP1[a] * a21, nP1 = mP0[a] * dt + mP1[a] * a22;
         const double nV0 = mV0[a] + mV1[a] * a21, nV1 = mV0[a] * dt + mV1[a] * a22;
         mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
       }
     }
+    }   // step s2 of the batch
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
