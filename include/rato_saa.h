@@ -499,6 +499,19 @@ int rato_comm_exchange(rato_comm* comm, const void* record, void* all, int64_t r
                        int64_t M_local, double* total, float* Z_all, void* stream);
 int rato_comm_destroy(rato_comm* comm);
 
+/* ----------------------------------------------------- host: the master QP */
+
+/*
+ * HOST function (no device work): Lawson-Hanson non-negative least squares  min |A y - b|, y >= 0  started from a
+ * guess of the passive set, with an incrementally updated QR of the passive columns (csrc/nnls.hip).  It is the inner
+ * solver of the cutting-plane master QP (riskaversetrajopt_amd/dense_qp.py) -- the counterpart of the C solver the
+ * reference hands its subproblem to (osqp, drone_risk.py:433-457).  A: m x n COLUMN-major; passive: n bytes in/out;
+ * y: n doubles out; maxiter <= 0: 3 n + 10.  Returns 1 converged (KKT test of the original algorithm), 0 not, < 0 bad
+ * arguments.
+ */
+int rato_nnls_warm(const double* A, int32_t m, int32_t n, const double* b, uint8_t* passive, double* y,
+                   int32_t maxiter);
+
 /* ------------------------------------------------------------- statistics */
 
 /* Deterministic second stage of the sample mean (drone_risk.py:294-296,

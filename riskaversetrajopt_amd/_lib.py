@@ -66,6 +66,7 @@ SIGNATURES = {
                                            C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_unpack_records": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_float_p, c_float_p,
                                       c_stream]),
+    "rato_nnls_warm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "rato_sum_partials": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_sum_partials_f64": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_count_nonfinite": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_stream]),

@@ -57,7 +57,39 @@ def solve(P, q, A_eq, b_eq, A_in, b_in):
     return x0 + N @ w, lam
 
 
+_NATIVE = []
+
+
+def _native():
+    """librato_saa.so's host-side NNLS (csrc/nnls.hip: the same algorithm with an incrementally updated QR), or None when
+    the library cannot be loaded (then the NumPy version below runs: this module has no device code of its own)."""
+    if not _NATIVE:
+        try:
+            from . import _lib
+            _NATIVE.append(_lib.load().rato_nnls_warm)
+        except Exception:                          # pragma: no cover
+            _NATIVE.append(None)
+    return _NATIVE[0]
+
+
 def nnls_warm(A, b, passive0=None, maxiter=None):
+    """Lawson-Hanson NNLS, warm-started: the native implementation when the library is there, else ``nnls_warm_py``."""
+    fn = _native()
+    if fn is None:
+        return nnls_warm_py(A, b, passive0, maxiter)
+    m, n = A.shape
+    Af = np.asfortranarray(A, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    P = np.zeros(n, dtype=np.uint8)
+    if passive0 is not None and len(passive0):
+        k = min(n, len(passive0))
+        P[:k] = np.asarray(passive0[:k], dtype=bool)
+    y = np.zeros(n)
+    ok = fn(Af.ctypes.data, m, n, bb.ctypes.data, P.ctypes.data, y.ctypes.data, 0 if maxiter is None else int(maxiter))
+    return y, P.astype(bool), ok == 1
+
+
+def nnls_warm_py(A, b, passive0=None, maxiter=None):
     """Lawson-Hanson NNLS  min |A y - b|, y >= 0  started from a guess of the passive (positive) set.
 
     A cutting-plane loop solves a sequence of problems that differ by one column; the active-set method started

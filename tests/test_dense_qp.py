@@ -139,3 +139,33 @@ def test_master_diagonal_hessian_fast_path_equals_general_solver():
         np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-8)
         np.testing.assert_allclose(A_eq @ x, b_eq, atol=1e-9)
         assert np.all(np.vstack(rows) @ x <= np.concatenate(rhs) + 1e-9)
+
+
+def test_native_nnls_matches_scipy_and_the_numpy_version():
+    """rato_nnls_warm (csrc/nnls.hip: Lawson-Hanson with an incrementally updated QR, host code inside librato_saa.so)
+    against scipy.optimize.nnls and the NumPy version it replaces in the master QP, cold and warm-started, incl. nearly
+    dependent columns (consecutive cuts of a converging cutting-plane loop are nearly parallel)."""
+    from scipy.optimize import nnls
+    from riskaversetrajopt_amd import dense_qp
+    assert dense_qp._native() is not None
+    rng = np.random.RandomState(0)
+    for trial in range(120):
+        m, n = rng.randint(3, 160), rng.randint(1, 90)
+        A = rng.randn(m, n)
+        if trial % 3 == 0 and n > 1:
+            A[:, n // 2:] = A[:, :n - n // 2] + 1e-7 * rng.randn(m, n - n // 2)
+        b = rng.randn(m)
+        y0, _ = nnls(A, b, maxiter=50 * n)
+        P0 = (rng.rand(n) < 0.3) if trial % 2 else None
+        y, P, ok = dense_qp.nnls_warm(A, b, P0)
+        yp, Pp, okp = dense_qp.nnls_warm_py(A, b, P0)
+        assert ok and np.all(y >= 0.0) and np.array_equal(P, y > 0.0)
+        r0, r, rp = np.linalg.norm(A @ y0 - b), np.linalg.norm(A @ y - b), np.linalg.norm(A @ yp - b)
+        assert r <= r0 * (1 + 1e-9) + 1e-12 and r <= rp * (1 + 1e-9) + 1e-12
+        if trial % 3 and m >= 2 * n:                            # well conditioned and overdetermined: the minimiser is unique
+            np.testing.assert_allclose(y, y0, rtol=1e-8, atol=1e-10)
+    # KKT of the solution: dual w = A'(b - A y) <= tol on the zero set, = 0 on the passive set
+    A, b = rng.randn(146, 70), rng.randn(146)
+    y, P, ok = dense_qp.nnls_warm(A, b, None)
+    w = A.T @ (b - A @ y)
+    assert ok and np.all(w[~P] <= 1e-9) and np.all(np.abs(w[P]) <= 1e-9)
