@@ -73,9 +73,10 @@ extern "C" {
  * rato_packed_buffer_floats), rato_sums_and_risk_stats; 7: fp64 CVaR-cut oracle -- rato_saa_rowmax /
  * rato_drone_rowmax_implicit take (base, sign, double xs), the tail-row entry points write double partials
  * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
- * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy).
+ * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
+ * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_nnls_warm).
  * The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 7
+#define RATO_ABI_VERSION 8
 int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
@@ -204,6 +205,9 @@ typedef struct rato_car_params {
   float ego_goal[4];     /* driving.py:217-220 */
   int32_t rows_out;      /* g_up buffer of rato_car_linearize*: 0 = g_up = -g + (grad g).u_k (driving.py:295),
                             1 = g itself (see rato_drone_params.rows_out) */
+  /* the same constants in double precision, for the entry points that compute in fp64 (rato_car_*_rollout) */
+  double dt64, beta64, speed_ped_des64, d_min64;
+  double ego_init64[4];
 } rato_car_params;
 
 /* Scratch floats needed by the driving entry points for the shared ego
@@ -404,6 +408,21 @@ int rato_drone_tail_rows_rollout(const rato_drone_params* p, const double* uk, c
                                  const float* Qsym, const float* m_base, const int32_t* arg_base,
                                  const double* stats_base, int64_t stats_stride, const int32_t* slots, int32_t K,
                                  double alphaM, double* part, void* stream);
+
+/*
+ * The same for the driving problem (R = 1 row per step: g_t = -(|p_ego(t+1) - p_ped(t+1)| - d_min), driving.py:223-230,
+ * :260-313).  The ego trajectory at u_k, its tangent along xs and the tables of the adjoint are sample independent: every
+ * workgroup folds them in fp64 from uk / xs (doubles [S][2]); the pedestrian is re-rolled per sample from dW [S][2][M],
+ * x0_ped [4][M], w_speed [M], w_rep [M] (8 S + 24 bytes per sample against the 6240 of the packed Jacobian at S = 40).
+ * m_out / arg_out, part layout and reduction as above (2(S-1) gradient sums: u_s enters g_t for s <= t - 1).
+ */
+int rato_car_rowmax_rollout(const rato_car_params* p, const double* uk, const float* dW, const float* x0_ped,
+                            const float* w_speed, const float* w_rep, const double* xs, float* m_out,
+                            int32_t* arg_out, void* stream);
+int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const float* dW, const float* x0_ped,
+                               const float* w_speed, const float* w_rep, const float* m_base, const int32_t* arg_base,
+                               const double* stats_base, int64_t stats_stride, const int32_t* slots, int32_t K,
+                               double alphaM, double* part, void* stream);
 
 /* ------------------------------------------------------------ device sampler */
 

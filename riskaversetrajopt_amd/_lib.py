@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 7              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 8              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -25,7 +25,9 @@ class DroneParams(C.Structure):
 class CarParams(C.Structure):
     _fields_ = [("M", C.c_int32), ("S", C.c_int32), ("dt", C.c_float), ("beta", C.c_float),
                 ("speed_ped_des", C.c_float), ("d_min", C.c_float), ("tol", C.c_float),
-                ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32)]
+                ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32),   # 16 words
+                ("dt64", C.c_double), ("beta64", C.c_double), ("speed_ped_des64", C.c_double), ("d_min64", C.c_double),
+                ("ego_init64", C.c_double * 4)]
 
 
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
@@ -48,6 +50,9 @@ SIGNATURES = {
     "rato_drone_rowmax_rollout": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 + [c_stream]),
     "rato_drone_tail_rows_rollout": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 7 +
                                      [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_car_rowmax_rollout": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 8 + [c_stream]),
+    "rato_car_tail_rows_rollout": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 8 +
+                                   [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

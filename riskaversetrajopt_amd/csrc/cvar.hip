@@ -644,6 +644,288 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Table-free form of the DRIVING oracle (R = 1: g_t = -(|e_{t+1} - q_{t+1}| - d_min), e = ego position, q = pedestrian
+// position; driving.py:145-236, :260-313).  Everything about the ego is sample independent (its state carries no noise:
+// driving.py:196-203 puts the diffusion on the pedestrian's velocity only), so every workgroup first folds, in fp64,
+//   the ego trajectory at u_k                       v, phi:  v_{k+1} = v_k + dt u_{k,0},  phi_{k+1} = phi_k + dt u_{k,1}
+//                                                   e_{k+1} = e_k + dt v_k (cos phi_k, sin phi_k)
+//   TANGENT (rowmax): its derivative along x        de_{k+1} = de_k + dt (dv_k cos - v_k sin dphi_k, dv_k sin + v_k cos dphi_k)
+//   !TANGENT (tail rows): the adjoint's table       C_k = -dt^2 (cos, -v sin | sin, v cos)(phi_k)
+// into LDS (thread t sums the first t terms in the order of the recursion; S + 1 threads have work), then the samples
+// re-run the pedestrian (4 states) in fp64 from their own inputs.
+template <bool TANGENT>
+__device__ __forceinline__ void car_ego64_tables(const rato_car_params& P, const double* __restrict__ uk,
+                                                 const double* __restrict__ xs, double* U /* [S][2] (+ [S][2] xs) */,
+                                                 double* TERM /* [S+1][4] */, double* EGO /* [S+1][2] */,
+                                                 double* AUX /* TANGENT: dEGO [S+1][2]; else C [S][4] */) {
+  const int S = P.S;
+  const double dt = P.dt64;
+  for (int i = threadIdx.x; i < 2 * S; i += blockDim.x) {
+    U[i] = uk[i];
+    if (TANGENT) U[2 * S + i] = xs[i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t <= S; t += blockDim.x) {
+    double v = P.ego_init64[2], ph = P.ego_init64[3], dv = 0.0, dph = 0.0;
+    for (int k = 0; k < t; ++k) {
+      v += dt * U[2 * k + 0];
+      ph += dt * U[2 * k + 1];
+      if (TANGENT) {
+        dv += dt * U[2 * S + 2 * k + 0];
+        dph += dt * U[2 * S + 2 * k + 1];
+      }
+    }
+    double sn, cs;
+    sincos(ph, &sn, &cs);
+    TERM[t * 4 + 0] = dt * v * cs;
+    TERM[t * 4 + 1] = dt * v * sn;
+    if (TANGENT) {
+      TERM[t * 4 + 2] = dt * (dv * cs - v * sn * dph);
+      TERM[t * 4 + 3] = dt * (dv * sn + v * cs * dph);
+    } else if (t < S) {
+      AUX[t * 4 + 0] = -dt * dt * cs;
+      AUX[t * 4 + 1] = dt * dt * v * sn;
+      AUX[t * 4 + 2] = -dt * dt * sn;
+      AUX[t * 4 + 3] = -dt * dt * v * cs;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t <= S; t += blockDim.x) {
+    double x = P.ego_init64[0], y = P.ego_init64[1], dx = 0.0, dy = 0.0;
+    for (int k = 0; k < t; ++k) {
+      x += TERM[k * 4 + 0];
+      y += TERM[k * 4 + 1];
+      if (TANGENT) {
+        dx += TERM[k * 4 + 2];
+        dy += TERM[k * 4 + 3];
+      }
+    }
+    EGO[t * 2 + 0] = x;
+    EGO[t * 2 + 1] = y;
+    if (TANGENT) {
+      AUX[t * 2 + 0] = dx;
+      AUX[t * 2 + 1] = dy;
+    }
+  }
+  __syncthreads();
+}
+
+__host__ __device__ inline size_t car_rollout_ego_doubles(int S) {   // U (uk | xs) + TERM + EGO + AUX
+  return (size_t)4 * S + (size_t)(S + 1) * 4 + (size_t)(S + 1) * 2 + (size_t)(S + 1) * 4;
+}
+
+// m_i(u) = max_t [ g_t + grad g_t . x ],  x = u - u_k: the pedestrian and its tangent along x, one sample per thread.
+//   d = e_t - q_t, n = d / |d|, H = (I - n n') / |d|
+//   F = -w_r n + w_s (v_des - qv_y) (1, 1)                       dF = -w_r H (de_t - dq_t) - w_s dqv_y (1, 1)
+//   q_{t+1} = q_t + dt qv_t,  qv_{t+1} = qv_t + dt F + sqrt(dt) beta dW_t          (same recursion for dq, dqv with dF)
+//   row t = g_t - n_{t+1} . (de_{t+1} - dq_{t+1})
+__global__ __launch_bounds__(RATO_BLOCK) void car_rowmax_rollout_kernel(
+    rato_car_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ x0_ped,
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const double* __restrict__ xs,
+    float* __restrict__ m_out, int* __restrict__ arg_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char crr_lds[];
+  const int S = P.S;
+  double* U = reinterpret_cast<double*>(crr_lds);
+  double* TERM = U + 4 * S;
+  double* EGO = TERM + (size_t)(S + 1) * 4;
+  double* DEGO = EGO + (size_t)(S + 1) * 2;
+  car_ego64_tables<true>(P, uk, xs, U, TERM, EGO, DEGO);
+  const size_t M = (size_t)P.M;
+  const size_t m = (size_t)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  if (m >= M) return;
+  const double dt = P.dt64, w_s = (double)w_speed[m], w_r = (double)w_rep[m], cn = sqrt(dt) * P.beta64;
+  double px = (double)x0_ped[0 * M + m], py = (double)x0_ped[1 * M + m], vx = (double)x0_ped[2 * M + m],
+         vy = (double)x0_ped[3 * M + m];
+  double dqx = 0.0, dqy = 0.0, dvx = 0.0, dvy = 0.0;
+  double best = -INFINITY;
+  int best_idx = 0;
+  // geometry at the current state (carried: the normal of row t - 1 is the normal of step t)
+  double dx = EGO[0] - px, dy = EGO[1] - py;
+  double rinv = 1.0 / sqrt(dx * dx + dy * dy);
+  constexpr int TB = 8;   // noise of 8 steps in flight before their dependent steps
+  for (int t0 = 0; t0 < S; t0 += TB) {
+    float xi[TB][2];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = (t0 + i < S) ? t0 + i : S - 1;
+      xi[i][0] = dW[(size_t)(t * 2 + 0) * M + m];
+      xi[i][1] = dW[(size_t)(t * 2 + 1) * M + m];
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = t0 + i;
+      if (t < S) {
+        const double n0 = dx * rinv, n1 = dy * rinv;
+        const double ddx = DEGO[t * 2 + 0] - dqx, ddy = DEGO[t * 2 + 1] - dqy;
+        const double nd = n0 * ddx + n1 * ddy;
+        const double hx = (ddx - n0 * nd) * rinv, hy = (ddy - n1 * nd) * rinv;   // H (de - dq)
+        const double dcommon = -w_s * dvy;
+        const double dF0 = -w_r * hx + dcommon, dF1 = -w_r * hy + dcommon;
+        const double common = w_s * (P.speed_ped_des64 - vy);
+        const double F0 = -w_r * n0 + common, F1 = -w_r * n1 + common;
+        const double ndqx = dqx + dt * dvx, ndqy = dqy + dt * dvy;
+        dvx += dt * dF0;
+        dvy += dt * dF1;
+        dqx = ndqx;
+        dqy = ndqy;
+        const double npx = px + dt * vx, npy = py + dt * vy;
+        vx += dt * F0 + cn * (double)xi[i][0];
+        vy += dt * F1 + cn * (double)xi[i][1];
+        px = npx;
+        py = npy;
+        dx = EGO[(t + 1) * 2 + 0] - px;
+        dy = EGO[(t + 1) * 2 + 1] - py;
+        const double r2 = dx * dx + dy * dy;
+        rinv = 1.0 / sqrt(r2);
+        const double g = -(r2 * rinv - P.d_min64);
+        const double val = g - rinv * (dx * (DEGO[(t + 1) * 2 + 0] - dqx) + dy * (DEGO[(t + 1) * 2 + 1] - dqy));
+        if (val > best) {   // ascending t: the smallest row index among equal values
+          best = val;
+          best_idx = t;
+        }
+      }
+    }
+  }
+  m_out[m] = (float)best;
+  arg_out[m] = best_idx;
+}
+
+// The cut of the rollout form.  The tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
+// pedestrian in fp64 up to their own t*, leaving K_k = dt w_r H_k (3 numbers; ~1e-3, a correction to the identity, kept
+// as floats: 1e-10 of the step Jacobian) in LDS, pick up g and n of their arg-max row on the way, and run the 8-state
+// adjoint from t* down in the reduced form of car_linearize_rows_kernel (eta_e = -eta_q; E = dt (eta_v, eta_phi) IS the
+// Jacobian entry):      E += q . C_k;   qv' = qv + dt q - dt w_s (qv_x + qv_y) e_y;   q += qv K_k;   column k - 1 = E.
+__global__ __launch_bounds__(RATO_BLOCK) void car_tail_rows_rollout_kernel(
+    rato_car_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ x0_ped,
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const float* __restrict__ m_base,
+    const int* __restrict__ arg_base, const double* __restrict__ stats_base, long stats_stride,
+    const int* __restrict__ slots, double alphaM, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ctr_lds[];
+  const int S = P.S;
+  const long M = P.M;
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  double* U = reinterpret_cast<double*>(ctr_lds);
+  double* TERM = U + 4 * S;
+  double* EGO = TERM + (size_t)(S + 1) * 4;
+  double* C = EGO + (size_t)(S + 1) * 2;
+  double* acc = C + (size_t)(S + 1) * 4;                              // [nc] column sums of the block
+  float* KT = reinterpret_cast<float*>(acc + nc);                     // [S][3][64] K of the current chunk
+  car_ego64_tables<false>(P, uk, nullptr, U, TERM, EGO, C);
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots ? slots[kk] : 0;
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  float tstar, lambda;
+  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w0f = 0.0f;
+  int t0 = 0;
+  {
+    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+    if (m0 < M) {
+      w0f = tail_weight(mvals[m0], tstar, lambda);
+      t0 = arg[m0];
+    }
+  }
+  TailLane unused;
+  TailLists lists;
+  const int n_tail = compact_tail(w0f, t0, 0, (long)blockIdx.x * RATO_BLOCK, M, unused, &lists);
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) acc[i] = 0.0;
+  __syncthreads();
+  if (wave == 0) {
+    const double dt = P.dt64, cn = sqrt(dt) * P.beta64;
+    for (int c0 = 0; c0 < n_tail; c0 += RATO_WAVE) {   // chunks of 64 tail samples, in sample order
+      const bool on = c0 + lane < n_tail;
+      const size_t m = on ? (size_t)((long)blockIdx.x * RATO_BLOCK + lists.src[c0 + lane]) : 0;
+      const double w = on ? (double)lists.w[c0 + lane] : 0.0;
+      const int ts = on ? (lists.tr[c0 + lane] & 0xfffff) : 0;
+      const double w_s = (double)w_speed[m], w_r = (double)w_rep[m], ks = dt * w_s;
+      double px = (double)x0_ped[0 * (size_t)M + m], py = (double)x0_ped[1 * (size_t)M + m],
+             vx = (double)x0_ped[2 * (size_t)M + m], vy = (double)x0_ped[3 * (size_t)M + m];
+      double n0s = 0.0, n1s = 0.0, gval = 0.0;
+      int t_hi = 0;   // wave-uniform: the forward pass only has to reach the largest t* of the chunk
+      {
+        int tm = ts;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
+        t_hi = __builtin_amdgcn_readfirstlane(tm);
+      }
+      double dx = EGO[0] - px, dy = EGO[1] - py;
+      double rinv = 1.0 / sqrt(dx * dx + dy * dy);
+      constexpr int TB = 8;
+      for (int tb = 0; tb <= t_hi; tb += TB) {
+        float xi[TB][2];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = (tb + i <= t_hi) ? tb + i : t_hi;
+          xi[i][0] = dW[(size_t)(t * 2 + 0) * (size_t)M + m];
+          xi[i][1] = dW[(size_t)(t * 2 + 1) * (size_t)M + m];
+        }
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = tb + i;
+          if (t <= t_hi) {
+            const double n0 = dx * rinv, n1 = dy * rinv;
+            const double kr = dt * w_r * rinv;
+            KT[(t * 3 + 0) * RATO_WAVE + lane] = (float)(kr * (1.0 - n0 * n0));
+            KT[(t * 3 + 1) * RATO_WAVE + lane] = (float)(-kr * n0 * n1);
+            KT[(t * 3 + 2) * RATO_WAVE + lane] = (float)(kr * (1.0 - n1 * n1));
+            const double common = w_s * (P.speed_ped_des64 - vy);
+            const double F0 = -w_r * n0 + common, F1 = -w_r * n1 + common;
+            const double npx = px + dt * vx, npy = py + dt * vy;
+            vx += dt * F0 + cn * (double)xi[i][0];
+            vy += dt * F1 + cn * (double)xi[i][1];
+            px = npx;
+            py = npy;
+            dx = EGO[(t + 1) * 2 + 0] - px;
+            dy = EGO[(t + 1) * 2 + 1] - py;
+            const double r2 = dx * dx + dy * dy;
+            rinv = 1.0 / sqrt(r2);
+            if (on && t == ts) {   // the arg-max row of this sample: g and the normal at t* + 1
+              gval = -(r2 * rinv - P.d_min64);
+              n0s = dx * rinv;
+              n1s = dy * rinv;
+            }
+          }
+        }
+      }
+      double qx = 0.0, qy = 0.0, qvx = 0.0, qvy = 0.0, Ex = 0.0, Ey = 0.0;
+      for (int k = t_hi; k >= 1; --k) {   // wave-uniform
+        const bool in = on && k <= ts;
+        if (in && k == ts) {
+          qx = n0s; qy = n1s; qvx = 0.0; qvy = 0.0; Ex = 0.0; Ey = 0.0;
+        }
+        double cx = 0.0, cy = 0.0;
+        if (in) {
+          const double k00 = (double)KT[(k * 3 + 0) * RATO_WAVE + lane], k01 = (double)KT[(k * 3 + 1) * RATO_WAVE + lane],
+                       k11 = (double)KT[(k * 3 + 2) * RATO_WAVE + lane];
+          const double fx = qvx * k00 + qvy * k01, fy = qvx * k01 + qvy * k11;
+          Ex += qx * C[k * 4 + 0] + qy * C[k * 4 + 2];   // uses eta_q BEFORE its update
+          Ey += qx * C[k * 4 + 1] + qy * C[k * 4 + 3];
+          const double nqvx = dt * qx + qvx, nqvy = dt * qy + qvy - ks * (qvx + qvy);
+          qx += fx;
+          qy += fy;
+          qvx = nqvx;
+          qvy = nqvy;
+          cx = w * Ex;
+          cy = w * Ey;
+        }
+        const double s0 = rato::wave_sum_dpp(cx);
+        const double s1 = rato::wave_sum_dpp(cy);
+        if (lane == 0) {
+          acc[(k - 1) * 2 + 0] += s0;
+          acc[(k - 1) * 2 + 1] += s1;
+        }
+      }
+      const double sg = rato::wave_sum_dpp(w * gval);
+      if (lane == 0) acc[nw] += sg;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
+}
+
 }  // namespace
 
 extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
@@ -762,6 +1044,54 @@ extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const do
   dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_tail_rows_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, mass, Qsym,
                      m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+
+namespace {
+bool car_params64_ok(const rato_car_params* p) {
+  return p && p->M > 0 && p->S >= 1 && p->S <= 1024 && p->dt64 > 0.0 && p->d_min64 >= 0.0;
+}
+}  // namespace
+
+extern "C" int rato_car_rowmax_rollout(const rato_car_params* p, const double* uk, const float* dW,
+                                       const float* x0_ped, const float* w_speed, const float* w_rep,
+                                       const double* xs, float* m_out, int32_t* arg_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!car_params64_ok(p) || !uk || !dW || !x0_ped || !w_speed || !w_rep || !xs || !m_out || !arg_out) return RATO_EINVAL;
+  const size_t lds = car_rollout_ego_doubles(p->S) * sizeof(double);
+  if (lds > 64 * 1024) return RATO_EINVAL;
+  dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  hipLaunchKernelGGL(car_rowmax_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, x0_ped, w_speed,
+                     w_rep, xs, m_out, arg_out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const float* dW,
+                                          const float* x0_ped, const float* w_speed, const float* w_rep,
+                                          const float* m_base, const int32_t* arg_base, const double* stats_base,
+                                          int64_t stats_stride, const int32_t* slots, int32_t K, double alphaM,
+                                          double* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!car_params64_ok(p) || p->S < 2 || !uk || !dW || !x0_ped || !w_speed || !w_rep || !m_base || !arg_base ||
+      !stats_base || !part || K < 1 || K > 65535 || (!slots && K != 1) || stats_stride < 11)
+    return RATO_EINVAL;
+  const size_t lds = (car_rollout_ego_doubles(p->S) + (size_t)(2 * (p->S - 1) + 1)) * sizeof(double) +
+                     (size_t)p->S * 3 * RATO_WAVE * sizeof(float);
+  static rato::DynamicLdsLimit limit;
+  if (lds + 4096 > 160 * 1024) return RATO_EINVAL;
+  {
+    const hipError_t e = limit.ensure(lds + 4096, [](size_t bytes) {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(car_tail_rows_rollout_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    });
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
+  hipLaunchKernelGGL(car_tail_rows_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, x0_ped,
+                     w_speed, w_rep, m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -84,9 +84,11 @@ class CvarCutSolver:
         # drone: (rato_drone_params, mass, A22, a22_axes) -> Jacobian-free evaluation of m(u); with G = None in
         # evaluate / relinearize_kept_cuts the tail rows are regenerated from A22 as well (generators-only mode)
         self.implicit = None
-        # drone, table-free: (rato_drone_params, dW, mass, Qsym) -> the oracle re-runs the rollout at u_lin in fp64 from
-        # the samples (rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout); needs the delta form (u_lin)
+        # table-free: ('drone', rato_drone_params, dW, mass, Qsym) / ('driving', rato_car_params, dW, x0_ped, w_speed,
+        # w_rep) -> the oracle re-runs the rollout at u_lin in fp64 from the samples (rato_*_rowmax_rollout /
+        # rato_*_tail_rows_rollout); needs the delta form (u_lin)
         self.rollout = None
+        self.check_finite = False                        # raise RatoNonFiniteError when an oracle call's m values hold NaN/Inf
         n = self.nU + 1
         Pu = sp.kron(sp.eye(S), sp.csc_matrix(2.0 * dt * np.asarray(Rcost, dtype=np.float64)))
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
@@ -161,11 +163,7 @@ class CvarCutSolver:
         self.x_host.copy_(torch.from_numpy(x.reshape(S, n_u)))
         self.x_dev.copy_(self.x_host, non_blocking=True)
         if self.rollout is not None:
-            p, dW, mass, Qsym = self.rollout
-            _lib.check(self.lib.rato_drone_rowmax_rollout(_lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW),
-                                                          _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(self.x_dev),
-                                                          _lib.ptr(m_buf), _lib.ptr(arg_buf), st),
-                       "rato_drone_rowmax_rollout")
+            self._rollout_rowmax(m_buf, arg_buf, st)
         elif self.implicit is not None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_rowmax_implicit(_lib.C.byref(p), _lib.ptr(mass), _lib.ptr(A22), axes,
@@ -180,11 +178,7 @@ class CvarCutSolver:
         stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
             if self.rollout is not None:
-                p, dW, mass, Qsym = self.rollout
-                _lib.check(self.lib.rato_drone_tail_rows_rollout(
-                    _lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
-                    _lib.ptr(m_buf), _lib.ptr(arg_buf), _lib.ptr(res), self.nres, None, 1, float(self.alphaM),
-                    _lib.ptr(self.part), st), "rato_drone_tail_rows_rollout")
+                self._rollout_tail_rows(m_buf, arg_buf, res, None, 1, self.part, st)
             elif G is None:              # generators-only linearization: rows regenerated from A22
                 p, mass, A22, axes = self.implicit
                 _lib.check(self.lib.rato_drone_tail_rows_implicit(
@@ -202,6 +196,8 @@ class CvarCutSolver:
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
         r = self.res_host.numpy()
+        if self.check_finite and not (np.isfinite(r[3]) and np.isfinite(r[4])):      # mean and max of the m values
+            raise _lib.RatoNonFiniteError("CVaR-cut oracle: non-finite constraint values m_i(u) (RATO_ENONFINITE)")
         g = np.zeros(self.nU)
         if S > 1:
             sums = r[stats.N_STATS:] / self.alphaM
@@ -210,6 +206,19 @@ class CvarCutSolver:
         else:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
+
+    def _rollout_rowmax(self, m_buf, arg_buf, st):
+        kind, p, *samples = self.rollout
+        name = {"drone": "rato_drone_rowmax_rollout", "driving": "rato_car_rowmax_rollout"}[kind]
+        _lib.check(getattr(self.lib, name)(_lib.C.byref(p), _lib.ptr(self.uk_dev), *[_lib.ptr(a) for a in samples],
+                                           _lib.ptr(self.x_dev), _lib.ptr(m_buf), _lib.ptr(arg_buf), st), name)
+
+    def _rollout_tail_rows(self, m_base, arg_base, res_base, slots, K, part, st):
+        kind, p, *samples = self.rollout
+        name = {"drone": "rato_drone_tail_rows_rollout", "driving": "rato_car_tail_rows_rollout"}[kind]
+        _lib.check(getattr(self.lib, name)(_lib.C.byref(p), _lib.ptr(self.uk_dev), *[_lib.ptr(a) for a in samples],
+                                           _lib.ptr(m_base), _lib.ptr(arg_base), _lib.ptr(res_base), self.nres, slots, K,
+                                           float(self.alphaM), _lib.ptr(part), st), name)
 
     def set_linearization_point(self, u_lin):
         """The controls the current linearization was taken at (delta form of the rows; None: reference form).  For the
@@ -252,12 +261,8 @@ class CvarCutSolver:
         self.slots_dev.copy_(self.slots_host, non_blocking=True)
         part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
         if self.rollout is not None:
-            p, dW, mass, Qsym = self.rollout
-            _lib.check(self.lib.rato_drone_tail_rows_rollout(
-                _lib.C.byref(p), _lib.ptr(self.uk_dev), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym),
-                _lib.ptr(self.ring_m), _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres,
-                _lib.ptr(self.slots_dev), K, float(self.alphaM), _lib.ptr(part), _lib.current_stream()),
-                "rato_drone_tail_rows_rollout")
+            self._rollout_tail_rows(self.ring_m, self.ring_arg, self.ring_res, _lib.ptr(self.slots_dev), K, part,
+                                    _lib.current_stream())
         elif G is None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_tail_rows_implicit(

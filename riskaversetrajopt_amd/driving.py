@@ -138,6 +138,9 @@ class Model:
         for i in range(4):
             p.ego_init[i] = float(self._ego_init[i])
             p.ego_goal[i] = float(goal[i])
+            p.ego_init64[i] = float(self._ego_init[i])
+        p.dt64, p.beta64 = float(self.dt), float(self.beta)
+        p.speed_ped_des64, p.d_min64 = float(P.speed_ped_des), float(P.min_separation_distance)
         return p
 
     def _us_device(self, us_mat):
@@ -389,15 +392,46 @@ class Model:
         self._cut_solver = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-8, verbose=False, delta=True):
+    def ego_final_rows(self, us_mat):
+        """The final-state rows of the ego in double precision -> (final_du (4, 2S), final_rhs (4,)):  the ego carries no
+        noise, so x_S[0:4] and its control Jacobian are sample independent (the mean of driving.py:311 is a no-op) and
+        O(S^2) numbers -- folded on the host, the way the row kernel's workgroup 0 folds them in fp32.
+        final_rhs = -(x_S - goal) + final_du . u  (driving.py:283-288)."""
+        S, dt = self.S, float(self.dt)
+        us = np.asarray(us_mat, dtype=np.float64).reshape(S, n_u)
+        x0, y0, v0, ph0 = (float(a) for a in self._ego_init)
+        v = v0 + dt * np.concatenate(([0.0], np.cumsum(us[:, 0])))          # v_k, phi_k, k = 0..S
+        ph = ph0 + dt * np.concatenate(([0.0], np.cumsum(us[:, 1])))
+        cs, sn = np.cos(ph[:S]), np.sin(ph[:S])
+        xS = np.array([x0 + dt * np.sum(v[:S] * cs), y0 + dt * np.sum(v[:S] * sn), v[S], ph[S]])
+        # d x_S / d u_{t,0} = dt^2 sum_{k > t} cos phi_k,   d x_S / d u_{t,1} = -dt^2 sum_{k > t} v_k sin phi_k  (y alike)
+        after = lambda a: np.concatenate((np.cumsum(a[::-1])[::-1][1:], [0.0]))
+        E = np.zeros((4, S, n_u))
+        E[0, :, 0], E[0, :, 1] = dt * dt * after(cs), -dt * dt * after(v[:S] * sn)
+        E[1, :, 0], E[1, :, 1] = dt * dt * after(sn), dt * dt * after(v[:S] * cs)
+        E[2, :, 0] = dt
+        E[3, :, 1] = dt
+        E = E.reshape(4, S * n_u)
+        goal = np.concatenate((P.position_ego_goal, P.velocity_ego_goal)).astype(np.float64)
+        return E, -(xS - goal) + E @ us.reshape(-1)
+
+    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-8, verbose=False, delta=True, rollout=None):
         """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
         scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint.
         ``method='baseline'`` (driving.py:320-329): the rows (G_i u)_t <= g_up_{i,t} of every sample as the one
         constraint max_i m_i(u) <= 0.  (At scp_iter 0 the reference's ``[n_x:]`` with n_x = 8 leaves the rows
-        t = 0..3 of sample 0 in its baseline QP; they are inactive at the initial guess and are not kept here.)"""
-        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), rows_out=1 if delta else 0)
-        self._lin_buffers = r
-        M, S = r["M"], self.S
+        t = 0..3 of sample 0 in its baseline QP; they are inactive at the initial guess and are not kept here.)
+
+        ``rollout`` (default: on with the delta form and a materialised dW): NO Jacobian is formed at all.  The cut
+        oracle re-runs the rollout at ``us_mat_p`` in fp64 from the samples (rato_car_rowmax_rollout /
+        rato_car_tail_rows_rollout: 344 bytes per sample at S = 40 instead of the 6240 of the packed Jacobian) and the
+        sample-independent final rows come from ``ego_final_rows``."""
+        dW, x0, ws, wr = self._dW, self._x0, self._ws, self._wr
+        if rollout is None:
+            rollout = bool(delta and dW is not None and self.S >= 2)
+        if rollout and not (delta and dW is not None):
+            raise ValueError("the rollout form of the oracle needs delta=True and a materialised dW")
+        M, S = int(ws.numel()), self.S
         cs = getattr(self, "_cut_solver", None)
         if cs is None:
             cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=M, R=1, alpha=self.alpha,
@@ -406,11 +440,27 @@ class Model:
                                          group=getattr(self, "_group", None), world=getattr(self, "_world", 1),
                                          mode=self.method, rhs0=0.0)
             self._cut_solver = cs
+        u_lin = np.asarray(us_mat_p, dtype=np.float64) if delta else None
+        if rollout:
+            cs.rollout = ("driving", self._params(M), dW, x0, ws, wr)
+            cs.check_finite = self.check_finite          # (no linearization to scan: the oracle's statistics are checked)
+            final_du, final_rhs = self.ego_final_rows(us_mat_p)
+            if self.check_finite and not (np.isfinite(final_du).all() and np.isfinite(final_rhs).all()):
+                raise _lib.RatoNonFiniteError("driving final rows: non-finite values (RATO_ENONFINITE)")
+            if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
+                cs.set_linearization_point(u_lin)
+                cs.enqueue_relinearize(None, None, 0, None)
+            info = cs.solve(None, None, 0, None, final_du, final_rhs, u_lin=u_lin, with_cvar=(scp_iter >= 1), tol=tol,
+                            verbose=verbose)
+            return info["us"], info["t_risk"], info
+        cs.rollout = None
+        r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), rows_out=1 if delta else 0)
+        self._lin_buffers = r
         if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
+            cs.set_linearization_point(u_lin)
             cs.enqueue_relinearize(r["G"], None, r["tile"], r["g_up"])      # one device round trip with the read-backs below
         info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
-                        r["final_rhs"].double().cpu().numpy(),
-                        u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
+                        r["final_rhs"].double().cpu().numpy(), u_lin=u_lin,
                         with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
 

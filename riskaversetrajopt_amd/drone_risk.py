@@ -620,7 +620,7 @@ class Model:
         if implicit:
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
         if rollout:
-            cs.rollout = (self._params(M, mass.numel()), dW, mass, Qsym)
+            cs.rollout = ("drone", self._params(M, mass.numel()), dW, mass, Qsym)
         cs.set_linearization_point(np.asarray(us_mat_p, dtype=np.float64) if delta else None)
         if scp_iter >= 2 and world == 1:
             # the kept cuts against this linearization: launched now, so that the read-back of the sample sums below

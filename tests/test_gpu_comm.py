@@ -69,3 +69,17 @@ def test_nonfinite_status_is_raised_by_the_facade():
     with pytest.raises(_lib.RatoNonFiniteError):                    # the SCP drivers switch the check on
         scp.run_drone_reduced(d, num_scp_iters_max=2)
     assert _lib.RatoNonFiniteError.status == -2
+
+
+def test_nonfinite_status_in_the_table_free_driving_solve():
+    """the table-free reduced solve has no linearization to scan: the oracle's statistics of m are checked instead"""
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import _lib, driving, scp
+    S, M = 20, 300
+    samples = ocar.sample_uncertain_parameters(np.random.RandomState(0), M, 'saa', S)
+    d = driving.Model(M, 'saa', 0.1, S=S, samples=samples)
+    scp.run_driving_reduced(d, num_scp_iters_max=3)                 # finite: no error
+    d._dW[3, 1, 17] = float("nan")
+    d._cut_solver = None
+    with pytest.raises(_lib.RatoNonFiniteError):
+        scp.run_driving_reduced(d, num_scp_iters_max=3)

@@ -649,3 +649,94 @@ def test_rollout_form_of_the_oracle(S, M):
                                               _lib.ptr(gen["_g_up"]), 1.0, _lib.ptr(x_d), _lib.ptr(m_t), _lib.ptr(a_t),
                                               _lib.current_stream()), "rowmax_implicit")
     np.testing.assert_allclose(m_t.double().cpu().numpy(), md, rtol=0, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("S,M", [(20, 300), (40, 1000), (2, 5), (90, 70)])
+def test_driving_rollout_form_of_the_oracle(S, M):
+    """rato_car_rowmax_rollout / rato_car_tail_rows_rollout (ego tables folded per workgroup and the pedestrian re-rolled
+    per sample, all in fp64, no Jacobian) against (a) the fp64 oracle's dense rows g + G (u - u_k) on the SAME
+    fp32-rounded samples and (b) the explicit form (packed Jacobian of the row kernel + rato_saa_rowmax); and the
+    host-folded final rows against the oracle's."""
+    import ctypes as C
+    import torch
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import _lib, driving, stats
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    samples = [r32(a) for a in ocar.sample_uncertain_parameters(np.random.RandomState(0), M, 'saa', S)]
+    alpha = 0.2
+    o = ocar.Model(*samples, method='saa', alpha=alpha)
+    d = driving.Model(M, 'saa', alpha, S=S, samples=samples)
+    t = np.arange(S)[:, None]
+    uk = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * (20.0 / S)
+    x = 0.3 * np.random.RandomState(4).randn(S, 2) * np.array([1.0, 0.05])
+    dev, lib = d.device, d._lib
+    dW, x0, ws, wr = d._dW, d._x0, d._ws, d._wr
+    p = d._params(M)
+    uk_d = torch.as_tensor(uk, dtype=torch.float64, device=dev).contiguous()
+    x_d = torch.as_tensor(x, dtype=torch.float64, device=dev).contiguous()
+    m = torch.empty(M, dtype=torch.float32, device=dev)
+    a = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(lib.rato_car_rowmax_rollout(C.byref(p), _lib.ptr(uk_d), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                                           _lib.ptr(x_d), _lib.ptr(m), _lib.ptr(a), _lib.current_stream()), "rowmax_rollout")
+    fdu_o, flo_o, _, gdu_o, gup_o = o.get_all_constraints_coeffs(uk)
+    G = gdu_o.reshape(M, S, 2 * S)
+    g = -(gup_o.reshape(M, S) - G @ uk.reshape(-1))
+    rows = g + G @ x.reshape(-1)
+    m_o, a_o = rows.max(axis=1), rows.argmax(axis=1)
+    scale = max(1.0, np.abs(rows).max())
+    md = m.double().cpu().numpy()
+    print(f"S={S} M={M}: driving rollout oracle vs fp64 rows: max |dm| {np.abs(md - m_o).max():.2e} (rows up to {scale:.1f}; "
+          f"fp32 rounding of the OUTPUT alone is {np.abs(m_o.astype(np.float32).astype(np.float64) - m_o).max():.2e})")
+    assert np.all(np.abs(md - m_o) <= 6.0e-8 * np.abs(m_o) + 2e-9 * scale)             # exact up to the final rounding ...
+    srt = np.sort(rows, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-8 * scale
+    assert np.array_equal(a.cpu().numpy()[clear], a_o[clear])                        # ... and the same arg-max rows
+    # final rows (sample independent), folded on the host in fp64
+    fdu, frhs = d.ego_final_rows(uk)
+    np.testing.assert_allclose(fdu, fdu_o[0], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(frhs, flo_o[0], rtol=1e-12, atol=1e-12)
+    # the cut
+    st = torch.zeros(stats.N_STATS, dtype=torch.float64, device=dev)
+    stats.risk_stats_device(m, alpha, out=st)
+    nblk, nc = (M + 255) // 256, 2 * (S - 1) + 1
+    part = torch.zeros((nblk, nc), dtype=torch.float64, device=dev)
+    _lib.check(lib.rato_car_tail_rows_rollout(C.byref(p), _lib.ptr(uk_d), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws),
+                                              _lib.ptr(wr), _lib.ptr(m), _lib.ptr(a), _lib.ptr(st), stats.N_STATS, None, 1,
+                                              alpha * M, _lib.ptr(part), _lib.current_stream()), "tail_rows_rollout")
+    sums = part.sum(0).cpu().numpy()
+    sth = st.cpu().numpy()
+    tq, n_gt, n_eq = np.float32(sth[10]), sth[8], sth[9]
+    lam = min(max((alpha * M - n_gt) / n_eq, 0.0), 1.0) if n_eq > 0 else 0.0
+    m32 = md.astype(np.float32)
+    w = (m32 > tq) * 1.0 + (m32 == tq) * lam
+    arg_h = a.cpu().numpy()
+    idx = np.arange(M)
+    grad_full = (w[:, None] * G[idx, arg_h]).sum(axis=0).reshape(S, 2)
+    assert np.all(grad_full[S - 1] == 0.0)                          # u_{S-1} enters no row
+    grad_o = grad_full[:S - 1].reshape(-1)
+    off_o = float(w @ g[idx, arg_h])
+    np.testing.assert_allclose(sums[:nc - 1], grad_o, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(grad_o).max()))
+    np.testing.assert_allclose(sums[nc - 1], off_o, rtol=1e-7, atol=1e-8 * float(w @ np.abs(g[idx, arg_h]) + 1.0))
+    # (b) the explicit form on the same linearization point: equal to the rounding of the fp32 Jacobian
+    r = d.linearize_device(uk, rows_out=1)
+    m_t = torch.empty(M, dtype=torch.float32, device=dev)
+    a_t = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(lib.rato_saa_rowmax(_lib.ptr(r["G"]), None, r["tile"], 1, S, M, M, _lib.ptr(r["g_up"]), 1.0, _lib.ptr(x_d), 2,
+                                   _lib.ptr(m_t), _lib.ptr(a_t), _lib.current_stream()), "rowmax")
+    np.testing.assert_allclose(m_t.double().cpu().numpy(), md, rtol=0, atol=1e-5 * scale)
+
+
+def test_driving_reduced_solve_rollout_equals_explicit():
+    """one subproblem of the driving SCP from the same iterate: table-free oracle against the packed-Jacobian oracle"""
+    o, d = _car(1500, 30, alpha=0.1, seed=3)
+    us = np.zeros((30, 2)) + 1e-2
+    for it in range(3):
+        d._cut_solver = None
+        u_r, t_r, info_r = d.solve_reduced(us, it, rollout=True)
+        d._cut_solver = None
+        u_e, t_e, info_e = d.solve_reduced(us, it, rollout=False)
+        print("iteration %d: |du| %.2e |dt| %.2e cuts %d / %d" % (it, np.abs(u_r - u_e).max(), abs(t_r - t_e),
+                                                                    info_r["cuts"], info_e["cuts"]))
+        np.testing.assert_allclose(u_r, u_e, rtol=0, atol=1e-5)
+        assert abs(t_r - t_e) < 1e-5
+        us = u_r

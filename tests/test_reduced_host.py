@@ -102,3 +102,22 @@ def test_reduced_solution_satisfies_the_kkt_conditions_of_the_full_qp(system, me
             checked += 1
         us = nxt
     assert checked >= 4
+
+
+def test_driving_ego_final_rows_closed_form_equals_the_oracle():
+    """driving.Model.ego_final_rows (the sample-independent final rows of the table-free reduced solve, folded on the
+    host in fp64) against the fp64 oracle's forward sensitivities (driving.py:283-288)."""
+    import types
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving as drv
+    for S in (2, 20, 40):
+        samples = ocar.sample_uncertain_parameters(np.random.RandomState(0), 3, 'saa', S)
+        o = ocar.Model(*samples, method='saa', alpha=0.2)
+        t = np.arange(S)[:, None]
+        uk = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * (20.0 / S)
+        fdu, flo, fup, _, _ = o.get_all_constraints_coeffs(uk)
+        fake = types.SimpleNamespace(S=S, dt=ocar.T / S, _ego_init=ocar.state_init[:4].astype(np.float64))
+        E, rhs = drv.Model.ego_final_rows(fake, uk)
+        np.testing.assert_allclose(E, fdu[0], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(rhs, flo[0], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(fdu[0], fdu[-1])        # the ego carries no noise: the same rows for every sample
