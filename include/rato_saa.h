@@ -58,6 +58,7 @@ extern "C" {
 #define RATO_ENONFINITE (-2) /* a checked output holds NaN/Inf: the reference only prints
                                 "[solve]: Problem infeasible." (drone_risk.py:458-459) and carries on.
                                 Raised by the facades (check_finite=True) from rato_count_nonfinite_acc. */
+#define RATO_EINFEASIBLE (-4) /* rato_master_solve: the rows of the master QP admit no point */
 #define RATO_ENOCOMM (-3)    /* librccl could not be bound at run time (rato_comm_*) */
 #define RATO_EHIP (-1000)    /* RATO_EHIP - hipError_t */
 #define RATO_ERCCL (-2000)   /* RATO_ERCCL - ncclResult_t */
@@ -74,7 +75,8 @@ extern "C" {
  * rato_drone_rowmax_implicit take (base, sign, double xs), the tail-row entry points write double partials
  * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
  * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
- * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_nnls_warm).
+ * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
+ * rato_copy_async, rato_stream_synchronize).
  * The Python binding refuses a library that reports another version. */
 #define RATO_ABI_VERSION 8
 int rato_abi_version(void);
@@ -95,6 +97,11 @@ int rato_device_clock_probe(double* out3, int32_t us, void* stream);
  * them occupy every wave slot of an MI355X.  Used to show that the one-launch statistics, which wait inside the
  * launch for their own workgroups, survive a chip that another stream owns. */
 int rato_device_occupy(int32_t blocks, int64_t us, void* stream);
+
+/* Plumbing for the facades' small transfers inside the SCP loop: one asynchronous copy between device memory and
+ * (pinned) host memory in either direction on `stream` (hipMemcpyDefault), and the matching synchronisation. */
+int rato_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+int rato_stream_synchronize(void* stream);
 
 /* ------------------------------------------------------------------ drone */
 
@@ -358,7 +365,8 @@ int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, co
  * linearization in 12 S numbers per sample and NO Jacobian entries: Phi[t,s,a] = e_0' A_t ... A_{s+1} B is
  * regenerated from A22 by the consumers (rato_drone_rowmax_implicit for G.x, rato_drone_tail_rows_implicit for rows
  * of G).  60 B per sample-step of HBM traffic instead of 245 B; what a reduced SCP iteration needs
- * (Model.solve_reduced).
+ * (Model.solve_reduced).  W and g_up may both be NULL (a caller whose cut oracle re-runs the rollout --
+ * rato_drone_*_rollout -- needs only the sample sums; A22 stays: it is the lane's scratch for the final-state adjoint).
  */
 int rato_drone_linearize_generators(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym,
@@ -423,6 +431,20 @@ int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const
                                const float* w_speed, const float* w_rep, const float* m_base, const int32_t* arg_base,
                                const double* stats_base, int64_t stats_stride, const int32_t* slots, int32_t K,
                                double alphaM, double* part, void* stream);
+
+/*
+ * One oracle round trip of a cutting-plane solve in ONE call (table-free forms; system 0 = drone: s0..s2 = dW, mass,
+ * Qsym, s3 unused; 1 = driving: s0..s3 = dW, x0_ped, w_speed, w_rep):
+ *   x_host [S][n_u] doubles (pinned for an asynchronous copy) -> x_dev;  m_out / arg_out = rato_*_rowmax_rollout;
+ *   res_dev[0..11) = rato_risk_stats(m_out, alpha, thr);  S > 1: part_dev = rato_*_tail_rows_rollout (K = 1, record =
+ *   res_dev, stride 11 + nc), res_dev[11..11+nc) = its column sums, nc = 2(S-1) + 1;  res_dev -> res_host;  the stream
+ *   is SYNCHRONISED before the call returns.  Replaces two copies, four calls and a synchronize of the host loop
+ *   (drone_risk.py:425-469 hands the whole QP to OSQP; here every cut of the reduced subproblem is one such trip).
+ */
+int rato_cut_oracle_rollout(int32_t system, const void* params, const double* uk, const float* s0, const float* s1,
+                            const float* s2, const float* s3, const double* x_host, double* x_dev, float* m_out,
+                            int32_t* arg_out, double alpha, float thr, double alphaM, void* workspace,
+                            size_t workspace_bytes, double* res_dev, double* part_dev, double* res_host, void* stream);
 
 /* ------------------------------------------------------------ device sampler */
 
@@ -530,6 +552,23 @@ int rato_comm_destroy(rato_comm* comm);
  */
 int rato_nnls_warm(const double* A, int32_t m, int32_t n, const double* b, uint8_t* passive, double* y,
                    int32_t maxiter);
+
+/*
+ * The master QP of the cutting-plane loop as an object that lives across the cuts of one SCP subproblem (host code,
+ * csrc/master.hip):   min 1/2 z'Pz + q'z   s.t.  A_eq z = b_eq,  rows_j . z <= rhs_j  (rows appended one at a time),
+ * P = diag(p_diag) > 0, A_eq (m_eq x n, row-major) of full row rank (RATO_EINVAL otherwise: the Python facade then takes
+ * its general NumPy path).  Equalities are eliminated and the Hessian whitened once, in O(n m_eq^2); a row costs
+ * O(n m_eq); a solve is one warm-started rato_nnls_warm on the rows so far.
+ *   rato_master_solve -> 1: z (n doubles) and lam (one multiplier >= 0 per row);  0: NNLS did not converge;
+ *                        RATO_EINFEASIBLE.
+ */
+typedef struct rato_master rato_master;
+int rato_master_create(rato_master** out, int32_t n, const double* p_diag, const double* q, int32_t m_eq,
+                       const double* A_eq, const double* b_eq);
+int rato_master_add_rows(rato_master* m, int32_t k, const double* A /* k x n, row-major */, const double* b);
+int rato_master_solve(rato_master* m, double* z, double* lam);
+int32_t rato_master_rows(const rato_master* m);
+void rato_master_destroy(rato_master* m);
 
 /* ------------------------------------------------------------- statistics */
 

@@ -53,6 +53,16 @@ SIGNATURES = {
     "rato_car_rowmax_rollout": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 8 + [c_stream]),
     "rato_car_tail_rows_rollout": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 8 +
                                    [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
+    "rato_cut_oracle_rollout": (C.c_int, [C.c_int32] + [c_float_p] * 10 + [C.c_double, C.c_float, C.c_double, C.c_void_p,
+                                          C.c_size_t, c_float_p, c_float_p, c_float_p, c_stream]),
+    "rato_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
+    "rato_stream_synchronize": (C.c_int, [c_stream]),
+    "rato_master_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "rato_master_add_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rato_master_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rato_master_rows": (C.c_int32, [C.c_void_p]),
+    "rato_master_destroy": (None, [C.c_void_p]),
     "rato_drone_obstacle_constraints": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 3 + [c_stream]),
     "rato_car_ego_scratch_floats": (C.c_size_t, [C.c_int32]),
     "rato_car_linearize_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -164,8 +174,27 @@ def ptr(t):
 
 
 def current_stream():
+    """the current torch stream of the current device as a C pointer (the raw getter: torch.cuda.current_stream()
+    builds a Stream object through three layers of device-index helpers, ~10 us a call)"""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def copy_async(dst, src, stream=None):
+    """dst <- src (torch tensors: device or host -- pinned for the copy to be asynchronous --, contiguous, same byte
+    size) on the current stream (rato_copy_async)."""
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size() or not (dst.is_contiguous() and src.is_contiguous()):
+        raise RatoError("copy_async needs contiguous tensors of the same byte size")
+    check(load().rato_copy_async(dst.data_ptr(), src.data_ptr(), nbytes, current_stream() if stream is None else stream),
+          "rato_copy_async")
+
+
+def synchronize(stream=None):
+    check(load().rato_stream_synchronize(current_stream() if stream is None else stream), "rato_stream_synchronize")
 
 
 def require_f32_device(t, name):

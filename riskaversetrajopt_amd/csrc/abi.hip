@@ -47,6 +47,22 @@ extern "C" int rato_device_occupy(int32_t blocks, int64_t us, void* stream) {
   return RATO_OK;
 }
 
+// Plumbing: one asynchronous copy between any two of (device memory, pinned host memory) on the caller's stream.  The
+// facades' small read-backs / uploads inside the SCP loop go through this instead of torch.Tensor.copy_, whose dispatch
+// costs ~40 us per call on this stack -- more than the copies and several of the kernels they sit between.
+extern "C" int rato_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!dst || !src) return RATO_EINVAL;
+  if (bytes == 0) return RATO_OK;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, rato::as_stream(stream));
+  return e == hipSuccess ? RATO_OK : RATO_EHIP - (int)e;
+}
+
+extern "C" int rato_stream_synchronize(void* stream) {
+  const hipError_t e = hipStreamSynchronize(rato::as_stream(stream));
+  return e == hipSuccess ? RATO_OK : RATO_EHIP - (int)e;
+}
+
 extern "C" int rato_device_clock_probe(double* out3, int32_t us, void* stream) {
   RATO_CLEAR_ERROR();
   if (!out3 || us < 1 || us > 100000) return RATO_EINVAL;

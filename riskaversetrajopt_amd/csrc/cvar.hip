@@ -477,15 +477,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   double dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};
   double best = -INFINITY;
   int best_idx = 0;
-  constexpr int TB = 8;   // noise of 8 steps in flight before their dependent steps
-  for (int t0 = 0; t0 < S; t0 += TB) {
-    float xi[TB][2];
+  // The kernel is bound by load latency (1.5 waves per SIMD at M = 1e5): the noise of 8 steps is requested as one batch,
+  // and the NEXT batch is already in flight while a batch is consumed (two register buffers, the loop unrolled by two).
+  constexpr int TB = 8;
+  auto load = [&](float (&xi)[TB][2], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = (t0 + i < S) ? t0 + i : S - 1;
       xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
       xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
     }
+  };
+  auto steps = [&](const float (&xi)[TB][2], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = t0 + i;
@@ -516,6 +519,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
         }
       }
     }
+  };
+  float xa[TB][2], xb[TB][2];
+  load(xa, 0);
+  for (int t0 = 0; t0 < S; t0 += 2 * TB) {
+    load(xb, t0 + TB);
+    steps(xa, t0);
+    load(xa, t0 + 2 * TB);
+    steps(xb, t0 + TB);
   }
   m_out[m] = (float)best;
   arg_out[m] = best_idx;
@@ -580,15 +591,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
         for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
         t_hi = __builtin_amdgcn_readfirstlane(tm);
       }
-      constexpr int TB = 8;
-      for (int tb = 0; tb <= t_hi; tb += TB) {
-        float xi[TB][2];
+      constexpr int TB = 8;   // noise in batches of 8 steps, the next batch in flight while one is consumed
+      auto load = [&](float (&xi)[TB][2], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = (tb + i <= t_hi) ? tb + i : t_hi;
           xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
           xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
         }
+      };
+      auto steps = [&](const float (&xi)[TB][2], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = tb + i;
@@ -610,6 +622,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
               wy = -(qss * dx + 2.0 * q11 * dy);
             }
           }
+        }
+      };
+      {
+        float xa[TB][2], xb[TB][2];
+        load(xa, 0);
+        for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
+          load(xb, tb + TB);
+          steps(xa, tb);
+          load(xa, tb + 2 * TB);
+          steps(xb, tb + TB);
         }
       }
       // adjoint sweep: mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
@@ -740,18 +762,20 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_rowmax_rollout_kernel(
   double dqx = 0.0, dqy = 0.0, dvx = 0.0, dvy = 0.0;
   double best = -INFINITY;
   int best_idx = 0;
+  bool bad = false;
   // geometry at the current state (carried: the normal of row t - 1 is the normal of step t)
   double dx = EGO[0] - px, dy = EGO[1] - py;
   double rinv = 1.0 / sqrt(dx * dx + dy * dy);
-  constexpr int TB = 8;   // noise of 8 steps in flight before their dependent steps
-  for (int t0 = 0; t0 < S; t0 += TB) {
-    float xi[TB][2];
+  constexpr int TB = 8;   // noise: batches of 8 steps, the next batch in flight while one is consumed (see the drone kernel)
+  auto load = [&](float (&xi)[TB][2], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = (t0 + i < S) ? t0 + i : S - 1;
       xi[i][0] = dW[(size_t)(t * 2 + 0) * M + m];
       xi[i][1] = dW[(size_t)(t * 2 + 1) * M + m];
     }
+  };
+  auto steps = [&](const float (&xi)[TB][2], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = t0 + i;
@@ -780,14 +804,25 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_rowmax_rollout_kernel(
         rinv = 1.0 / sqrt(r2);
         const double g = -(r2 * rinv - P.d_min64);
         const double val = g - rinv * (dx * (DEGO[(t + 1) * 2 + 0] - dqx) + dy * (DEGO[(t + 1) * 2 + 1] - dqy));
+        bad = bad || (val != val);
         if (val > best) {   // ascending t: the smallest row index among equal values
           best = val;
           best_idx = t;
         }
       }
     }
+  };
+  float xa[TB][2], xb[TB][2];
+  load(xa, 0);
+  for (int t0 = 0; t0 < S; t0 += 2 * TB) {
+    load(xb, t0 + TB);
+    steps(xa, t0);
+    load(xa, t0 + 2 * TB);
+    steps(xb, t0 + TB);
   }
-  m_out[m] = (float)best;
+  // a NaN row loses every comparison: it is reported, not dropped (the facades check the statistics of m; there is
+  // no stored linearization to scan in this form)
+  m_out[m] = bad ? __builtin_nanf("") : (float)best;
   arg_out[m] = best_idx;
 }
 
@@ -853,15 +888,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_tail_rows_rollout_kernel(
       }
       double dx = EGO[0] - px, dy = EGO[1] - py;
       double rinv = 1.0 / sqrt(dx * dx + dy * dy);
-      constexpr int TB = 8;
-      for (int tb = 0; tb <= t_hi; tb += TB) {
-        float xi[TB][2];
+      constexpr int TB = 8;   // noise in batches of 8 steps, the next batch in flight while one is consumed
+      auto load = [&](float (&xi)[TB][2], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = (tb + i <= t_hi) ? tb + i : t_hi;
           xi[i][0] = dW[(size_t)(t * 2 + 0) * (size_t)M + m];
           xi[i][1] = dW[(size_t)(t * 2 + 1) * (size_t)M + m];
         }
+      };
+      auto steps = [&](const float (&xi)[TB][2], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = tb + i;
@@ -888,6 +924,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_tail_rows_rollout_kernel(
               n1s = dy * rinv;
             }
           }
+        }
+      };
+      {
+        float xa[TB][2], xb[TB][2];
+        load(xa, 0);
+        for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
+          load(xb, tb + TB);
+          steps(xa, tb);
+          load(xa, tb + 2 * TB);
+          steps(xb, tb + TB);
         }
       }
       double qx = 0.0, qy = 0.0, qvx = 0.0, qvy = 0.0, Ex = 0.0, Ey = 0.0;
@@ -1095,3 +1141,55 @@ extern "C" int rato_car_tail_rows_rollout(const rato_car_params* p, const double
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
+
+// One oracle round trip of the cutting-plane loop in ONE call: upload x = u - u_k, m(u) by the table-free rowmax, exact
+// tail selection, the cut's sums, read-back, stream synchronisation.  The same five stream-ordered steps the Python
+// facade issued one by one (cvar_cuts.CvarCutSolver.evaluate: two copies, four library calls, one synchronize -- about as
+// much host time per cut as the ~100 us the device works on it at M = 1e5).
+extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const double* uk, const float* s0,
+                                       const float* s1, const float* s2, const float* s3, const double* x_host,
+                                       double* x_dev, float* m_out, int32_t* arg_out, double alpha, float thr,
+                                       double alphaM, void* workspace, size_t workspace_bytes, double* res_dev,
+                                       double* part_dev, double* res_host, void* stream) {
+  RATO_CLEAR_ERROR();
+  if ((system != 0 && system != 1) || !params || !x_host || !x_dev || !res_dev || !res_host) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  int S, n_u;
+  int64_t M;
+  if (system == 0) {
+    const rato_drone_params* p = static_cast<const rato_drone_params*>(params);
+    S = p->S, n_u = 3, M = p->M;
+  } else {
+    const rato_car_params* p = static_cast<const rato_car_params*>(params);
+    S = p->S, n_u = 2, M = p->M;
+  }
+  if (S < 1 || M < 1) return RATO_EINVAL;
+  const int nc = 2 * (S - 1) + 1;
+  hipError_t e = hipMemcpyAsync(x_dev, x_host, sizeof(double) * (size_t)S * n_u, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  int rc = system == 0
+               ? rato_drone_rowmax_rollout(static_cast<const rato_drone_params*>(params), uk, s0, s1, s2, x_dev, m_out,
+                                           arg_out, stream)
+               : rato_car_rowmax_rollout(static_cast<const rato_car_params*>(params), uk, s0, s1, s2, s3, x_dev, m_out,
+                                         arg_out, stream);
+  if (rc != RATO_OK) return rc;
+  rc = rato_risk_stats(m_out, M, alpha, thr, workspace, workspace_bytes, res_dev, stream);
+  if (rc != RATO_OK) return rc;
+  if (S > 1) {
+    if (!part_dev) return RATO_EINVAL;
+    const int64_t stride = RATO_N_STATS + nc;
+    rc = system == 0 ? rato_drone_tail_rows_rollout(static_cast<const rato_drone_params*>(params), uk, s0, s1, s2, m_out,
+                                                    arg_out, res_dev, stride, nullptr, 1, alphaM, part_dev, stream)
+                     : rato_car_tail_rows_rollout(static_cast<const rato_car_params*>(params), uk, s0, s1, s2, s3, m_out,
+                                                  arg_out, res_dev, stride, nullptr, 1, alphaM, part_dev, stream);
+    if (rc != RATO_OK) return rc;
+    rc = rato_sum_partials_f64(part_dev, (int32_t)rato::nblocks_for(M), nc, 1.0, res_dev + RATO_N_STATS, stream);
+    if (rc != RATO_OK) return rc;
+  }
+  e = hipMemcpyAsync(res_host, res_dev, sizeof(double) * (size_t)(RATO_N_STATS + (S > 1 ? nc : 0)), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  return RATO_OK;
+}
+

@@ -195,20 +195,22 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     v[a] = P.x_init64[3 + a];
   }
   double zmax = -INFINITY;
-  constexpr int TB = 8;   // the noise of 8 steps (24 loads) in flight before their dependent steps: the kernel is bound by
-                          // load latency (one lane per sample, 50 sequential steps), not by bandwidth or flops
-  for (int t0 = 0; t0 < S; t0 += TB) {
-    float xib[TB][3];
+  constexpr int TB = 8;   // the noise of 8 steps (24 loads) is requested as one batch and the NEXT batch is in flight while a
+                          // batch is consumed (two register buffers): the kernel is bound by load latency (one lane per
+                          // sample, 50 sequential steps), not by bandwidth or flops
+  auto load_noise = [&](float (&xib)[TB][3], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int tt = (t0 + i < S) ? t0 + i : S - 1;
 #pragma unroll
       for (int a = 0; a < 3; ++a) xib[i][a] = dW[(size_t)(tt * 3 + a) * ld + m];
     }
+  };
+  auto forward_steps = [&](const float (&xib)[TB][3], int t0) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
     const int t = t0 + i;
-    if (t >= S) break;
+    if (t < S) {
     const float* xi = xib[i];
     double a22[3];
 #pragma unroll
@@ -241,14 +243,25 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
       const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
       zmax = fmax(zmax, gj);
-      if (valid) {
+      if (valid && W) {   // (W == NULL: a caller whose cut oracle re-runs the rollout needs only the sample sums)
         W[(((size_t)j * S + t) * 2 + 0) * ld + m] = (float)wx;
         W[(((size_t)j * S + t) * 2 + 1) * ld + m] = (float)wy;
         // -g + (grad g) . u   (drone_risk.py:278), or -- rows_out = 1 -- the constraint value g itself
         g_up[((size_t)j * S + t) * ld + m] = (float)(P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]));
       }
     }
+    }
     }   // step t of the batch
+  };
+  {
+    float xa[TB][3], xb[TB][3];
+    load_noise(xa, 0);
+    for (int t0 = 0; t0 < S; t0 += 2 * TB) {
+      load_noise(xb, t0 + TB);
+      forward_steps(xa, t0);
+      load_noise(xa, t0 + 2 * TB);
+      forward_steps(xb, t0 + TB);
+    }
   }
   if (Z && valid) Z[m] = (float)(zmax - P.tol64);
   // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
@@ -261,18 +274,19 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   for (int a = 0; a < 3; ++a) {
     mP0[a] = 1.0; mP1[a] = 0.0; mV0[a] = 0.0; mV1[a] = 1.0; dP[a] = 0.0; dV[a] = 0.0;
   }
-  for (int sb = S - 1; sb >= 0; sb -= TB) {
-    float e22b[TB][3];   // the table entries of 8 steps in flight (same lane wrote them: program order)
+  auto load_e22 = [&](float (&e22b)[TB][3], int sb) {   // the table entries of 8 steps (same lane wrote them: program order)
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int k = (sb - i > 0) ? sb - i : 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) e22b[i][a] = A22[((size_t)k * 3 + a) * ld + m];
     }
+  };
+  auto backward_steps = [&](const float (&e22b)[TB][3], int sb) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
     const int s2 = sb - i;
-    if (s2 < 0) break;
+    if (s2 >= 0) {
     double eP[3], eV[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -300,7 +314,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
         mP0[a] = nP0; mP1[a] = nP1; mV0[a] = nV0; mV1[a] = nV1;
       }
     }
+    }
     }   // step s2 of the batch
+  };
+  {
+    float ea[TB][3], eb[TB][3];
+    load_e22(ea, S - 1);
+    for (int sb = S - 1; sb >= 0; sb -= 2 * TB) {
+      load_e22(eb, sb - TB);
+      backward_steps(ea, sb);
+      load_e22(ea, sb - 2 * TB);
+      backward_steps(eb, sb - TB);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -1111,7 +1136,8 @@ extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const
                                                const float* mass, const float* Qsym, float* A22, float* W,
                                                float* g_up, float* Z, float* part, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!params_ok(p) || !params64_ok(p) || !us || !dW || !mass || !Qsym || !A22 || !W || !g_up || !part) return RATO_EINVAL;
+  // W and g_up may BOTH be NULL: only A22 (the lane's own scratch for the backward pass), Z and the sample sums
+  if (!params_ok(p) || !params64_ok(p) || !us || !dW || !mass || !Qsym || !A22 || (!W != !g_up) || !part) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
   const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(double);
   if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 340

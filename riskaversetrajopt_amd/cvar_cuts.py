@@ -139,6 +139,14 @@ class CvarCutSolver:
         self.x_host = torch.zeros((S, n_u), dtype=torch.float64).pin_memory()
         self.x_dev = e(S, n_u, dt=torch.float64)
         self.uk_dev = e(S, n_u, dt=torch.float64)        # the linearization point, for the rollout form of the oracle
+        # (pointers of the fixed buffers of the one-call round trip, looked up once)
+        self._x_np = self.x_host.numpy()
+        self._slots_np = self.slots_host.numpy()
+        self.uk_host = torch.zeros((S, n_u), dtype=torch.float64).pin_memory()
+        self._uk_np = self.uk_host.numpy()
+        self._uk_ptr, self._x_host_ptr, self._x_dev_ptr = _lib.ptr(self.uk_dev), _lib.ptr(self.x_host), _lib.ptr(self.x_dev)
+        self._ws_ptr, self._res_host_ptr = _lib.ptr(self.ws), _lib.ptr(self.res_host)
+        self._part_ptr = _lib.ptr(self.part)
 
     # ---- the two forms of the rows ------------------------------------------
     def _form(self):
@@ -156,10 +164,38 @@ class CvarCutSolver:
         S, M, n_u = self.S, self.M, self.n_u
         slot = self.cap - 1 if slot is None else slot
         m_buf, arg_buf, res = self.ring_m[slot], self.ring_arg[slot], self.ring_res[slot]
-        tstream = torch.cuda.current_stream()
-        st = _lib.C.c_void_p(tstream.cuda_stream)        # one stream lookup per call
         sign, x0 = self._form()
         x = np.ascontiguousarray(np.asarray(u_vec, dtype=np.float64) - x0)
+        if self.rollout is not None and self.world == 1:
+            # table-free forms: the whole round trip (upload, rowmax, selection, cut sums, read-back, synchronize) is one
+            # library call
+            self._x_np[:] = x.reshape(S, n_u)
+            kind, p, *samples = self.rollout
+            samples = [_lib.ptr(a) for a in samples] + [None] * (4 - len(samples))
+            _lib.check(self.lib.rato_cut_oracle_rollout(
+                0 if kind == "drone" else 1, _lib.C.byref(p), self._uk_ptr, *samples, self._x_host_ptr, self._x_dev_ptr,
+                _lib.ptr(m_buf), _lib.ptr(arg_buf), float(self.alpha), float(stats.SATISFIED_THRESHOLD),
+                float(self.alphaM), self._ws_ptr, self.ws.numel(), _lib.ptr(res), self._part_ptr, self._res_host_ptr,
+                _lib.current_stream()), "rato_cut_oracle_rollout")
+        else:
+            self._evaluate_stepwise(G, W, tile, base, x, sign, m_buf, arg_buf, res)
+        r = self.res_host.numpy()
+        if self.check_finite and not (np.isfinite(r[3]) and np.isfinite(r[4])):      # mean and max of the m values
+            raise _lib.RatoNonFiniteError("CVaR-cut oracle: non-finite constraint values m_i(u) (RATO_ENONFINITE)")
+        g = np.zeros(self.nU)
+        if S > 1:
+            sums = r[stats.N_STATS:] / self.alphaM
+            g.reshape(S, n_u)[:S - 1, 0:2] = sums[:self.nc - 1].reshape(S - 1, 2)
+            phi = float(g @ x + sign * sums[self.nc - 1])   # the cut's own value at the candidate (fp64, consistent with g)
+        else:
+            phi = float(r[1])                               # no control enters row t = 0: the value is a constant
+        return phi, float(r[0]), g
+
+    def _evaluate_stepwise(self, G, W, tile, base, x, sign, m_buf, arg_buf, res):
+        """the same round trip as separate stream-ordered calls (table forms of the oracle, sharded batches)"""
+        S, M, n_u = self.S, self.M, self.n_u
+        tstream = torch.cuda.current_stream()
+        st = _lib.C.c_void_p(tstream.cuda_stream)        # one stream lookup per call
         self.x_host.copy_(torch.from_numpy(x.reshape(S, n_u)))
         self.x_dev.copy_(self.x_host, non_blocking=True)
         if self.rollout is not None:
@@ -195,17 +231,6 @@ class CvarCutSolver:
                 res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
-        r = self.res_host.numpy()
-        if self.check_finite and not (np.isfinite(r[3]) and np.isfinite(r[4])):      # mean and max of the m values
-            raise _lib.RatoNonFiniteError("CVaR-cut oracle: non-finite constraint values m_i(u) (RATO_ENONFINITE)")
-        g = np.zeros(self.nU)
-        if S > 1:
-            sums = r[stats.N_STATS:] / self.alphaM
-            g.reshape(S, n_u)[:S - 1, 0:2] = sums[:self.nc - 1].reshape(S - 1, 2)
-            phi = float(g @ x + sign * sums[self.nc - 1])   # the cut's own value at the candidate (fp64, consistent with g)
-        else:
-            phi = float(r[1])                               # no control enters row t = 0: the value is a constant
-        return phi, float(r[0]), g
 
     def _rollout_rowmax(self, m_buf, arg_buf, st):
         kind, p, *samples = self.rollout
@@ -227,7 +252,8 @@ class CvarCutSolver:
         if self.rollout is not None:
             if self.u_lin is None:
                 raise ValueError("the rollout form of the oracle needs the linearization point (delta form)")
-            self.uk_dev.copy_(torch.from_numpy(self.u_lin.reshape(self.S, self.n_u)), non_blocking=False)
+            self._uk_np[:] = self.u_lin.reshape(self.S, self.n_u)    # (pinned; every solve ends synchronised, so the
+            _lib.copy_async(self.uk_dev, self.uk_host)               #  previous upload from it has long completed)
 
     def enqueue_relinearize(self, G, W, tile, base):
         """Stream-ordered half of ``relinearize_kept_cuts`` (launches + the read-back into pinned memory, NO
@@ -244,7 +270,7 @@ class CvarCutSolver:
         if K == 0:
             return np.zeros((0, self.nU)), np.zeros(0)
         S, n_u = self.S, self.n_u
-        torch.cuda.current_stream().synchronize()
+        _lib.synchronize()
         r = self.sums_b_host.numpy()[:K * self.nc].reshape(K, self.nc) / self.alphaM
         rows = np.zeros((K, self.nU))
         rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
@@ -257,12 +283,12 @@ class CvarCutSolver:
         K, S, M, n_u = len(self.keep), self.S, self.M, self.n_u
         if K == 0 or S < 2 or not self.recycle:
             return 0
-        self.slots_host[:K] = torch.as_tensor(self.keep, dtype=torch.int32)
-        self.slots_dev.copy_(self.slots_host, non_blocking=True)
+        st = _lib.current_stream()
+        self._slots_np[:K] = self.keep
+        _lib.copy_async(self.slots_dev, self.slots_host, st)
         part = self.part_b.view(-1)[:self.nblk * K * self.nc].view(self.nblk, K * self.nc)
         if self.rollout is not None:
-            self._rollout_tail_rows(self.ring_m, self.ring_arg, self.ring_res, _lib.ptr(self.slots_dev), K, part,
-                                    _lib.current_stream())
+            self._rollout_tail_rows(self.ring_m, self.ring_arg, self.ring_res, _lib.ptr(self.slots_dev), K, part, st)
         elif G is None:
             p, mass, A22, axes = self.implicit
             _lib.check(self.lib.rato_drone_tail_rows_implicit(
@@ -275,10 +301,10 @@ class CvarCutSolver:
                 _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(base), _lib.ptr(self.ring_m),
                 _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
                 float(self.alphaM), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
-        stats.sum_partials(part, out=self.sums_b[:K * self.nc])
+        stats.sum_partials(part, out=self.sums_b[:K * self.nc], stream=st)
         if self.world > 1:
             self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
-        self.sums_b_host.copy_(self.sums_b, non_blocking=True)
+        _lib.copy_async(self.sums_b_host, self.sums_b, st)
         return K
 
     # ---- master QP (host, exact: dense_qp) -----------------------------------------

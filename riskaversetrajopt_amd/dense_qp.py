@@ -158,9 +158,81 @@ def _null_space(A):
     return sla.null_space(A)
 
 
-class Master:
-    """The same solve with the equality elimination and the Cholesky whitening done ONCE, and inequality rows
-    appended incrementally (a cutting-plane loop adds one row per iteration)."""
+def _native_master():
+    """librato_saa.so's rato_master_* entry points (csrc/master.hip), or None when the library cannot be loaded"""
+    if len(_NATIVE) < 2:
+        _native()
+        try:
+            from . import _lib
+            _NATIVE.append(_lib.load())
+        except Exception:                          # pragma: no cover
+            _NATIVE.append(None)
+    return _NATIVE[1]
+
+
+def Master(P, q, A_eq, b_eq):
+    """The same solve with the equality elimination and the whitening done ONCE, and inequality rows appended
+    incrementally (a cutting-plane loop adds one row per iteration).  Diagonal Hessian + full-row-rank equalities (the
+    SCP master) -> the native implementation (``MasterNative``: csrc/master.hip, same algorithm, no dense null-space
+    basis); anything else, or no library -> ``MasterPy``."""
+    P = np.asarray(P, dtype=np.float64)
+    lib = _native_master()
+    if lib is not None and A_eq is not None and len(A_eq) and np.count_nonzero(P - np.diag(np.diagonal(P))) == 0:
+        try:
+            return MasterNative(lib, np.diagonal(P), q, A_eq, b_eq)
+        except ValueError:                         # rank-deficient equalities, non-positive diagonal
+            pass
+    return MasterPy(P, q, A_eq, b_eq)
+
+
+class MasterNative:
+    """ctypes face of rato_master_* (include/rato_saa.h)."""
+    L = None                                       # (MasterPy's marker of the diagonal fast path)
+
+    def __init__(self, lib, p_diag, q, A_eq, b_eq):
+        import ctypes as C
+        self._lib, self._C = lib, C
+        p_diag = np.ascontiguousarray(p_diag, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        A_eq = np.ascontiguousarray(A_eq, dtype=np.float64)
+        b_eq = np.ascontiguousarray(b_eq, dtype=np.float64)
+        self.n = q.shape[0]
+        h = C.c_void_p()
+        rc = lib.rato_master_create(C.byref(h), self.n, p_diag.ctypes.data, q.ctypes.data, A_eq.shape[0],
+                                    A_eq.ctypes.data, b_eq.ctypes.data)
+        if rc != 0:
+            raise ValueError(f"rato_master_create: status {rc}")
+        self._h = h
+        self._z = np.zeros(self.n)
+        self.rows = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rato_master_destroy(h)
+
+    def add_rows(self, A_in, b_in):
+        A_in = np.ascontiguousarray(np.atleast_2d(np.asarray(A_in, dtype=np.float64)))
+        b_in = np.ascontiguousarray(np.atleast_1d(np.asarray(b_in, dtype=np.float64)))
+        if A_in.shape != (b_in.shape[0], self.n):
+            raise ValueError(f"rows must be (k, {self.n}) with k right-hand sides, got {A_in.shape} / {b_in.shape}")
+        rc = self._lib.rato_master_add_rows(self._h, A_in.shape[0], A_in.ctypes.data, b_in.ctypes.data)
+        if rc != 0:
+            raise ValueError(f"rato_master_add_rows: status {rc}")
+        self.rows += A_in.shape[0]
+
+    def solve(self):
+        lam = np.zeros(self.rows)
+        rc = self._lib.rato_master_solve(self._h, self._z.ctypes.data, lam.ctypes.data)
+        if rc == -4:
+            raise InfeasibleError("master QP infeasible")
+        if rc != 1:
+            raise RuntimeError(f"rato_master_solve: status {rc} (the NNLS of the master did not converge)")
+        return self._z.copy(), lam
+
+
+class MasterPy:
+    """NumPy form of ``Master`` (general Hessian; also the reference the native one is tested against)."""
 
     def __init__(self, P, q, A_eq, b_eq):
         P = np.asarray(P, dtype=np.float64)

@@ -326,11 +326,14 @@ class Model:
                 "W": (Wf[..., :M] if factored else None), "_W": Wf,
                 "A22": (A22[..., :M] if A22 is not None else None), "_A22": A22}
 
-    def linearize_generators_device(self, us_mat, inputs=None, out=None, rows_out=0):
+    def linearize_generators_device(self, us_mat, inputs=None, out=None, rows_out=0, tables=True, defer_check=False):
         """Generators-only linearization (rato_drone_linearize_generators): A22 [S][3][M] (holding 1 - a22), W [n_obs][S][2][M],
         g_up [n_obs][S][M], Z [M] and the sample sums -- everything ``solve_reduced`` needs -- without the S(S-1)
         Jacobian entries per sample (60 B instead of 245 B of HBM traffic per sample-step).  Same dict keys as
-        ``linearize_device`` with G = None."""
+        ``linearize_device`` with G = None.  ``tables=False``: W and g_up are not written (keys None) -- a reduced solve whose
+        cut oracle re-runs the rollout only needs Z and the sample sums.  ``defer_check``: with ``check_finite`` the count
+        of non-finite outputs is left on the device (key ``_nonfinite``) for a caller that reads it back with its other
+        results instead of paying a synchronisation here."""
         dW, mass, Qsym, M = self._inputs(inputs)
         if dW is None:
             raise _lib.RatoError("linearize_generators_device reads a materialised dW (this Model regenerates its noise)")
@@ -345,8 +348,8 @@ class Model:
             return alloc()
 
         A22 = reuse("_A22", (S, 3, ld), lambda: self._empty(S, 3, ld))
-        Wf = reuse("_W", (n_obs, S, 2, ld), lambda: self._empty(n_obs, S, 2, ld))
-        g_up = reuse("_g_up", (n_obs, S, ld), lambda: self._rows(n_obs, S, ld, M=M))
+        Wf = reuse("_W", (n_obs, S, 2, ld), lambda: self._empty(n_obs, S, 2, ld)) if tables else None
+        g_up = reuse("_g_up", (n_obs, S, ld), lambda: self._rows(n_obs, S, ld, M=M)) if tables else None
         Z = reuse("_Z", (ld,), lambda: self._rows(ld, M=M))
         nblk = (M + 255) // 256
         part = reuse("part", (nblk, 6 * S + 6), lambda: self._empty(nblk, 6 * S + 6))
@@ -357,12 +360,15 @@ class Model:
             C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(A22), _lib.ptr(Wf),
             _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()), "rato_drone_linearize_generators")
         sums = stats.sum_partials(part, out=o.get("sums"))
+        bad = None
         if self.check_finite:
-            stats.assert_finite("drone linearize (generators)", g_up, Z, part)
-        return {"G": None, "g_up": g_up[..., :M], "Z": Z[:M], "du_sum": sums[:6 * S].view(S, 6),
+            bad = stats.enqueue_nonfinite_count("drone linearize (generators)", g_up, Z, part, out=o.get("_nonfinite"))
+            if not defer_check:
+                stats.raise_if_nonfinite("drone linearize (generators)", int(bad.item()))
+        return {"_nonfinite": bad, "G": None, "g_up": g_up[..., :M] if tables else None, "Z": Z[:M], "du_sum": sums[:6 * S].view(S, 6),
                 "rhs_sum": sums[6 * S:], "sums": sums, "part": part, "M": M, "_g_up": g_up, "_Z": Z,
-                "tile": 64, "factored": True, "W": Wf[..., :M], "_W": Wf, "A22": A22[..., :M], "_A22": A22,
-                "a22_axes": 3, "rows_out": int(rows_out)}
+                "tile": 64, "factored": True, "W": Wf[..., :M] if tables else None, "_W": Wf, "A22": A22[..., :M],
+                "_A22": A22, "a22_axes": 3, "rows_out": int(rows_out)}
 
     def expand_final_du(self, du_sum, scale):
         """[S][6] sums -> dense (n_x, n_u*S) like the reference's v_final_du."""
@@ -594,8 +600,15 @@ class Model:
         if generators_only and not implicit:
             raise ValueError("generators_only needs the implicit oracle")
         rows_out = 1 if delta else 0
+        dW, mass, Qsym, _ = self._inputs(None)
+        if rollout is None:
+            rollout = bool(implicit and generators_only and delta and dW is not None)
+        if rollout and not (implicit and delta and dW is not None):
+            raise ValueError("the rollout form of the oracle needs implicit=True, delta=True and a materialised dW")
         if generators_only:
-            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None), rows_out=rows_out)
+            # (the table-free oracle reads neither W nor g: only Z and the sample sums are produced then)
+            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None), rows_out=rows_out,
+                                                 tables=not rollout, defer_check=True)
             self._gen_buffers = r
         else:
             r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit,
@@ -605,18 +618,13 @@ class Model:
         world = getattr(self, "_world", 1)
         cs = getattr(self, "_cut_solver", None)
         if cs is None:
-            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=r["_g_up"].shape[-1],
+            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=mass.numel(),
                                          R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
                                          slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max,
                                          group=getattr(self, "_group", None), world=world, mode=self.method,
                                          rhs0=-1e-3 / self.MULTIPLIER)
             self._cut_solver = cs
         cs.implicit = cs.rollout = None
-        dW, mass, Qsym, _ = self._inputs(None)
-        if rollout is None:
-            rollout = bool(implicit and generators_only and delta and dW is not None)
-        if rollout and not (implicit and delta and dW is not None):
-            raise ValueError("the rollout form of the oracle needs implicit=True, delta=True and a materialised dW")
         if implicit:
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
         if rollout:
@@ -630,7 +638,20 @@ class Model:
         if world > 1:                                     # sample means over ALL shards, summed in rank order
             from . import dist as rdist
             sums = rdist.sum_in_rank_order(sums, getattr(self, "_group", None))
-        sums = sums.cpu().numpy()
+        # ONE synchronisation for the sample sums, the non-finite count and (enqueued above) the kept cuts
+        host = getattr(self, "_define_host", None)
+        if host is None or host[0].numel() != sums.numel():
+            host = (torch.zeros(sums.numel(), dtype=torch.float64).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory())
+            self._define_host = host
+        st = _lib.current_stream()
+        _lib.copy_async(host[0], sums, st)
+        bad = r.get("_nonfinite")
+        if bad is not None:
+            _lib.copy_async(host[1], bad, st)
+        _lib.synchronize(st)
+        if bad is not None:
+            stats.raise_if_nonfinite("drone linearize (generators)", int(host[1][0]))
+        sums = host[0].numpy()
         final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / (M * world))
         final_rhs = sums[6 * S:] / (M * world)
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs,

@@ -118,21 +118,33 @@ def count_nonfinite(x):
     return int(cnt.item())
 
 
-def assert_finite(what, *tensors):
-    """Failure detection for the hot path (SURVEY 8b: a distinct status on non-finite output; the reference only
-    prints "[solve]: Problem infeasible.", drone_risk.py:458-459, and keeps iterating on NaNs): counts the NaN/Inf
-    entries of the given device fp32 tensors into ONE device counter (rato_count_nonfinite + _acc), reads it back
-    once and raises ``RatoNonFiniteError`` (status RATO_ENONFINITE) if it is not zero."""
+def enqueue_nonfinite_count(what, *tensors, out=None):
+    """Stream-ordered half of ``assert_finite``: counts the NaN/Inf entries of the given device fp32 tensors into ONE
+    device counter (rato_count_nonfinite + _acc) and returns it WITHOUT reading it back (None if there is nothing to
+    scan) -- a caller that reads other results back anyway copies the counter along and pays one synchronisation."""
     lib = _lib.load()
     tensors = [t for t in tensors if t is not None]
     if not tensors:
-        return
-    cnt = torch.empty(1, dtype=torch.int32, device=tensors[0].device)
+        return None
+    cnt = out if out is not None else torch.empty(1, dtype=torch.int32, device=tensors[0].device)
     st = _lib.current_stream()
     for i, t in enumerate(tensors):
         _lib.require_f32_device(t, what)
         fn = lib.rato_count_nonfinite if i == 0 else lib.rato_count_nonfinite_acc
         _lib.check(fn(_lib.ptr(t), t.numel(), _lib.ptr(cnt), st), "rato_count_nonfinite")
-    bad = int(cnt.item())
+    return cnt
+
+
+def raise_if_nonfinite(what, bad):
     if bad:
-        raise _lib.RatoNonFiniteError(f"{what}: {bad} non-finite values in the device outputs (RATO_ENONFINITE)")
+        raise _lib.RatoNonFiniteError(f"{what}: {int(bad)} non-finite values in the device outputs (RATO_ENONFINITE)")
+
+
+def assert_finite(what, *tensors):
+    """Failure detection for the hot path (SURVEY 8b: a distinct status on non-finite output; the reference only
+    prints "[solve]: Problem infeasible.", drone_risk.py:458-459, and keeps iterating on NaNs): counts the NaN/Inf
+    entries of the given device fp32 tensors into ONE device counter (rato_count_nonfinite + _acc), reads it back
+    once and raises ``RatoNonFiniteError`` (status RATO_ENONFINITE) if it is not zero."""
+    cnt = enqueue_nonfinite_count(what, *tensors)
+    if cnt is not None:
+        raise_if_nonfinite(what, int(cnt.item()))

@@ -169,3 +169,40 @@ def test_native_nnls_matches_scipy_and_the_numpy_version():
     y, P, ok = dense_qp.nnls_warm(A, b, None)
     w = A.T @ (b - A @ y)
     assert ok and np.all(w[~P] <= 1e-9) and np.all(np.abs(w[P]) <= 1e-9)
+
+
+def test_native_master_equals_the_numpy_master():
+    """rato_master_* (csrc/master.hip: Householder reflectors instead of a dense null-space basis, warm-started native
+    NNLS) against MasterPy on an SCP-shaped problem: diagonal Hessian with a large slack penalty, 6 equalities, rows
+    arriving one at a time -- same minimiser and multipliers after every row; infeasible rows are reported."""
+    rng = np.random.RandomState(5)
+    n = 151
+    d = np.concatenate([np.tile([0.4, 0.4, 0.4], 50) * (1 + 0.1 * rng.rand(150)), [1e4]])
+    q = np.zeros(n)
+    q[-1] = 1e4
+    A_eq = np.hstack([rng.randn(6, n - 1), np.zeros((6, 1))])
+    xf = rng.randn(n)
+    b_eq = A_eq @ xf
+    nat, ref = dense_qp.Master(np.diag(d), q, A_eq, b_eq), dense_qp.MasterPy(np.diag(d), q, A_eq, b_eq)
+    assert isinstance(nat, dense_qp.MasterNative)
+    x, lam = nat.solve()                                   # no rows yet: the equality-constrained minimiser
+    xr, _ = ref.solve()
+    np.testing.assert_allclose(x, xr, rtol=0, atol=1e-10)
+    assert np.abs(A_eq @ x - b_eq).max() < 1e-10
+    for it in range(60):
+        a = rng.randn(1, n)
+        a[0, -1] = -3.0 if it % 2 else 0.0                 # cuts carry -c_s on the slack; bounds do not
+        bb = a @ xf + rng.rand(1) * 0.5
+        nat.add_rows(a, bb)
+        ref.add_rows(a, bb)
+        x, lam = nat.solve()
+        xr, lamr = ref.solve()
+        np.testing.assert_allclose(x, xr, rtol=0, atol=1e-8 * max(1.0, np.abs(xr).max()))
+        np.testing.assert_allclose(lam, lamr, rtol=1e-6, atol=1e-8 * max(1.0, lamr.max()))
+        assert lam.min() >= 0.0 and np.abs(A_eq @ x - b_eq).max() < 1e-9
+    nat.add_rows(np.vstack([np.eye(n)[0], -np.eye(n)[0]]), np.array([-1.0, -1.0]))      # x_0 <= -1 and x_0 >= 1
+    with pytest.raises(dense_qp.InfeasibleError):
+        nat.solve()
+    # rank-deficient equalities: the factory falls back to the NumPy master
+    m2 = dense_qp.Master(np.diag(d), q, np.vstack([A_eq, A_eq[0]]), np.concatenate([b_eq, b_eq[:1]]))
+    assert isinstance(m2, dense_qp.MasterPy)
