@@ -455,10 +455,20 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
 // samples themselves (noise of the two horizontal axes, mass, Q: 8 S + 40 bytes per sample) while it propagates the
 // response to x = u - u_k.  5 x less HBM traffic than the tables, and no stored intermediate at all: what is left of the
 // fp32 device path in the rows is the rounding of its INPUTS.  u_k and x are doubles ([S][3]).
+// BYVAL: x travels in the kernel arguments (S n_u <= XARG_MAX doubles) instead of device memory -- the one-call round
+// trip (rato_cut_oracle_rollout) then needs no upload in front of its first launch (an asynchronous 1.2 KB copy costs
+// ~25 us of host time on this stack, a quarter of the device time of the whole trip).
+constexpr int XARG_MAX = 192;
+struct XArg {
+  double v[XARG_MAX];
+};
+
+template <bool BYVAL>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
     rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
-    const float* __restrict__ Qsym, const double* __restrict__ xs, float* __restrict__ m_out,
+    const float* __restrict__ Qsym, const double* __restrict__ xs_mem, const XArg xv, float* __restrict__ m_out,
     int* __restrict__ arg_out) {
+  const double* __restrict__ xs = BYVAL ? xv.v : xs_mem;
   const long m = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
   if (m >= P.M) return;
   const size_t ld = (size_t)P.ld;
@@ -742,10 +752,12 @@ __host__ __device__ inline size_t car_rollout_ego_doubles(int S) {   // U (uk | 
 //   F = -w_r n + w_s (v_des - qv_y) (1, 1)                       dF = -w_r H (de_t - dq_t) - w_s dqv_y (1, 1)
 //   q_{t+1} = q_t + dt qv_t,  qv_{t+1} = qv_t + dt F + sqrt(dt) beta dW_t          (same recursion for dq, dqv with dF)
 //   row t = g_t - n_{t+1} . (de_{t+1} - dq_{t+1})
+template <bool BYVAL>
 __global__ __launch_bounds__(RATO_BLOCK) void car_rowmax_rollout_kernel(
     rato_car_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ x0_ped,
-    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const double* __restrict__ xs,
-    float* __restrict__ m_out, int* __restrict__ arg_out) {
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, const double* __restrict__ xs_mem,
+    const XArg xv, float* __restrict__ m_out, int* __restrict__ arg_out) {
+  const double* xs = BYVAL ? xv.v : xs_mem;
   extern __shared__ __attribute__((aligned(16))) unsigned char crr_lds[];
   const int S = P.S;
   double* U = reinterpret_cast<double*>(crr_lds);
@@ -1053,18 +1065,36 @@ extern "C" int rato_saa_tail_rows_batch(const float* G, const float* W, int64_t 
   return RATO_OK;
 }
 
+namespace {
+// xs_host != NULL and S n_u <= XARG_MAX: x is passed by value (no device copy of it is read)
+int drone_rowmax_rollout_launch(const rato_drone_params* p, const double* uk, const float* dW, const float* mass,
+                                const float* Qsym, const double* xs, const double* xs_host, float* m_out,
+                                int32_t* arg_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !uk || !dW || !mass || !Qsym ||
+      (!xs && !xs_host) || !m_out || !arg_out)
+    return RATO_EINVAL;
+  dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
+  XArg xv;
+  if (xs_host && p->S * 3 <= XARG_MAX) {
+    for (int i = 0; i < p->S * 3; ++i) xv.v[i] = xs_host[i];
+    hipLaunchKernelGGL(drone_rowmax_rollout_kernel<true>, grid, block, 0, rato::as_stream(stream), *p, uk, dW, mass, Qsym,
+                       xs, xv, m_out, arg_out);
+  } else {
+    if (!xs) return RATO_EINVAL;
+    hipLaunchKernelGGL(drone_rowmax_rollout_kernel<false>, grid, block, 0, rato::as_stream(stream), *p, uk, dW, mass, Qsym,
+                       xs, xv, m_out, arg_out);
+  }
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+}  // namespace
+
 extern "C" int rato_drone_rowmax_rollout(const rato_drone_params* p, const double* uk, const float* dW,
                                          const float* mass, const float* Qsym, const double* xs, float* m_out,
                                          int32_t* arg_out, void* stream) {
-  RATO_CLEAR_ERROR();
-  if (!p || p->M <= 0 || p->S < 1 || p->ld < p->M || !(p->dt > 0.0f) || !(p->dt64 > 0.0) || !uk || !dW || !mass || !Qsym || !xs || !m_out ||
-      !arg_out)
-    return RATO_EINVAL;
-  dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  hipLaunchKernelGGL(drone_rowmax_rollout_kernel, grid, block, 0, rato::as_stream(stream), *p, uk, dW, mass, Qsym, xs,
-                     m_out, arg_out);
-  RATO_LAUNCH_CHECK();
-  return RATO_OK;
+  if (!xs) return RATO_EINVAL;
+  return drone_rowmax_rollout_launch(p, uk, dW, mass, Qsym, xs, nullptr, m_out, arg_out, stream);
 }
 
 extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const double* uk, const float* dW,
@@ -1101,18 +1131,36 @@ bool car_params64_ok(const rato_car_params* p) {
 }
 }  // namespace
 
-extern "C" int rato_car_rowmax_rollout(const rato_car_params* p, const double* uk, const float* dW,
-                                       const float* x0_ped, const float* w_speed, const float* w_rep,
-                                       const double* xs, float* m_out, int32_t* arg_out, void* stream) {
+namespace {
+int car_rowmax_rollout_launch(const rato_car_params* p, const double* uk, const float* dW, const float* x0_ped,
+                              const float* w_speed, const float* w_rep, const double* xs, const double* xs_host,
+                              float* m_out, int32_t* arg_out, void* stream) {
   RATO_CLEAR_ERROR();
-  if (!car_params64_ok(p) || !uk || !dW || !x0_ped || !w_speed || !w_rep || !xs || !m_out || !arg_out) return RATO_EINVAL;
+  if (!car_params64_ok(p) || !uk || !dW || !x0_ped || !w_speed || !w_rep || (!xs && !xs_host) || !m_out || !arg_out)
+    return RATO_EINVAL;
   const size_t lds = car_rollout_ego_doubles(p->S) * sizeof(double);
   if (lds > 64 * 1024) return RATO_EINVAL;
   dim3 grid((unsigned)rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  hipLaunchKernelGGL(car_rowmax_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, x0_ped, w_speed,
-                     w_rep, xs, m_out, arg_out);
+  XArg xv;
+  if (xs_host && p->S * 2 <= XARG_MAX) {
+    for (int i = 0; i < p->S * 2; ++i) xv.v[i] = xs_host[i];
+    hipLaunchKernelGGL(car_rowmax_rollout_kernel<true>, grid, block, lds, rato::as_stream(stream), *p, uk, dW, x0_ped,
+                       w_speed, w_rep, xs, xv, m_out, arg_out);
+  } else {
+    if (!xs) return RATO_EINVAL;
+    hipLaunchKernelGGL(car_rowmax_rollout_kernel<false>, grid, block, lds, rato::as_stream(stream), *p, uk, dW, x0_ped,
+                       w_speed, w_rep, xs, xv, m_out, arg_out);
+  }
   RATO_LAUNCH_CHECK();
   return RATO_OK;
+}
+}  // namespace
+
+extern "C" int rato_car_rowmax_rollout(const rato_car_params* p, const double* uk, const float* dW,
+                                       const float* x0_ped, const float* w_speed, const float* w_rep,
+                                       const double* xs, float* m_out, int32_t* arg_out, void* stream) {
+  if (!xs) return RATO_EINVAL;
+  return car_rowmax_rollout_launch(p, uk, dW, x0_ped, w_speed, w_rep, xs, nullptr, m_out, arg_out, stream);
 }
 
 extern "C" int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const float* dW,
@@ -1165,13 +1213,16 @@ extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const
   }
   if (S < 1 || M < 1) return RATO_EINVAL;
   const int nc = 2 * (S - 1) + 1;
-  hipError_t e = hipMemcpyAsync(x_dev, x_host, sizeof(double) * (size_t)S * n_u, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  hipError_t e = hipSuccess;
+  if (S * n_u > XARG_MAX) {   // long horizons: x goes through device memory; otherwise it rides in the kernel arguments
+    e = hipMemcpyAsync(x_dev, x_host, sizeof(double) * (size_t)S * n_u, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
   int rc = system == 0
-               ? rato_drone_rowmax_rollout(static_cast<const rato_drone_params*>(params), uk, s0, s1, s2, x_dev, m_out,
-                                           arg_out, stream)
-               : rato_car_rowmax_rollout(static_cast<const rato_car_params*>(params), uk, s0, s1, s2, s3, x_dev, m_out,
-                                         arg_out, stream);
+               ? drone_rowmax_rollout_launch(static_cast<const rato_drone_params*>(params), uk, s0, s1, s2, x_dev, x_host,
+                                             m_out, arg_out, stream)
+               : car_rowmax_rollout_launch(static_cast<const rato_car_params*>(params), uk, s0, s1, s2, s3, x_dev, x_host,
+                                           m_out, arg_out, stream);
   if (rc != RATO_OK) return rc;
   rc = rato_risk_stats(m_out, M, alpha, thr, workspace, workspace_bytes, res_dev, stream);
   if (rc != RATO_OK) return rc;

@@ -301,9 +301,11 @@ class CvarCutSolver:
                 _lib.ptr(G), _lib.ptr(W), self.ld, tile, self.R, S, M, _lib.ptr(base), _lib.ptr(self.ring_m),
                 _lib.ptr(self.ring_arg), _lib.ptr(self.ring_res), self.nres, _lib.ptr(self.slots_dev), K,
                 float(self.alphaM), _lib.ptr(part), _lib.current_stream()), "rato_saa_tail_rows_batch")
+        if self.world == 1:       # the reduction writes straight into pinned host memory: no read-back copy to issue
+            stats.sum_partials(part, out=self.sums_b_host[:K * self.nc], stream=st)
+            return K
         stats.sum_partials(part, out=self.sums_b[:K * self.nc], stream=st)
-        if self.world > 1:
-            self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
+        self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
         _lib.copy_async(self.sums_b_host, self.sums_b, st)
         return K
 

@@ -607,8 +607,13 @@ class Model:
             raise ValueError("the rollout form of the oracle needs implicit=True, delta=True and a materialised dW")
         if generators_only:
             # (the table-free oracle reads neither W nor g: only Z and the sample sums are produced then)
-            r = self.linearize_generators_device(us_mat_p, out=getattr(self, "_gen_buffers", None), rows_out=rows_out,
-                                                 tables=not rollout, defer_check=True)
+            bufs = getattr(self, "_gen_buffers", None)
+            if bufs is None and getattr(self, "_world", 1) == 1:
+                # single GPU: the sample sums are consumed on the host only, so the partial-sum kernel writes them straight
+                # into pinned host memory (visible after the synchronisation below) -- no read-back copy to issue
+                bufs = {"sums": torch.zeros(6 * self.S + 6, dtype=torch.float64).pin_memory()}
+            r = self.linearize_generators_device(us_mat_p, out=bufs, rows_out=rows_out, tables=not rollout,
+                                                 defer_check=True)
             self._gen_buffers = r
         else:
             r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), want_A22=implicit,
@@ -644,14 +649,15 @@ class Model:
             host = (torch.zeros(sums.numel(), dtype=torch.float64).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory())
             self._define_host = host
         st = _lib.current_stream()
-        _lib.copy_async(host[0], sums, st)
+        if sums.is_cuda:
+            _lib.copy_async(host[0], sums, st)
         bad = r.get("_nonfinite")
         if bad is not None:
             _lib.copy_async(host[1], bad, st)
         _lib.synchronize(st)
         if bad is not None:
             stats.raise_if_nonfinite("drone linearize (generators)", int(host[1][0]))
-        sums = host[0].numpy()
+        sums = (host[0] if sums.is_cuda else sums).numpy()
         final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / (M * world))
         final_rhs = sums[6 * S:] / (M * world)
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs,
