@@ -47,6 +47,7 @@ Jacobian of its samples; a cut costs one all-gather of the m shards (the exact V
 then runs the same selection), and one rank-ordered sum of the 2(S-1) subgradient partial sums.  Every rank
 solves the same tiny master; rank 0's solution is broadcast so that the ranks cannot drift apart.
 """
+import os
 import time
 
 import numpy as np
@@ -109,10 +110,13 @@ class CvarCutSolver:
             raise ValueError(f"mode must be 'saa' or 'baseline', got {mode!r}")
         self.recycle = recycle
         self.keep_max = 48
+        self.keep_recent = int(os.environ.get("RATO_KEEP_RECENT", 4))   # newest cuts kept beside the ones with a multiplier
         self.cap = (160 if recycle else 1) + 1          # last slot: scratch for calls beyond the ring
         self.nc = 2 * max(S - 1, 0) + 1
         self.nres = stats.N_STATS + self.nc
         self.keep = []                                   # slots kept from the previous solve
+        self.idle = {}                                   # slot -> consecutive solves it has carried no multiplier
+        self.keep_idle = int(os.environ.get("RATO_KEEP_IDLE", 0))        # (A/B knobs: profiles/EXPERIMENTS.md, "2-cycles")
         self.u_lin = None                                # linearization point of the delta form (None: reference form)
         self._relin_pending = None                       # kept cuts whose re-linearization is already in flight
         if device is not None:                           # (None: a host oracle overrides evaluate / relinearize_kept_cuts
@@ -429,8 +433,15 @@ class CvarCutSolver:
             n_cuts += 1
         if self.recycle and with_cvar:
             # keep the cuts that carry a multiplier at the solution (newest first), plus the newest few
-            act = [sl for row, sl in reversed(cut_rows) if row < lam.shape[0] and lam[row] > 1e-12]
-            recent = [sl for _, sl in reversed(cut_rows)][:4]
+            # (keep_idle > 0: hysteresis -- a cut that carried a multiplier in one of the last keep_idle solves stays.  Tried
+            # against the 2-cycles some batches end in, iterates ~1e-6 apart: two sets of active cuts alternating, the
+            # subproblems being accurate to the cut tolerance in VALUE only; no keep rule removed them on every batch, so
+            # the cheapest one stays the default.)
+            for row, sl in cut_rows:
+                active = row < lam.shape[0] and lam[row] > 1e-12
+                self.idle[sl] = 0 if active else self.idle.get(sl, 0) + 1
+            act = [sl for row, sl in reversed(cut_rows) if self.idle[sl] <= self.keep_idle]
+            recent = [sl for _, sl in reversed(cut_rows)][:self.keep_recent]
             keep = []
             for sl in act + recent:
                 if sl not in keep:
@@ -443,6 +454,7 @@ class CvarCutSolver:
                 pad = rdist.broadcast_from_rank0(pad, self.device, self.group)
                 keep = [int(v) for v in pad[1:1 + int(pad[0])]]
             self.keep = keep
+            self.idle = {sl: self.idle[sl] for sl in keep}
             info["recycled"] = len(kept)
         # t_risk: VaR + slack where the CVaR rows are present (y, t eliminated at their optimum); the relaxed QP of
         # the first iterations and the 'baseline' QP leave it undetermined (no row and no cost touches it): 0

@@ -16,6 +16,7 @@ import numpy as np
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--system", default="drone", choices=["drone", "driving"])
+    ap.add_argument("--seed", type=int, default=0, help="seed of the device sampler (bench.py's scp block uses 7)")
     ap.add_argument("--M", type=int, default=50)
     ap.add_argument("--S", type=int, default=20)
     ap.add_argument("--alpha", type=float, default=0.1)
@@ -36,7 +37,7 @@ def main():
     dev = f"cuda:{local}"
     if args.system == "drone" and args.reduced:
         from riskaversetrajopt_amd import drone_risk, drone_utils
-        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank, device=dev)
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank + args.seed, device=dev)
         model = drone_risk.Model.from_device(args.S, dW, mass, Qsym, 'saa', args.alpha, M=args.M)
         if world > 1:
             model.shard()
@@ -60,7 +61,7 @@ def main():
         return
     if args.system == "driving" and args.reduced:
         from riskaversetrajopt_amd import driving
-        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank, device=dev)
+        dW, x0, ws, wr = driving.sample_uncertain_parameters_device(args.M, args.S, seed=1000 * rank + args.seed, device=dev)
         model = driving.Model.from_device(args.S, dW, x0, ws, wr, 'saa', args.alpha)
         if world > 1:
             model.shard()
