@@ -713,6 +713,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   }
 }
 
+
 bool params_ok(const rato_car_params* p) {
   return p && p->M > 0 && p->S > 0 && p->S <= 1024 && p->dt > 0.0f;   // 1024: the ego prologue's LDS tables (48 KB)
 }

@@ -100,3 +100,4 @@ def test_two_captured_graphs_replayed_concurrently_do_not_share_a_tile_queue():
     r = d.linearize_device(us)
     torch.cuda.synchronize()
     assert torch.equal(untile(r["G"], M), refs[0]["G"]) and torch.equal(untile(outs[1]["G"], M), refs[1]["G"])
+
