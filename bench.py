@@ -587,6 +587,27 @@ def scp_block(work, args):
             "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
 
 
+def scp_driving_block(device):
+    """The driving SCP with the reference's protocol (driving.py:482-529: 15 iterations from the initial guess) at
+    M = 1e5, S = 40, alpha = 0.05 on a fresh device-sampled batch -- reduced subproblems with the table-free oracle
+    (no Jacobian is formed at all: rato_car_rowmax_rollout / rato_car_tail_rows_rollout)."""
+    import torch
+    from riskaversetrajopt_amd import driving, scp
+    M, S, alpha, iters = 100000, 40, 0.05, 15
+    dW, x0, ws, wr = driving.sample_uncertain_parameters_device(M, S, seed=7, device=device)
+    model = driving.Model.from_device(S, dW, x0, ws, wr, 'saa', alpha)
+    model.solve_reduced(model.initial_guess_us_mat(), 1)             # warm-up: allocations, first launches
+    model._cut_solver = None
+    torch.cuda.synchronize()
+    out = scp.run_driving_reduced(model, num_scp_iters_max=iters, verbose=False)
+    st = model.monte_carlo_statistics(out["us"], alpha=alpha)
+    return {"system": "driving", "M": M, "S": S, "alpha": alpha, "iters": iters,
+            "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
+            "cumulative_s": float(out["cumulative_s"][-1]), "cuts_max": int(out["cuts"].max()),
+            "L2_error_last": float(out["L2_error"][-1]),
+            "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
+
+
 def configs_block(args, device, stats, rdist, dist, torch):
     """BASELINE.json's other single-GPU configurations (C2 drone M=1e4 S=50, C3 driving M=1e4 S=40, C4 hopper M=5e4
     S=60 / 40 contacts, C5's shard: driving 125,000 samples per GPU S=40) as whole steps, after and outside the timed
@@ -732,6 +753,8 @@ def main():
                         delattr(w, attr)
             torch.cuda.empty_cache()
             line["configs"] = configs_block(args, device, stats, rdist, dist, torch)
+            if not args.no_scp:
+                line["scp_driving"] = scp_driving_block(device)
         if world == 1 and not args.no_cpu_baseline:
             n = args.cpu_samples or CPU_SAMPLES[args.workload] or M
             cpu_step = work.cpu_baseline(n, args.alpha)

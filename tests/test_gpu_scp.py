@@ -740,3 +740,31 @@ def test_driving_reduced_solve_rollout_equals_explicit():
         np.testing.assert_allclose(u_r, u_e, rtol=0, atol=1e-5)
         assert abs(t_r - t_e) < 1e-5
         us = u_r
+
+
+@pytest.mark.parametrize("system", ["drone", "driving"])
+def test_one_call_round_trip_equals_the_stepwise_calls(system):
+    """rato_cut_oracle_rollout (x in the kernel arguments, rowmax, selection, cut sums, read-back, synchronisation in one
+    library call) against the same round trip issued call by call through device memory: identical m values, arg-max
+    rows, statistics and cut sums."""
+    import torch
+    from riskaversetrajopt_amd import stats
+    if system == "drone":
+        o, d = _drone(3000, 30, alpha=0.1, seed=5)
+    else:
+        o, d = _car(3000, 30, alpha=0.1, seed=5)
+    us = d.initial_guess_us_mat()
+    for it in range(3):
+        us, _, _ = d.solve_reduced(us, it)                    # leaves a solver with the table-free oracle configured
+    cs = d._cut_solver
+    assert cs.rollout is not None and cs.world == 1
+    rng = np.random.RandomState(2)
+    u = np.asarray(us, dtype=np.float64).reshape(-1) + 0.05 * rng.randn(cs.nU)
+    phi, t, g = cs.evaluate(None, None, 0, None, u, slot=3)
+    one = (cs.ring_m[3].clone(), cs.ring_arg[3].clone(), cs.ring_res[3].clone())
+    sign, x0 = cs._form()
+    cs._evaluate_stepwise(None, None, 0, None, np.ascontiguousarray(u - x0), sign, cs.ring_m[4], cs.ring_arg[4], cs.ring_res[4])
+    assert torch.equal(one[0], cs.ring_m[4]) and torch.equal(one[1], cs.ring_arg[4])
+    assert torch.equal(one[2], cs.ring_res[4])
+    r = cs.res_host.numpy()
+    assert np.array_equal(r, one[2].cpu().numpy()) and np.isfinite(phi) and t == r[0]
