@@ -462,7 +462,10 @@ def test_reduced_baseline_scp_matches_full_qp_scp(system, M):
 
 
 @pytest.mark.parametrize("system,M,alpha,S", [("drone", 200, 0.1, 20), ("drone", 10000, 0.05, 20), ("driving", 200, 0.1, 20),
-                                              ("driving", 10000, 0.05, 20), ("drone", 3000, 0.1, 50), ("driving", 3000, 0.05, 40)])
+                                              ("driving", 10000, 0.05, 20), ("drone", 3000, 0.1, 50), ("driving", 3000, 0.05, 40),
+                                              # horizons whose x no longer fits the kernel arguments of the one-call round
+                                              # trip (S n_u > 192: it is uploaded instead) and ragged sample counts
+                                              ("drone", 301, 0.1, 70), ("driving", 333, 0.1, 100)])
 def test_reduced_subproblems_device_vs_fp64_host_oracle(system, M, alpha, S):
     """The benchmarked path (device linearization in fp32, device cut oracle) against the SAME algorithm run entirely
     in fp64 on the fp64 oracle's linearization (tests/_host_cuts.py; its equality with the reference's full QP is a CPU
