@@ -76,7 +76,7 @@ extern "C" {
  * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
  * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
  * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
- * rato_copy_async, rato_stream_synchronize).
+ * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
 #define RATO_ABI_VERSION 8
 int rato_abi_version(void);
@@ -620,6 +620,13 @@ int rato_risk_stats_init(void* workspace, size_t workspace_bytes, void* stream);
 #define RATO_N_STATS 11
 int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
                     void* workspace, size_t workspace_bytes, double* out, void* stream);
+
+/* Recovery path: the same statistics by the launch-per-pass form (which waits for nothing) on a workspace re-initialised
+ * on the stream.  For a caller whose rato_risk_stats record came back NaN although Z is finite -- the one-launch forms
+ * give up, loudly, when the workgroups of their launch could not run together for seconds or the workspace was left
+ * unclean by an aborted call.  The Python facades do this by themselves (stats.risk_stats, CvarCutSolver.evaluate). */
+int rato_risk_stats_recover(const float* Z, int64_t M, double alpha, float thr,
+                            void* workspace, size_t workspace_bytes, double* out, void* stream);
 
 /* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
  * M <= 1,048,576 (the partial-sum workgroups ride along with the selection workgroups; two stream-ordered calls

@@ -797,7 +797,7 @@ extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
 namespace {
 int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
                     double* out, const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
-                    void* stream) {
+                    void* stream, bool recover = false) {
   RATO_CLEAR_ERROR();
   if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
     return RATO_EINVAL;
@@ -816,7 +816,8 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   Workspace* ws = static_cast<Workspace*>(workspace);
   const int sp_blocks = part ? (ncols + SP_COLS - 1) / SP_COLS : 0;
   // RATO_RS_PATH=multi: diagnostic override (A/B timing of the launch structure; tools/stats_time.py)
-  static const int force_multi = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'm') ? 1 : 0; }();
+  static const int force_multi_env = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'm') ? 1 : 0; }();
+  const int force_multi = force_multi_env || recover;   // recover: the launch-per-pass form, which waits for nothing
   static const int force_coop = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'c') ? 1 : 0; }();
   if (M <= RS_SMALL_MAX && !force_multi && !force_coop) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
     hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out,
@@ -872,6 +873,16 @@ extern "C" int rato_risk_stats_init(void* workspace, size_t workspace_bytes, voi
 extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
                                size_t workspace_bytes, double* out, void* stream) {
   return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream);
+}
+
+// Recovery path of the one-launch forms: a call that ended in NaN statistics (its wait for the workgroups of its own launch
+// gave up -- a chip some other stream owned for seconds -- or it found the workspace unclean) is repeated with the
+// workspace re-initialised on the stream and the selection as five stream-ordered launches that wait for nothing.
+extern "C" int rato_risk_stats_recover(const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                                       size_t workspace_bytes, double* out, void* stream) {
+  const int rc = rato_risk_stats_init(workspace, workspace_bytes, stream);
+  if (rc != RATO_OK) return rc;
+  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream, true);
 }
 
 extern "C" int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int32_t ncols, double scale,

@@ -184,6 +184,11 @@ class CvarCutSolver:
         else:
             self._evaluate_stepwise(G, W, tile, base, x, sign, m_buf, arg_buf, res)
         r = self.res_host.numpy()
+        if np.isnan(r[0]) and stats.count_nonfinite(m_buf) == 0:
+            # finite m values, NaN statistics: the one-launch selection gave up (a chip some other stream owned for
+            # seconds, an unclean workspace) -- the same round trip with the launch-per-pass selection
+            self._evaluate_stepwise(G, W, tile, base, x, sign, m_buf, arg_buf, res, recover=True)
+            r = self.res_host.numpy()
         if self.check_finite and not (np.isfinite(r[3]) and np.isfinite(r[4])):      # mean and max of the m values
             raise _lib.RatoNonFiniteError("CVaR-cut oracle: non-finite constraint values m_i(u) (RATO_ENONFINITE)")
         g = np.zeros(self.nU)
@@ -195,8 +200,9 @@ class CvarCutSolver:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
 
-    def _evaluate_stepwise(self, G, W, tile, base, x, sign, m_buf, arg_buf, res):
-        """the same round trip as separate stream-ordered calls (table forms of the oracle, sharded batches)"""
+    def _evaluate_stepwise(self, G, W, tile, base, x, sign, m_buf, arg_buf, res, recover=False):
+        """the same round trip as separate stream-ordered calls (table forms of the oracle, sharded batches);
+        ``recover``: the selection by the launch-per-pass form on a re-initialised workspace"""
         S, M, n_u = self.S, self.M, self.n_u
         tstream = torch.cuda.current_stream()
         st = _lib.C.c_void_p(tstream.cuda_stream)        # one stream lookup per call
@@ -215,7 +221,8 @@ class CvarCutSolver:
                                                 _lib.ptr(base), sign, _lib.ptr(self.x_dev), n_u, _lib.ptr(m_buf),
                                                 _lib.ptr(arg_buf), st), "rato_saa_rowmax")
         m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
-        stats.risk_stats_device(m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
+        (stats.risk_stats_recover_device if recover else stats.risk_stats_device)(
+            m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
             if self.rollout is not None:
                 self._rollout_tail_rows(m_buf, arg_buf, res, None, 1, self.part, st)

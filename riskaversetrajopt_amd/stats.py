@@ -72,9 +72,33 @@ def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=Non
     return out
 
 
-def risk_stats(Z, alpha, thr=SATISFIED_THRESHOLD):
-    """-> dict with var, cvar, frac_satisfied, mean, max, ... (host floats)."""
-    out = risk_stats_device(Z, alpha, thr).cpu().numpy()
+def risk_stats_recover_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):
+    """The same record by the launch-per-pass form on a re-initialised workspace (rato_risk_stats_recover): what to call
+    when ``risk_stats_device`` came back NaN on finite input -- the one-launch forms give up, loudly, when the workgroups
+    of their launch could not run together for seconds or the workspace was left unclean."""
+    lib = _lib.load()
+    Z = _as_device_f32(Z)
+    M = Z.numel()
+    if workspace is None:
+        workspace = new_workspace(M, Z.device)
+    if out is None:
+        out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
+    _lib.check(lib.rato_risk_stats_recover(_lib.ptr(Z), M, float(alpha), float(thr), _lib.ptr(workspace),
+                                           workspace.numel(), _lib.ptr(out),
+                                           _lib.current_stream() if stream is None else stream),
+               "rato_risk_stats_recover")
+    return out
+
+
+def risk_stats(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None):
+    """-> dict with var, cvar, frac_satisfied, mean, max, ... (host floats).  A NaN record on finite input (a one-launch
+    selection that gave up) is recovered through the launch-per-pass form before it is returned."""
+    Z = _as_device_f32(Z)
+    if workspace is None:
+        workspace = new_workspace(Z.numel(), Z.device)
+    out = risk_stats_device(Z, alpha, thr, workspace=workspace).cpu().numpy()
+    if np.isnan(out[0]) and count_nonfinite(Z) == 0:
+        out = risk_stats_recover_device(Z, alpha, thr, workspace=workspace).cpu().numpy()
     return dict(zip(_STAT_NAMES, out.tolist()))
 
 

@@ -312,3 +312,24 @@ def test_one_launch_selection_waits_out_a_chip_owned_by_another_stream():
     np.testing.assert_allclose(st[1], srt[::-1][:k].astype(np.float64).mean(), rtol=1e-12)
     again = stats.risk_stats_device(Z, 0.1, workspace=ws)       # and the workspace was left clean
     assert torch.equal(again, out)
+
+
+def test_facades_recover_from_a_selection_that_gave_up():
+    """a NaN record on finite input is repeated through rato_risk_stats_recover (workspace re-initialised on the stream,
+    launch-per-pass selection) -- by stats.risk_stats and by the cut oracle's round trip -- and gives the exact answer"""
+    import torch
+    from riskaversetrajopt_amd import stats
+    M = 50000
+    Z = torch.randn(M, device="cuda")
+    ws = stats.new_workspace(M, Z.device)
+    good = stats.risk_stats(Z, 0.1, workspace=ws)
+    ws.view(torch.int32)[100] = 7                # a stale count: the one-launch form gives up and un-tags the workspace
+    torch.cuda.synchronize()
+    assert torch.isnan(stats.risk_stats_device(Z, 0.1, workspace=ws)).all()
+    ws.view(torch.int32)[100] = 7
+    rec = stats.risk_stats(Z, 0.1, workspace=ws)                       # facade: recovers by itself
+    for k in good:
+        assert rec[k] == good[k] or abs(rec[k] - good[k]) <= 1e-12 * abs(good[k]), k      # fp64 sums: equal to summation order
+    assert rec["var"] == good["var"] and rec["count_satisfied"] == good["count_satisfied"]
+    again = stats.risk_stats(Z, 0.1, workspace=ws)                     # and the workspace is usable again
+    assert again == good
