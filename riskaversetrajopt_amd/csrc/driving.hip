@@ -362,6 +362,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
 //            accumulating the row's dot product with u for g_up (driving.py:295).
 // The forward/column kernel above re-rolls the pedestrian once per column group and carries
 // 8 registers per control step; it stays as the fallback when the LDS tables do not fit.
+#ifndef RATO_CDIAG
+#define RATO_CDIAG 0             // diagnostic builds: 1 no Jacobian stores; 4 phase times of every workgroup into g_up; 5 both
+#endif
 #ifndef RATO_CROWS_NW
 #define RATO_CROWS_NW 8          // waves per workgroup (A/B builds: tools/ab.sh ... -DRATO_CROWS_NW=16)
 #endif
@@ -488,6 +491,11 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // LOOP with split > 1: the queue hands the first n_whole tiles out whole and the LAST ones as `split` row-interleaved
   // parts each (shorter last units shorten the drain of the launch, as in the drone kernel).
   const int n_units = LOOP ? n_whole + (n_tiles_total - n_whole) * split : n_tiles_total * split;
+#if RATO_CDIAG >= 4   // diagnostic builds 4 / 5 (tools/car_phases.py): where does a tile's time go?  100 MHz ticks, thread 0 / wave 0
+  unsigned long long dg_t0 = wall_clock64(), dg_prologue = 0, dg_stage = 0, dg_roll = 0, dg_rows = 0, dg_next = 0, dg_mark = 0;
+  int dg_tiles = 0;
+  dg_mark = wall_clock64();
+#endif
   for (int unit = (int)blockIdx.x; unit < n_units;) {
   int tile, part_id, row_split;
   if (LOOP && unit < n_whole) {
@@ -555,6 +563,14 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     }
   }
   __syncthreads();
+#if RATO_CDIAG >= 4
+  if (threadIdx.x == 0) {
+    const unsigned long long now = wall_clock64();
+    dg_stage += now - dg_mark;
+    dg_mark = now;
+    ++dg_tiles;
+  }
+#endif
   // final rows (sample independent: driving.py:283-288, :311): workgroup 0 propagates one control column per thread
   if (tile == 0 && part_id == 0 && (final_du || final_rhs)) {
     const int NC = 2 * S;
@@ -627,6 +643,13 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       xi = xi_n;
       e = e_n;
     }
+#if RATO_CDIAG >= 4
+    if (threadIdx.x == 0) {
+      const unsigned long long now = wall_clock64();
+      dg_roll += now - dg_mark;
+      dg_mark = now;
+    }
+#endif
   }
 
   // ---- phase 2: row tasks in ascending order (task S: Z = max_t g_t - tol from the q table)
@@ -685,7 +708,11 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         q2 += f2;
         qv2 = nqv2;
         acc2 = E2 * u2 + acc2;                                          // d g_t / d u_{k-1, 0|1} = E2
+#if RATO_CDIAG == 1 || RATO_CDIAG == 5   // diagnostic builds: everything but the Jacobian stores (the condition is never true)
+        if (valid && E2.x == 123.456f) {
+#else
         if (valid) {
+#endif
           float* __restrict__ o = Grow + (k - 1) * (2 * RT);
           o[lane] = E2.x;
           o[RT + lane] = E2.y;
@@ -699,11 +726,32 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // ---- next tile
   if (!LOOP) break;
   __syncthreads();   // every wave has finished this tile's rows: the sample tables are dead, head[] may be rewritten
+#if RATO_CDIAG >= 4
+  if (threadIdx.x == 0) {
+    const unsigned long long now = wall_clock64();
+    dg_rows += now - dg_mark;
+    dg_mark = now;
+  }
+#endif
   if (threadIdx.x == 0)
     head[2] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   unit = head[2];
+#if RATO_CDIAG >= 4
+  if (threadIdx.x == 0) {
+    const unsigned long long now = wall_clock64();
+    dg_next += now - dg_mark;
+    dg_mark = now;
+  }
+#endif
   }  // unit loop
+#if RATO_CDIAG >= 4
+  if (threadIdx.x == 0 && (size_t)(blockIdx.x + 1) * 8 <= (size_t)S * M) {
+    float* o = g_up + (size_t)blockIdx.x * 8;
+    o[0] = (float)dg_tiles; o[1] = (float)dg_stage; o[2] = (float)dg_roll; o[3] = (float)dg_rows; o[4] = (float)dg_next;
+    o[5] = (float)(wall_clock64() - dg_t0); o[6] = (float)dg_prologue; o[7] = 0.f;
+  }
+#endif
   if (LOOP && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == gridDim.x - 1) {
