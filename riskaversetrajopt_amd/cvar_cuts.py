@@ -95,6 +95,9 @@ class CvarCutSolver:
         self.P = sp.block_diag([Pu, sp.csc_matrix([[float(slack_penalty)]])], format="csc")
         self.q = np.zeros(n)
         self.q[-1] = float(slack_penalty)
+        self._Pd, self._I = self.P.toarray(), np.eye(n)
+        off = self._Pd - np.diag(np.diagonal(self._Pd))
+        self._p_diag = np.ascontiguousarray(np.diagonal(self._Pd)) if not off.any() else None   # diagonal cost matrix R
         if mode == 'saa':
             self.alpha = float(alpha)
             self.alphaM = self.alpha * self.M_total           # tail mass of a cut
@@ -343,15 +346,14 @@ class CvarCutSolver:
             self.set_linearization_point(new_lin)       # (solve_reduced has usually done this before enqueueing work)
         F = np.hstack([np.asarray(final_du, dtype=np.float64), np.zeros((np.shape(final_du)[0], 1))])
         f = np.asarray(final_rhs, dtype=np.float64)
-        Pd = self.P.toarray()
-        I = np.eye(n)
+        Pd, I = self._Pd, self._I                       # (dense P, identity: built once)
         info = {"oracle_s": 0.0, "master_s": 0.0}
         phi = tstar = np.nan
         status = "solved"
         n_cuts = 0
         slack_row = with_cvar and self.mode == 'saa'    # -slack <= 0 (relaxed with the CVaR rows; absent in 'baseline')
         t0 = time.perf_counter()
-        master = dense_qp.Master(Pd, self.q, F, f)      # equality elimination + whitening once per SCP iteration
+        master = dense_qp.Master(Pd, self.q, F, f, p_diag=self._p_diag)   # equality elimination + whitening once per SCP iteration
         n_rows = 0
         if slack_row:
             master.add_rows(-I[nU:], [0.0])             # slack >= 0
