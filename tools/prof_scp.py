@@ -12,3 +12,4 @@ out = scp.run_drone_reduced(model, num_scp_iters_max=60)
 pr.disable()
 print("cumulative_s", out["cumulative_s"][-1])
 pstats.Stats(pr).sort_stats("cumulative").print_stats(38)
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)
