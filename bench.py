@@ -754,7 +754,10 @@ def main():
             torch.cuda.empty_cache()
             line["configs"] = configs_block(args, device, stats, rdist, dist, torch)
             if not args.no_scp:
-                line["scp_driving"] = scp_driving_block(device)
+                try:                                      # an extra block: its failure must not cost the metric line
+                    line["scp_driving"] = scp_driving_block(device)
+                except Exception as e:                    # noqa: BLE001
+                    line["scp_driving"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             n = args.cpu_samples or CPU_SAMPLES[args.workload] or M
             cpu_step = work.cpu_baseline(n, args.alpha)
