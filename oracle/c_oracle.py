@@ -22,6 +22,18 @@ def load(build=True):
         _lib.rato_oracle_drone_stream.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 8 + [C.c_int]
         _lib.rato_oracle_drone_stream.restype = None
         _lib.rato_oracle_max_threads.restype = C.c_int
+        ip = C.POINTER(C.c_int)
+        _lib.rato_oracle_drone_rowmax.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 6 + [ip, C.c_int]
+        _lib.rato_oracle_drone_rowmax.restype = None
+        _lib.rato_oracle_drone_tail_rows.argtypes = ([C.c_int, C.c_int, C.c_double] + [dp] * 4 + [C.c_int, dp, ip, dp, dp,
+                                                                                              C.c_int])
+        _lib.rato_oracle_drone_tail_rows.restype = None
+        _lib.rato_oracle_car.argtypes = [C.c_int, C.c_int] + [dp] * 9 + [C.c_int]
+        _lib.rato_oracle_car.restype = None
+        _lib.rato_oracle_car_rowmax.argtypes = [C.c_int, C.c_int] + [dp] * 7 + [ip, C.c_int]
+        _lib.rato_oracle_car_rowmax.restype = None
+        _lib.rato_oracle_car_tail_rows.argtypes = [C.c_int, C.c_int] + [dp] * 5 + [C.c_int, dp, ip, dp, dp, C.c_int]
+        _lib.rato_oracle_car_tail_rows.restype = None
     return _lib
 
 
@@ -63,6 +75,76 @@ def drone_stream(us, DWs, masses, obs_Qs, dt, nthreads=0):
     lib.rato_oracle_drone_stream(M, S, float(dt), _p(us), _p(DWs), _p(masses), _p(obs_Qs), _p(out["sum_final_du"]),
                                  _p(out["sum_val_final"]), _p(out["Z"]), _p(out["checksum"]), int(nthreads))
     return out
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class DroneCutOracle:
+    """Streaming fp64 cut oracle on a drone batch (rato_oracle_drone_rowmax / _tail_rows): rows of the reference's QP
+    (drone_risk.py:357-364, without kappa, y_i, t) formed one sample at a time, nothing stored per sample."""
+
+    def __init__(self, DWs, masses, obs_Qs, dt, nthreads=0):
+        self.DWs, self.masses, self.obs_Qs = _f64(DWs), _f64(masses), _f64(obs_Qs)
+        self.M, self.S, self.dt, self.nU, self.nthreads = self.DWs.shape[0], self.DWs.shape[1], float(dt), 3 * self.DWs.shape[1], nthreads
+
+    def rowmax(self, us_k, u):
+        """-> (m (M,), arg (M,)):  m_i = max_r (G_i(u_k) u - g_up_i(u_k))_r"""
+        m, arg = np.empty(self.M), np.empty(self.M, dtype=np.int32)
+        load().rato_oracle_drone_rowmax(self.M, self.S, self.dt, _p(_f64(us_k)), _p(_f64(u).reshape(-1)), _p(self.DWs),
+                                        _p(self.masses), _p(self.obs_Qs), _p(m), _ip(arg), int(self.nthreads))
+        return m, arg
+
+    def tail_rows(self, us_k, w, arg):
+        """w, arg (K, M) -> (sum_i w_ki G_i[arg_ki] (K, nU), sum_i w_ki g_up_i[arg_ki] (K,))"""
+        w, arg = np.atleast_2d(_f64(w)), np.ascontiguousarray(np.atleast_2d(arg), dtype=np.int32)
+        K = w.shape[0]
+        grad, gup = np.empty((K, self.nU)), np.empty(K)
+        load().rato_oracle_drone_tail_rows(self.M, self.S, self.dt, _p(_f64(us_k)), _p(self.DWs), _p(self.masses),
+                                           _p(self.obs_Qs), K, _p(w), _ip(arg), _p(grad), _p(gup), int(self.nthreads))
+        return grad, gup
+
+    def final_rows(self, us_k):
+        """-> sample means (final_du (6, 3S), val_final (6,)) of drone_risk.py:294-300"""
+        st = drone_stream(us_k, self.DWs, self.masses, self.obs_Qs, self.dt, self.nthreads)
+        return st["sum_final_du"] / self.M, st["sum_val_final"] / self.M
+
+
+def car(us, states_init, omegas_speed, omegas_rep, DWs, nthreads=0):
+    """Driving, all samples, dense -> dict(xs (M,S+1,8), g_obs_du (M,S,2S), g_up (M,S), Z (M,))."""
+    DWs = _f64(DWs)
+    M, S = DWs.shape[0], DWs.shape[1]
+    out = {"xs": np.empty((M, S + 1, 8)), "g_obs_du": np.empty((M, S, 2 * S)), "g_up": np.empty((M, S)), "Z": np.empty(M)}
+    load().rato_oracle_car(M, S, _p(_f64(us)), _p(_f64(states_init)), _p(_f64(omegas_speed)), _p(_f64(omegas_rep)), _p(DWs),
+                           _p(out["xs"]), _p(out["g_obs_du"]), _p(out["g_up"]), _p(out["Z"]), int(nthreads))
+    return out
+
+
+class CarCutOracle:
+    """Streaming fp64 cut oracle on a driving batch (driving.py:358-363 rows, one sample at a time)."""
+
+    def __init__(self, states_init, omegas_speed, omegas_rep, DWs, nthreads=0):
+        self.x0, self.ws, self.wr, self.DWs = _f64(states_init), _f64(omegas_speed), _f64(omegas_rep), _f64(DWs)
+        self.M, self.S, self.nU, self.nthreads = self.DWs.shape[0], self.DWs.shape[1], 2 * self.DWs.shape[1], nthreads
+
+    def rowmax(self, us_k, u):
+        m, arg = np.empty(self.M), np.empty(self.M, dtype=np.int32)
+        load().rato_oracle_car_rowmax(self.M, self.S, _p(_f64(us_k)), _p(_f64(u).reshape(-1)), _p(self.x0), _p(self.ws),
+                                      _p(self.wr), _p(self.DWs), _p(m), _ip(arg), int(self.nthreads))
+        return m, arg
+
+    def tail_rows(self, us_k, w, arg):
+        w, arg = np.atleast_2d(_f64(w)), np.ascontiguousarray(np.atleast_2d(arg), dtype=np.int32)
+        K = w.shape[0]
+        grad, gup = np.empty((K, self.nU)), np.empty(K)
+        load().rato_oracle_car_tail_rows(self.M, self.S, _p(_f64(us_k)), _p(self.x0), _p(self.ws), _p(self.wr), _p(self.DWs),
+                                         K, _p(w), _ip(arg), _p(grad), _p(gup), int(self.nthreads))
+        return grad, gup
 
 
 def max_threads():

@@ -193,3 +193,291 @@ void rato_oracle_drone_stream(int M, int S, double dt, const double* us, const d
   }
   if (checksum) checksum[0] = total;
 }
+
+/* =====================================================================================================================
+ * Streaming fp64 CUT ORACLE (round 4).  The reduced SCP subproblem (tests/_host_cuts.py) needs, per candidate u,
+ *     m_i(u) = max_r [ (G_i u)_r - g_up_{i,r} ]        the rows of drone_risk.py:357-364 / driving.py:358-363 without
+ *                                                       kappa, y_i, t:  g_obs_du . u - g_up,  g_up = -g + g_obs_du . u_k
+ * its arg-max row, and for a tail weighting w the sums  sum_i w_i G_i[r_i, :],  sum_i w_i g_up_i[r_i].
+ * The dense fp64 rows of M = 1e5 samples do not fit a host (drone S = 50: 18 GB), so nothing is stored per sample: each
+ * thread forms ONE sample's linearization in the reference's dense shapes (drone_sample / car_sample), consumes it and
+ * overwrites it with the next sample's.  Same arithmetic as the dense oracle (tests/test_oracle_c.py: equal to 1e-12).
+ * ===================================================================================================================== */
+
+void rato_oracle_drone_rowmax(int M, int S, double dt, const double* us_k, const double* u, const double* DWs,
+                              const double* masses, const double* obs_Qs, double* m_out, int* arg_out, int nthreads) {
+  const int nU = NU * S, R = NOBS * S;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * NX);
+    double* Phi = (double*)malloc(sizeof(double) * (size_t)(S + 1) * 3 * S * 2);
+    double* gdu = (double*)malloc(sizeof(double) * (size_t)R * nU);
+    double* gup = (double*)malloc(sizeof(double) * R);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      drone_sample(i, 0, S, dt, us_k, DWs, masses, obs_Qs, xs, Phi, NULL, NULL, NULL, gdu, gup, NULL);
+      double best = -INFINITY;
+      int arg = 0;
+      for (int r = 0; r < R; ++r) {
+        const double* row = gdu + (size_t)r * nU;
+        double dot = 0.0;
+        for (int c = 0; c < nU; ++c) dot += row[c] * u[c];
+        const double v = dot - gup[r];
+        if (v > best) { best = v; arg = r; }          /* first maximum, as numpy.argmax */
+      }
+      m_out[i] = best;
+      arg_out[i] = arg;
+    }
+    free(xs); free(Phi); free(gdu); free(gup);
+  }
+}
+
+/* K tail weightings at once (w, arg: (K, M) C order): grad_out (K, nU) = sum_i w_ki G_i[arg_ki, :],
+ * gup_out (K) = sum_i w_ki g_up_i[arg_ki].  Per-thread partial sums are added in thread order: the result does not
+ * depend on the schedule of a run. */
+void rato_oracle_drone_tail_rows(int M, int S, double dt, const double* us_k, const double* DWs, const double* masses,
+                                 const double* obs_Qs, int K, const double* w, const int* arg, double* grad_out,
+                                 double* gup_out, int nthreads) {
+  const int nU = NU * S, R = NOBS * S, W = nU + 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int nt_max = omp_get_max_threads();
+#else
+  const int nt_max = 1;
+#endif
+  double* acc_all = (double*)calloc((size_t)nt_max * K * W, sizeof(double));
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    double* acc = acc_all + (size_t)omp_get_thread_num() * K * W;
+#else
+    double* acc = acc_all;
+#endif
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * NX);
+    double* Phi = (double*)malloc(sizeof(double) * (size_t)(S + 1) * 3 * S * 2);
+    double* gdu = (double*)malloc(sizeof(double) * (size_t)R * nU);
+    double* gup = (double*)malloc(sizeof(double) * R);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      int any = 0;
+      for (int k = 0; k < K; ++k) any |= (w[(size_t)k * M + i] != 0.0);
+      if (!any) continue;
+      drone_sample(i, 0, S, dt, us_k, DWs, masses, obs_Qs, xs, Phi, NULL, NULL, NULL, gdu, gup, NULL);
+      for (int k = 0; k < K; ++k) {
+        const double wk = w[(size_t)k * M + i];
+        if (wk == 0.0) continue;
+        const int r = arg[(size_t)k * M + i];
+        const double* row = gdu + (size_t)r * nU;
+        double* a = acc + (size_t)k * W;
+        for (int c = 0; c < nU; ++c) a[c] += wk * row[c];
+        a[nU] += wk * gup[r];
+      }
+    }
+    free(xs); free(Phi); free(gdu); free(gup);
+  }
+  for (int k = 0; k < K; ++k) {
+    for (int c = 0; c < nU; ++c) grad_out[(size_t)k * nU + c] = 0.0;
+    gup_out[k] = 0.0;
+  }
+  for (int t = 0; t < nt_max; ++t)
+    for (int k = 0; k < K; ++k) {
+      const double* a = acc_all + ((size_t)t * K + k) * W;
+      for (int c = 0; c < nU; ++c) grad_out[(size_t)k * nU + c] += a[c];
+      gup_out[k] += a[nU];
+    }
+  free(acc_all);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Driving (car + pedestrian), /root/reference/car/driving.py, one sample: rollout (:186-214), forward sensitivities
+ * X_{t+1} = J_t X_t + B_t of the Euler-Maruyama step (what jacfwd of :267-276 computes), separation rows (:232-236,
+ * :269), g_up (:295).  Constants: driving_params.py:13-40.  Outputs in the reference's dense shapes:
+ *   g_obs_du (S, 2S),  g_up (S),  optionally xs (S+1, 8).
+ * ------------------------------------------------------------------------------------------------------------------- */
+#define CNX 8
+#define CNU 2
+static const double C_T = 10.0, C_BETA = 3e-2, C_SPEED_DES = 1.3;
+static const double C_EGO_W = 2.695, C_EGO_H = 1.663, C_PED_R = 0.5;
+
+static void car_sample(int i, int S, const double* us, const double* states_init, const double* omegas_speed,
+                       const double* omegas_rep, const double* DWs, double* xs, double* X, double* Xn, double* g_obs_du,
+                       double* g_up, double* zmax_out) {
+  const int nU = CNU * S;
+  const double dt = C_T / S, sq = sqrt(dt);
+  const double min_sep = C_PED_R + sqrt(C_EGO_W * C_EGO_W + C_EGO_H * C_EGO_H);
+  const double ws = omegas_speed[i], wr = omegas_rep[i];
+  const double* dW = DWs + (size_t)i * S * CNX;
+  memcpy(xs, states_init + (size_t)i * CNX, sizeof(double) * CNX);
+  memset(X, 0, sizeof(double) * CNX * nU);
+  double zmax = -INFINITY;
+  for (int t = 0; t < S; ++t) {
+    const double* x = xs + (size_t)t * CNX;
+    double* xn = xs + (size_t)(t + 1) * CNX;
+    /* force on the pedestrian (:145-158): -w_r delta/|delta| + w_s (v_des - v_y) added to BOTH components */
+    const double dx = x[0] - x[4], dy = x[1] - x[5];
+    const double r = sqrt(dx * dx + dy * dy), nx = dx / r, ny = dy / r;
+    const double fs = ws * (C_SPEED_DES - x[7]);
+    const double c = cos(x[3]), s = sin(x[3]);
+    xn[0] = x[0] + dt * x[2] * c;
+    xn[1] = x[1] + dt * x[2] * s;
+    xn[2] = x[2] + dt * us[t * CNU + 0];
+    xn[3] = x[3] + dt * us[t * CNU + 1];
+    xn[4] = x[4] + dt * x[6];
+    xn[5] = x[5] + dt * x[7];
+    xn[6] = x[6] + dt * (-wr * nx + fs) + sq * C_BETA * dW[t * CNX + 6];      /* sqrt(dt) again, :200 */
+    xn[7] = x[7] + dt * (-wr * ny + fs) + sq * C_BETA * dW[t * CNX + 7];
+    /* sensitivities: only columns < 2t are nonzero in X_t */
+    const double h00 = (1.0 - nx * nx) / r, h01 = -nx * ny / r, h11 = (1.0 - ny * ny) / r;
+    const int nc = 2 * t;
+    for (int col = 0; col < nc; ++col) {
+      const double x0 = X[0 * nU + col], x1 = X[1 * nU + col], x2 = X[2 * nU + col], x3 = X[3 * nU + col];
+      const double x4 = X[4 * nU + col], x5 = X[5 * nU + col], x6 = X[6 * nU + col], x7 = X[7 * nU + col];
+      const double d0 = x0 - x4, d1 = x1 - x5;
+      Xn[0 * nU + col] = x0 + dt * c * x2 - dt * x[2] * s * x3;
+      Xn[1 * nU + col] = x1 + dt * s * x2 + dt * x[2] * c * x3;
+      Xn[2 * nU + col] = x2;
+      Xn[3 * nU + col] = x3;
+      Xn[4 * nU + col] = x4 + dt * x6;
+      Xn[5 * nU + col] = x5 + dt * x7;
+      Xn[6 * nU + col] = x6 - dt * wr * (h00 * d0 + h01 * d1) - dt * ws * x7;
+      Xn[7 * nU + col] = x7 - dt * wr * (h01 * d0 + h11 * d1) - dt * ws * x7;
+    }
+    for (int k = 0; k < CNX; ++k) {
+      Xn[k * nU + nc] = 0.0;
+      Xn[k * nU + nc + 1] = 0.0;
+    }
+    Xn[2 * nU + nc] = dt;
+    Xn[3 * nU + nc + 1] = dt;
+    for (int k = 0; k < CNX; ++k) memcpy(X + (size_t)k * nU, Xn + (size_t)k * nU, sizeof(double) * (nc + 2));
+    /* row t: g = -(|delta_{t+1}| - min_sep), gradient -n . (X[0:2] - X[4:6]) */
+    const double ex = xn[0] - xn[4], ey = xn[1] - xn[5];
+    const double rr = sqrt(ex * ex + ey * ey), mx = ex / rr, my = ey / rr;
+    const double g = -(rr - min_sep);
+    if (g > zmax) zmax = g;
+    double dot = 0.0;
+    double* row = g_obs_du + (size_t)t * nU;
+    for (int col = 0; col < nU; ++col) {
+      double v = 0.0;
+      if (col < nc + 2) v = -(mx * (X[0 * nU + col] - X[4 * nU + col]) + my * (X[1 * nU + col] - X[5 * nU + col]));
+      row[col] = v;
+      dot += v * us[col];
+    }
+    g_up[t] = -g + dot;
+  }
+  if (zmax_out) *zmax_out = zmax;
+}
+
+/* dense form (small M; checked against the NumPy oracle): g_obs_du (M,S,2S), g_up (M,S), xs (M,S+1,8), Z (M) */
+void rato_oracle_car(int M, int S, const double* us, const double* states_init, const double* omegas_speed,
+                     const double* omegas_rep, const double* DWs, double* xs_out, double* g_obs_du, double* g_up,
+                     double* Z, int nthreads) {
+  const int nU = CNU * S;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * CNX);
+    double* X = (double*)malloc(sizeof(double) * CNX * nU);
+    double* Xn = (double*)malloc(sizeof(double) * CNX * nU);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      double z;
+      car_sample(i, S, us, states_init, omegas_speed, omegas_rep, DWs, xs, X, Xn, g_obs_du + (size_t)i * S * nU,
+                 g_up + (size_t)i * S, &z);
+      if (xs_out) memcpy(xs_out + (size_t)i * (S + 1) * CNX, xs, sizeof(double) * (size_t)(S + 1) * CNX);
+      if (Z) Z[i] = z - 3e-4;                                      /* OSQP_TOL, driving_params.py:4; driving.py:630-638 */
+    }
+    free(xs); free(X); free(Xn);
+  }
+}
+
+void rato_oracle_car_rowmax(int M, int S, const double* us_k, const double* u, const double* states_init,
+                            const double* omegas_speed, const double* omegas_rep, const double* DWs, double* m_out,
+                            int* arg_out, int nthreads) {
+  const int nU = CNU * S;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * CNX);
+    double* X = (double*)malloc(sizeof(double) * CNX * nU);
+    double* Xn = (double*)malloc(sizeof(double) * CNX * nU);
+    double* gdu = (double*)malloc(sizeof(double) * (size_t)S * nU);
+    double* gup = (double*)malloc(sizeof(double) * S);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      car_sample(i, S, us_k, states_init, omegas_speed, omegas_rep, DWs, xs, X, Xn, gdu, gup, NULL);
+      double best = -INFINITY;
+      int arg = 0;
+      for (int r = 0; r < S; ++r) {
+        const double* row = gdu + (size_t)r * nU;
+        double dot = 0.0;
+        for (int c = 0; c < nU; ++c) dot += row[c] * u[c];
+        const double v = dot - gup[r];
+        if (v > best) { best = v; arg = r; }
+      }
+      m_out[i] = best;
+      arg_out[i] = arg;
+    }
+    free(xs); free(X); free(Xn); free(gdu); free(gup);
+  }
+}
+
+void rato_oracle_car_tail_rows(int M, int S, const double* us_k, const double* states_init, const double* omegas_speed,
+                               const double* omegas_rep, const double* DWs, int K, const double* w, const int* arg,
+                               double* grad_out, double* gup_out, int nthreads) {
+  const int nU = CNU * S, W = nU + 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int nt_max = omp_get_max_threads();
+#else
+  const int nt_max = 1;
+#endif
+  double* acc_all = (double*)calloc((size_t)nt_max * K * W, sizeof(double));
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    double* acc = acc_all + (size_t)omp_get_thread_num() * K * W;
+#else
+    double* acc = acc_all;
+#endif
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(S + 1) * CNX);
+    double* X = (double*)malloc(sizeof(double) * CNX * nU);
+    double* Xn = (double*)malloc(sizeof(double) * CNX * nU);
+    double* gdu = (double*)malloc(sizeof(double) * (size_t)S * nU);
+    double* gup = (double*)malloc(sizeof(double) * S);
+#pragma omp for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      int any = 0;
+      for (int k = 0; k < K; ++k) any |= (w[(size_t)k * M + i] != 0.0);
+      if (!any) continue;
+      car_sample(i, S, us_k, states_init, omegas_speed, omegas_rep, DWs, xs, X, Xn, gdu, gup, NULL);
+      for (int k = 0; k < K; ++k) {
+        const double wk = w[(size_t)k * M + i];
+        if (wk == 0.0) continue;
+        const int r = arg[(size_t)k * M + i];
+        const double* row = gdu + (size_t)r * nU;
+        double* a = acc + (size_t)k * W;
+        for (int c = 0; c < nU; ++c) a[c] += wk * row[c];
+        a[nU] += wk * gup[r];
+      }
+    }
+    free(xs); free(X); free(Xn); free(gdu); free(gup);
+  }
+  for (int k = 0; k < K; ++k) {
+    for (int c = 0; c < nU; ++c) grad_out[(size_t)k * nU + c] = 0.0;
+    gup_out[k] = 0.0;
+  }
+  for (int t = 0; t < nt_max; ++t)
+    for (int k = 0; k < K; ++k) {
+      const double* a = acc_all + ((size_t)t * K + k) * W;
+      for (int c = 0; c < nU; ++c) grad_out[(size_t)k * nU + c] += a[c];
+      gup_out[k] += a[nU];
+    }
+  free(acc_all);
+}

@@ -105,6 +105,79 @@ class DrivingReducedOracle(_ReducedOracleModel):
         return fdu[0], flo[0], gdu, gup
 
 
+class StreamingCutSolver(HostCutSolver):
+    """The same two oracle methods on the oracle's C streaming cut oracle (oracle/saa_oracle.c, fp64, OpenMP): one
+    sample's dense linearization is formed at a time and nothing is stored per sample, so the all-fp64 leg runs at the
+    batch sizes the benchmark is quoted on (M = 1e5: the dense rows would be 18 GB).  Reference form of the rows
+    (G u - g_up, drone_risk.py:357-364): no linearization point enters the algebra."""
+
+    def __init__(self, cut_oracle, **kw):
+        super().__init__(**kw)
+        self.co, self.us_k = cut_oracle, None
+
+    def evaluate(self, G, W, tile, base, u_vec, slot=None):
+        u = np.asarray(u_vec, dtype=np.float64)
+        m, arg = self.co.rowmax(self.us_k, u)
+        w, t = self._weights(m)
+        if slot is not None:
+            self.cuts[slot] = (w, arg)
+        grad, _ = self.co.tail_rows(self.us_k, w, arg)
+        return float(w @ m) / self.alphaM, t, grad[0] / self.alphaM
+
+    def relinearize_kept_cuts(self, G, W, tile, base):
+        K = len(self.keep)
+        if K == 0:
+            return np.zeros((0, self.nU)), np.zeros(0)
+        w = np.stack([self.cuts[sl][0] for sl in self.keep])
+        arg = np.stack([self.cuts[sl][1] for sl in self.keep])
+        grad, gup = self.co.tail_rows(self.us_k, w, arg)
+        return grad / self.alphaM, self.rhs0 + gup / self.alphaM
+
+
+class _StreamingReducedModel:
+    """``solve_reduced`` / ``initial_guess_us_mat`` with the streaming fp64 cut oracle (any M)."""
+
+    def __init__(self, om, co, n_u, R, u_max, Rcost, slack_penalty, rhs0, first_cvar_iter):
+        self.o, self.co, self.first_cvar_iter = om, co, first_cvar_iter
+        self.cs = StreamingCutSolver(co, n_u=n_u, S=om.S, M=om.M, ld=om.M, R=R, alpha=om.alpha, dt=om.dt, Rcost=Rcost,
+                                     slack_penalty=slack_penalty, u_min=-u_max, u_max=u_max, mode=om.method, rhs0=rhs0)
+
+    def initial_guess_us_mat(self):
+        return self.o.initial_guess_us_mat()
+
+    def solve_reduced(self, us, scp_iter, tol=1e-10):
+        fdu, frhs = self.final_rows(us)
+        self.cs.us_k = np.asarray(us, dtype=np.float64).copy()
+        info = self.cs.solve(None, None, 0, None, fdu, frhs, u_lin=None,
+                             with_cvar=(scp_iter >= self.first_cvar_iter), tol=tol)
+        return info["us"], info["t_risk"], info
+
+
+class DroneStreamingOracle(_StreamingReducedModel):
+    def __init__(self, om, nthreads=0):
+        from oracle import c_oracle, drone as od
+        co = c_oracle.DroneCutOracle(om.DWs, om.masses, om.obs_Qs, om.dt, nthreads)
+        super().__init__(om, co, 3, 3, od.u_max, od.R, 10000.0, -1e-3 / 0.01, 2)
+
+    def final_rows(self, us):
+        return self.co.final_rows(us)
+
+
+class DrivingStreamingOracle(_StreamingReducedModel):
+    def __init__(self, om, nthreads=0):
+        from oracle import c_oracle, driving as ocar
+        co = c_oracle.CarCutOracle(om.states_init, om.omegas_speed, om.omegas_repulsive, om.DWs, nthreads)
+        super().__init__(om, co, 2, 1, ocar.u_max, ocar.R, 1000.0, 0.0, 1)
+        # the final rows only involve the ego car, which is sample-independent (driving.py:311-313 averages M equal
+        # rows): one sample of the NumPy oracle gives them
+        self._one = ocar.Model(om.states_init[:1], om.omegas_speed[:1], om.omegas_repulsive[:1], om.DWs[:1],
+                               method=om.method, alpha=om.alpha)
+
+    def final_rows(self, us):
+        fdu, flo, _, _, _ = self._one.get_all_constraints_coeffs(us)
+        return fdu[0], flo[0]
+
+
 def kkt_certificate(A, l, u, P, q, info, cut_data, *, n_c, n_u, S, M, R, kappa, alphaM, saa, u_max):
     """Optimality certificate of a reduced solution against the reference's FULL QP (its own row and column layout:
     SURVEY appendix A; ``A, l, u`` from ``get_constraints_coeffs`` / ``assemble.saa_constraints``, ``P, q`` from

@@ -776,3 +776,57 @@ def test_one_call_round_trip_equals_the_stepwise_calls(system):
         cs.ws.view(torch.int32)[100] = 7
         phi2, t2, g2 = cs.evaluate(None, None, 0, None, u, slot=5)
         assert t2 == t and abs(phi2 - phi) <= 1e-12 * max(1.0, abs(phi)) and np.allclose(g2, g, rtol=1e-12, atol=1e-15)
+
+
+def _bench_batch(system):
+    """The batch bench.py's SCP blocks run on (device Philox sampler, seed 7; drone M = 1e5, S = 50, alpha = 0.1 /
+    driving M = 1e5, S = 40, alpha = 0.05) -> (device Model, fp64 oracle Model holding the SAME fp32 numbers)."""
+    if system == "drone":
+        from oracle import drone as od
+        from riskaversetrajopt_amd import drone_risk, drone_utils
+        M, S, alpha = 100000, 50, 0.1
+        dW, mass, Qsym = drone_utils.sample_uncertain_parameters_device(M, S, seed=7)
+        d = drone_risk.Model.from_device(S, dW, mass, Qsym, 'saa', alpha, M=M)
+        DWs = np.zeros((M, S, 6))
+        DWs[:, :, 3:6] = dW[:, :, :M].permute(2, 0, 1).double().cpu().numpy()
+        Qs = Qsym[:, :, :M].double().cpu().numpy()                  # [obs][(Q00, Q01 + Q10, Q11)][M]
+        Q = np.zeros((M, 3, 3, 3))
+        Q[:, :, 0, 0], Q[:, :, 0, 1], Q[:, :, 1, 1] = Qs[:, 0].T, Qs[:, 1].T, Qs[:, 2].T
+        return d, od.Model(S, DWs, mass[:M].double().cpu().numpy(), Q, 'saa', alpha)
+    from oracle import driving as ocar
+    from riskaversetrajopt_amd import driving
+    M, S, alpha = 100000, 40, 0.05
+    dW, x0, ws, wr = driving.sample_uncertain_parameters_device(M, S, seed=7)
+    d = driving.Model.from_device(S, dW, x0, ws, wr, 'saa', alpha)
+    DWs = np.zeros((M, S, 8))
+    DWs[:, :, 6:8] = dW.permute(2, 0, 1).double().cpu().numpy()
+    x0h = np.repeat(ocar.state_init[None, :], M, axis=0)
+    x0h[:, 4:8] = x0.t().double().cpu().numpy()
+    return d, ocar.Model(x0h, ws.double().cpu().numpy(), wr.double().cpu().numpy(), DWs, method='saa', alpha=alpha)
+
+
+@pytest.mark.parametrize("system", ["drone", "driving"])
+def test_reduced_subproblems_at_the_benchmarked_size(system):
+    """North star: "SCP iterates matching reference to 1e-5" AT THE SIZE THE METRIC IS QUOTED ON.  bench.py's own
+    batch (M = 1e5; drone S = 50, driving S = 40): every subproblem of the SCP path solved by the benchmarked device
+    path (fp32 samples, table-free fp64 device oracle, recycled cuts, tol 1e-8) and by the all-fp64 leg on the
+    oracle's streaming C cut oracle (oracle/saa_oracle.c: every sample's dense linearization formed in the reference's
+    shapes, rows G u - g_up of drone_risk.py:357-364 / driving.py:358-363; == the dense NumPy leg == the reference's
+    full QP on the CPU, tests/test_reduced_host.py), from the SAME iterate -- the subproblems where the CVaR rows switch
+    on (the worst ones) included."""
+    from tests._host_cuts import DroneStreamingOracle, DrivingStreamingOracle
+    d, o = _bench_batch(system)
+    h = (DroneStreamingOracle if system == "drone" else DrivingStreamingOracle)(o)
+    iters = 9 if system == "drone" else 7
+    us = h.initial_guess_us_mat()
+    du, dtr, cuts = [], [], []
+    for k in range(iters):
+        ud, td, idv = d.solve_reduced(us, k)
+        uh, th, ih = h.solve_reduced(us, k)
+        du.append(np.abs(ud - uh).max())
+        dtr.append(abs(td - th))
+        cuts.append((idv["cuts"], ih["cuts"]))
+        us = uh
+    print(system, "M=1e5 per-subproblem max |du|:", " ".join("%.1e" % v for v in du), "| |dt_risk|:",
+          " ".join("%.1e" % v for v in dtr), "| cuts (device, fp64):", cuts)
+    assert max(du) < 1e-5 and max(dtr) < 1e-5

@@ -121,3 +121,24 @@ def test_driving_ego_final_rows_closed_form_equals_the_oracle():
         np.testing.assert_allclose(E, fdu[0], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(rhs, flo[0], rtol=1e-12, atol=1e-12)
         assert np.array_equal(fdu[0], fdu[-1])        # the ego carries no noise: the same rows for every sample
+
+
+@pytest.mark.parametrize("system", ["drone", "driving"])
+def test_streaming_fp64_leg_equals_the_dense_fp64_leg(system):
+    """tests/_host_cuts.py: StreamingCutSolver (C oracle, one sample at a time: the fp64 leg at M = 1e5 in
+    tests/test_gpu_scp.py) == HostCutSolver (NumPy, dense rows), subproblem by subproblem from the same iterate."""
+    from tests._host_cuts import DroneStreamingOracle, DrivingStreamingOracle
+    if system == "drone":
+        o = _drone(60, 20, 0.1, "saa", seed=4)
+        dense, stream, iters = DroneReducedOracle(o, delta=False), DroneStreamingOracle(o, nthreads=2), 6
+    else:
+        o = _car(48, 20, 0.1, "saa", seed=4)
+        dense, stream, iters = DrivingReducedOracle(o, delta=False), DrivingStreamingOracle(o, nthreads=2), 5
+    us = dense.initial_guess_us_mat()
+    for k in range(iters):
+        ud, td, idn = dense.solve_reduced(us, k)
+        ust, tst, ist = stream.solve_reduced(us, k)
+        assert abs(idn["cuts"] - ist["cuts"]) <= 2          # (the stopping test is a comparison against 1e-10)
+        np.testing.assert_allclose(ust, ud, rtol=0, atol=1e-9)
+        assert abs(tst - td) < 1e-9
+        us = ud
