@@ -13,7 +13,13 @@
  *   - every data pointer is a CALLER-OWNED DEVICE pointer (fp32 unless noted),
  *     e.g. torch.Tensor.data_ptr(); nothing is allocated or freed here.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls
- *     are asynchronous and stream-ordered; nothing synchronises the device.
+ *     are asynchronous and stream-ordered and never synchronise the device --
+ *     with the exceptions that exist to BE the synchronisation point of a host
+ *     loop and say so where they are declared: rato_stream_synchronize,
+ *     rato_cut_oracle_rollout (one oracle round trip of the cutting-plane loop:
+ *     its results are read by the host master) and rato_cut_solve (the whole
+ *     loop of one SCP subproblem).  Each waits for `stream` only
+ *     (hipStreamSynchronize), never for the device.
  *   - no global state beyond cached device properties (CU count, LDS attribute) and, for the row-parallel
  *     linearize kernels on large batches, one self-cleaning two-word work queue per STREAM in device memory
  *     (up to 64 streams; launches on one stream are ordered and share it, a 65th stream falls back to the static

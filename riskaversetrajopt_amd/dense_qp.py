@@ -57,19 +57,43 @@ def solve(P, q, A_eq, b_eq, A_in, b_in):
     return x0 + N @ w, lam
 
 
-_NATIVE = []
+_NATIVE = {}
+_STRICT = [False]
+
+
+def require_native(on=True):
+    """Product paths (scp.run_*_reduced on a device Model, bench.py) call this: from then on a library that cannot be
+    loaded RAISES instead of dropping to the NumPy implementations below (a ~10x slower SCP would otherwise be timed
+    without a word)."""
+    _STRICT[0] = bool(on)
+
+
+def _load_native():
+    """librato_saa.so (host-side NNLS and master QP: csrc/nnls.hip, csrc/master.hip), or None when the library is not
+    there -- ONLY then (OSError / RatoError from the loader; anything else is a bug and propagates), with one warning;
+    under ``require_native()`` the loader's error is raised instead."""
+    if "lib" not in _NATIVE:
+        from . import _lib
+        try:
+            _NATIVE["lib"] = _lib.load()
+        except (OSError, _lib.RatoError) as e:
+            if _STRICT[0]:
+                raise
+            import warnings
+            warnings.warn(f"librato_saa.so is not loadable ({e}): the master QP of the cutting-plane loop runs on its "
+                          "NumPy implementation (~10x slower); product paths call dense_qp.require_native() and raise",
+                          RuntimeWarning, stacklevel=3)
+            _NATIVE["lib"] = None
+    if _NATIVE["lib"] is None and _STRICT[0]:
+        from . import _lib
+        raise _lib.RatoError("librato_saa.so is required here (dense_qp.require_native) and could not be loaded")
+    return _NATIVE["lib"]
 
 
 def _native():
-    """librato_saa.so's host-side NNLS (csrc/nnls.hip: the same algorithm with an incrementally updated QR), or None when
-    the library cannot be loaded (then the NumPy version below runs: this module has no device code of its own)."""
-    if not _NATIVE:
-        try:
-            from . import _lib
-            _NATIVE.append(_lib.load().rato_nnls_warm)
-        except Exception:                          # pragma: no cover
-            _NATIVE.append(None)
-    return _NATIVE[0]
+    """the library's rato_nnls_warm, or None (see ``_load_native``)"""
+    lib = _load_native()
+    return None if lib is None else lib.rato_nnls_warm
 
 
 def nnls_warm(A, b, passive0=None, maxiter=None):
@@ -159,15 +183,8 @@ def _null_space(A):
 
 
 def _native_master():
-    """librato_saa.so's rato_master_* entry points (csrc/master.hip), or None when the library cannot be loaded"""
-    if len(_NATIVE) < 2:
-        _native()
-        try:
-            from . import _lib
-            _NATIVE.append(_lib.load())
-        except Exception:                          # pragma: no cover
-            _NATIVE.append(None)
-    return _NATIVE[1]
+    """the library (rato_master_* entry points, csrc/master.hip), or None (see ``_load_native``)"""
+    return _load_native()
 
 
 def Master(P, q, A_eq, b_eq, p_diag=None):

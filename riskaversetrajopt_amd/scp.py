@@ -68,6 +68,9 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
     ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
     "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop."""
     _finite_guard(model, check_finite)
+    if hasattr(model, "_lib"):                 # a device Model: its master QP must be the native one (no silent NumPy leg)
+        from . import dense_qp
+        dense_qp.require_native()
     us_prev = model.initial_guess_us_mat()
     define_s, solve_s, err, cuts, oracle_s = [], [], [], [], []
     t_risk = None

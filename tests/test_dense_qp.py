@@ -206,3 +206,31 @@ def test_native_master_equals_the_numpy_master():
     # rank-deficient equalities: the factory falls back to the NumPy master
     m2 = dense_qp.Master(np.diag(d), q, np.vstack([A_eq, A_eq[0]]), np.concatenate([b_eq, b_eq[:1]]))
     assert isinstance(m2, dense_qp.MasterPy)
+
+
+def test_missing_library_is_loud(monkeypatch):
+    """dense_qp drops to its NumPy master ONLY when the library cannot be loaded (OSError / RatoError), warns once, and
+    raises under require_native() -- which scp.run_*_reduced switches on for device Models."""
+    from riskaversetrajopt_amd import _lib, dense_qp
+    def missing():
+        raise _lib.RatoError("HIP extension is missing")
+    monkeypatch.setattr(_lib, "load", missing)
+    monkeypatch.setattr(dense_qp, "_NATIVE", {})
+    monkeypatch.setattr(dense_qp, "_STRICT", [False])
+    with pytest.warns(RuntimeWarning, match="not loadable"):
+        assert dense_qp._native_master() is None
+    assert dense_qp._native() is None                       # cached: no second warning, no second load
+    dense_qp.require_native()
+    with pytest.raises(_lib.RatoError):
+        dense_qp._native_master()
+    monkeypatch.setattr(dense_qp, "_NATIVE", {})
+    with pytest.raises(_lib.RatoError):
+        dense_qp._native()
+    # anything else the loader throws is a bug and is not swallowed
+    def broken():
+        raise AttributeError("rato_master_create")
+    monkeypatch.setattr(_lib, "load", broken)
+    monkeypatch.setattr(dense_qp, "_NATIVE", {})
+    monkeypatch.setattr(dense_qp, "_STRICT", [False])
+    with pytest.raises(AttributeError):
+        dense_qp._native_master()
