@@ -435,6 +435,9 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         if dist.is_initialized():
             dist.barrier()
 
+    if dist.is_initialized():
+        rdist.check_equal_shards(M)       # collective, once, outside the timed region: every step's all-gather relies on it
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     use_graph = world == 1 and not args.overlap and (args.graph == "on" or (args.graph == "auto" and M <= 50000))
     pipelined = args.overlap and not use_graph
@@ -474,7 +477,8 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             if getattr(work, "records", None):                # zero-copy record: [sums | Z] already in place
                 sums, Z_all = rdist.exchange_record(work.records[slot])
             else:
-                sums, Z_all = rdist.exchange(sums, r["Z"])    # the one collective (no-op at N=1)
+                sums, Z_all = rdist.exchange(sums, r["Z"], agreed=True)   # the one collective (no-op at N=1; equal
+                #                                                            shards were verified once, below)
             stats.risk_stats_device(Z_all, args.alpha, workspace=wss[slot], out=stats_out[slot])
             if pipelined:
                 ev_free[slot].record(side)

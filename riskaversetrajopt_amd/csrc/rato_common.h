@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <mutex>
 
@@ -150,11 +151,12 @@ static inline int nblocks_for(int32_t M) { return (M + RATO_BLOCK - 1) / RATO_BL
 //     torch.cuda.graph captures every graph on one shared side stream, so a stream-keyed queue would be shared by
 //     graphs that are later replayed concurrently on different streams -- two launches on one queue skip tiles.  A
 //     graph exec cannot run concurrently with itself, so one queue per captured launch is enough.  The queues of
-//     destroyed graphs are not reclaimed; when the pool is used up (RATO_QUEUES_TOTAL - RATO_QUEUES_EAGER captured
-//     launches in one process) further captured launches get none and use the static form.
+//     destroyed graphs are not reclaimed (16 KB of device words hold 1984 of them); when the pool is used up
+//     (RATO_QUEUES_TOTAL - RATO_QUEUES_EAGER captured launches in one process) further captured launches get none and
+//     use the static form, which is said once on stderr.
 // The CU count is cached per device here too (no device query inside a capture after the first, uncaptured call).
 #define RATO_QUEUES_EAGER 64
-#define RATO_QUEUES_TOTAL 256
+#define RATO_QUEUES_TOTAL 2048
 class TileQueuePool {
  public:
   // resolve(): device address of the CURRENT device's copy of the file's queue array (RATO_QUEUES_TOTAL * 2 words)
@@ -169,7 +171,14 @@ class TileQueuePool {
     }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
-      if (d.next_captured >= RATO_QUEUES_TOTAL) return nullptr;
+      if (d.next_captured >= RATO_QUEUES_TOTAL) {
+        if (!d.warned) {   // once per device and kernel file: the launch is still correct, only on the static form
+          d.warned = true;
+          fprintf(stderr, "librato_saa: work-queue pool used up (%d captured launches on device %d): further captured "
+                          "launches use the static launch form\n", RATO_QUEUES_TOTAL - RATO_QUEUES_EAGER, dev);
+        }
+        return nullptr;
+      }
       return d.base + 2 * d.next_captured++;
     }
     for (int i = 0; i < d.used; ++i)
@@ -197,6 +206,7 @@ class TileQueuePool {
     unsigned* base = nullptr;
     hipStream_t owner[RATO_QUEUES_EAGER] = {};
     int used = 0, next_captured = RATO_QUEUES_EAGER, cus = 0;
+    bool warned = false;
   };
   std::mutex mu_;
   PerDev dev_[kMaxDev];

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
     if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
   }
   flush_hist<B1, RS1_T>(h, ws->hist1);
-  unsigned b1, k1, c1, b2, k2, c2, b3, k3, c3;
+  unsigned b1 = 0, k1 = 0, c1 = 0, b2 = 0, k2 = 0, c2 = 0, b3 = 0, k3 = 0, c3 = 0;   // (a failed pass leaves them unset)
   bool ok = find_bin_coop<B1, RS1_T>(ws->hist1, k, (unsigned)n, b1, k1, c1);
   for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
   __syncthreads();

@@ -122,6 +122,11 @@ class CvarCutSolver:
         self.keep_idle = int(os.environ.get("RATO_KEEP_IDLE", 0))        # (A/B knobs: profiles/EXPERIMENTS.md, "2-cycles")
         self.u_lin = None                                # linearization point of the delta form (None: reference form)
         self._relin_pending = None                       # kept cuts whose re-linearization is already in flight
+        if self.world > 1:
+            # every collective of the loop moves buffers whose lengths follow from (M, S, n_u, keep_max): agreed on here,
+            # once, by every rank (the solver is built collectively, in the first solve_reduced after Model.shard()) --
+            # which is what lets the per-cut all-gathers skip their own length check (dist.gather_concat, agreed=True)
+            rdist.check_equal_shards(((M * 1009 + S) * 1009 + n_u) * 1009 + self.keep_max, group)
         if device is not None:                           # (None: a host oracle overrides evaluate / relinearize_kept_cuts
             self._alloc_device(device)                   #  -- tests/_host_cuts.py, the fp64 checker of this loop)
 
@@ -143,6 +148,7 @@ class CvarCutSolver:
         self.slots_host = torch.zeros(self.keep_max, dtype=torch.int32).pin_memory()
         self.ws = stats.new_workspace(self.M_total, device)
         self.res_host = torch.zeros(self.nres, dtype=torch.float64).pin_memory()
+        self.agree_host = torch.zeros(1, dtype=torch.float64).pin_memory()   # (sharded: see _selection_gave_up)
         self.x_host = torch.zeros((S, n_u), dtype=torch.float64).pin_memory()
         self.x_dev = e(S, n_u, dt=torch.float64)
         self.uk_dev = e(S, n_u, dt=torch.float64)        # the linearization point, for the rollout form of the oracle
@@ -187,7 +193,7 @@ class CvarCutSolver:
         else:
             self._evaluate_stepwise(G, W, tile, base, x, sign, m_buf, arg_buf, res)
         r = self.res_host.numpy()
-        if np.isnan(r[0]) and stats.count_nonfinite(m_buf) == 0:
+        if self._selection_gave_up(r, m_buf):
             # finite m values, NaN statistics: the one-launch selection gave up (a chip some other stream owned for
             # seconds, an unclean workspace) -- the same round trip with the launch-per-pass selection
             self._evaluate_stepwise(G, W, tile, base, x, sign, m_buf, arg_buf, res, recover=True)
@@ -202,6 +208,20 @@ class CvarCutSolver:
         else:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
+
+    def _selection_gave_up(self, r, m_buf):
+        """Did this round trip's one-launch selection give up on finite m values (-> redo it with the launch-per-pass
+        form)?  Sharded, the redo contains collectives, so the answer must be THE SAME ON EVERY RANK: it is taken from
+        what every rank holds identically -- the rank-ordered sum of the ranks' thresholds t*, which travels with the
+        cut sums (a selection that gave up leaves NaN in every slot of its record, and one NaN poisons the sum on every
+        rank), and the gathered m values -- never from this rank's own statistics or its own shard of m."""
+        if self.world == 1:
+            return bool(np.isnan(r[0])) and stats.count_nonfinite(m_buf) == 0
+        if self.S > 1:
+            nan_here = bool(np.isnan(self.agree_host.numpy()[0]))
+        else:                                       # no cut sums travel when S = 1: agree explicitly
+            nan_here = rdist.any_rank(bool(np.isnan(r[0])), self.device, self.group)
+        return nan_here and stats.count_nonfinite(self._m_all) == 0
 
     def _evaluate_stepwise(self, G, W, tile, base, x, sign, m_buf, arg_buf, res, recover=False):
         """the same round trip as separate stream-ordered calls (table forms of the oracle, sharded batches);
@@ -223,7 +243,8 @@ class CvarCutSolver:
             _lib.check(self.lib.rato_saa_rowmax(_lib.ptr(G), _lib.ptr(W), tile, self.R, S, M, self.ld,
                                                 _lib.ptr(base), sign, _lib.ptr(self.x_dev), n_u, _lib.ptr(m_buf),
                                                 _lib.ptr(arg_buf), st), "rato_saa_rowmax")
-        m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group)
+        m_all = m_buf if self.world == 1 else rdist.gather_concat(m_buf, self.group, agreed=True)
+        self._m_all = m_all
         (stats.risk_stats_recover_device if recover else stats.risk_stats_device)(
             m_all, self.alpha, workspace=self.ws, out=res[:stats.N_STATS], stream=st)
         if S > 1:
@@ -242,7 +263,11 @@ class CvarCutSolver:
                     st), "rato_saa_tail_rows_batch")
             stats.sum_partials(self.part, out=res[stats.N_STATS:], stream=st)
             if self.world > 1:
-                res[stats.N_STATS:].copy_(rdist.sum_in_rank_order(res[stats.N_STATS:], self.group))
+                # [t* | cut sums] in one collective: the sum of the ranks' t* is NaN on EVERY rank as soon as one rank's
+                # selection gave up (``_selection_gave_up``)
+                tot = rdist.sum_in_rank_order(res[stats.N_STATS - 1:], self.group, agreed=True)
+                res[stats.N_STATS:].copy_(tot[1:])
+                self.agree_host.copy_(tot[:1], non_blocking=True)
         self.res_host.copy_(res, non_blocking=True)
         tstream.synchronize()
 
@@ -319,7 +344,7 @@ class CvarCutSolver:
             stats.sum_partials(part, out=self.sums_b_host[:K * self.nc], stream=st)
             return K
         stats.sum_partials(part, out=self.sums_b[:K * self.nc], stream=st)
-        self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group))
+        self.sums_b[:K * self.nc].copy_(rdist.sum_in_rank_order(self.sums_b[:K * self.nc], self.group, agreed=True))
         _lib.copy_async(self.sums_b_host, self.sums_b, st)
         return K
 

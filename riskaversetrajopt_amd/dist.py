@@ -145,7 +145,6 @@ def transport(group=None):
 
 def destroy_comms():
     from . import _lib
-    _EQUAL_CHECKED.clear()
     for comm in _COMMS.values():
         if comm is not None:
             _lib.load().rato_comm_destroy(comm)
@@ -168,17 +167,18 @@ def unpack_records(buf, world, n_sums, M_local):
     return sums, Z
 
 
-def exchange(sums64, Z32, group=None):
+def exchange(sums64, Z32, group=None, agreed=False):
     """The single collective of an evaluation.  ``sums64``: rank-local fp64 sums
     (any shape), ``Z32``: rank-local fp32 Z (M_local,) — equal M_local on all
-    ranks.  Returns (total_sums (like sums64), Z_all (world*M_local,))."""
+    ranks (verified on every call unless ``agreed``: see ``gather_concat``).
+    Returns (total_sums (like sums64), Z_all (world*M_local,))."""
     if not (dist.is_available() and dist.is_initialized()) or \
             (dist.get_world_size(group) == 1 and os.environ.get("RATO_FORCE_DIST") != "1"):
         return sums64, Z32
     world = dist.get_world_size(group)
     n_sums, M_local = sums64.numel(), Z32.numel()
     rec = pack_record(sums64.reshape(-1).to(torch.float64), Z32.to(torch.float32))
-    out = gather_concat(rec, group)
+    out = gather_concat(rec, group, agreed)
     sums, Z_all = unpack_records(out, world, n_sums, M_local)
     total = sums[0].clone()
     for r in range(1, world):          # fixed (rank) order: bitwise identical on every rank
@@ -260,19 +260,19 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-_EQUAL_CHECKED = set()
+def gather_concat(t, group=None, agreed=False):
+    """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank).
 
-
-def gather_concat(t, group=None):
-    """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank).  The equal length
-    is verified once per (group, length, dtype) with one tiny collective (``check_equal_shards``): a mismatched RCCL
-    all-gather hangs or corrupts silently."""
+    A mismatched RCCL all-gather hangs or corrupts silently, so the equal length is verified with one tiny collective
+    (``check_equal_shards``) on EVERY call -- unless the caller states ``agreed=True``: the length follows from
+    quantities the ranks have already agreed on collectively (``Model.shard()`` checks M; the cutting-plane solver
+    checks its (M, S, n_u) once when it is built).  ``agreed`` is a property of the call site, the same on every rank;
+    whether the check runs is never decided from a rank-local value (a per-rank cache keyed on the local length would
+    send a rank whose length changed into the check while the others are already in the all-gather)."""
     world = dist.get_world_size(group)
     src = t.contiguous()
-    key = (group, src.numel(), src.dtype)
-    if key not in _EQUAL_CHECKED:
+    if not agreed:
         check_equal_shards(src.numel(), group)
-        _EQUAL_CHECKED.add(key)
     comm = device_comm(group) if src.is_cuda else None
     if comm is not None:
         from . import _lib
@@ -290,14 +290,23 @@ def gather_concat(t, group=None):
     return out
 
 
-def sum_in_rank_order(t, group=None):
+def sum_in_rank_order(t, group=None, agreed=False):
     """Sum of a small tensor over the ranks, added in rank order: bitwise identical on every rank."""
     world = dist.get_world_size(group)
-    parts = gather_concat(t.reshape(-1), group).view(world, -1)
+    parts = gather_concat(t.reshape(-1), group, agreed).view(world, -1)
     total = parts[0].clone()
     for r in range(1, world):
         total += parts[r]
     return total.view(t.shape)
+
+
+def any_rank(flag, device, group=None):
+    """Collective: True on every rank iff ``flag`` is true on at least one (one 4-byte MAX all-reduce)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
 
 
 def broadcast_from_rank0(arr, device, group=None):

@@ -388,8 +388,11 @@ class Model:
         import torch.distributed as tdist
         from . import dist as rdist
         rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
+        rdist.check_equal_shards(self.S, group)          # (... or the horizons: the lengths of every exchanged buffer)
         self._group, self._world = group, tdist.get_world_size(group)
-        self._cut_solver = None
+        # buffers a single-process solve_reduced may have left behind are single-process shaped (pinned HOST sums that
+        # the partial-sum kernel writes into directly): a sharded solve must not inherit them
+        self._cut_solver = self._gen_buffers = self._lin_buffers = self._define_host = None
         return self
 
     def ego_final_rows(self, us_mat):
@@ -447,8 +450,10 @@ class Model:
             final_du, final_rhs = self.ego_final_rows(us_mat_p)
             if self.check_finite and not (np.isfinite(final_du).all() and np.isfinite(final_rhs).all()):
                 raise _lib.RatoNonFiniteError("driving final rows: non-finite values (RATO_ENONFINITE)")
+            # unconditionally: the upload of u_k to the device happens only while cs.rollout is set, so a table-form call
+            # at the same u before this one must not leave the rollout kernels reading a stale uk_dev
+            cs.set_linearization_point(u_lin)
             if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
-                cs.set_linearization_point(u_lin)
                 cs.enqueue_relinearize(None, None, 0, None)
             info = cs.solve(None, None, 0, None, final_du, final_rhs, u_lin=u_lin, with_cvar=(scp_iter >= 1), tol=tol,
                             verbose=verbose)
@@ -456,8 +461,8 @@ class Model:
         cs.rollout = None
         r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), rows_out=1 if delta else 0)
         self._lin_buffers = r
+        cs.set_linearization_point(u_lin)
         if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
-            cs.set_linearization_point(u_lin)
             cs.enqueue_relinearize(r["G"], None, r["tile"], r["g_up"])      # one device round trip with the read-backs below
         info = cs.solve(r["G"], None, r["tile"], r["g_up"], r["final_du"].double().cpu().numpy(),
                         r["final_rhs"].double().cpu().numpy(), u_lin=u_lin,

@@ -573,8 +573,11 @@ class Model:
         import torch.distributed as tdist
         from . import dist as rdist
         rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
+        rdist.check_equal_shards(self.S, group)          # (... or the horizons: the lengths of every exchanged buffer)
         self._group, self._world = group, tdist.get_world_size(group)
-        self._cut_solver = None
+        # buffers a single-process solve_reduced may have left behind are single-process shaped (pinned HOST sums that
+        # the partial-sum kernel writes into directly): a sharded solve must not inherit them
+        self._cut_solver = self._gen_buffers = self._lin_buffers = self._define_host = None
         return self
 
     def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-8, verbose=False, implicit=True, generators_only=None,

@@ -92,3 +92,33 @@ def test_single_process_exchange_is_identity():
     sums, Z = torch.ones(3, dtype=torch.float64), torch.zeros(4)
     a, b = rdist.exchange(sums, Z)
     assert a is sums and b is Z
+
+
+def _mismatch_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from riskaversetrajopt_amd import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    ok = rdist.gather_concat(torch.arange(5, dtype=torch.float32) + rank)           # equal lengths: fine
+    assert ok.numel() == 10
+    # a LATER call where only ONE rank's length changed: a rank-local cache keyed on the local length would send that
+    # rank into the length check while the other, finding its length cached, is already in the all-gather -- every
+    # rank must raise instead
+    n = 5 if rank == 0 else 6
+    try:
+        rdist.gather_concat(torch.zeros(n))
+        outcome = "no error"
+    except ValueError as e:
+        outcome = "ValueError" if "differ" in str(e) else repr(e)
+    flags = [rdist.any_rank(rank == 1, "cpu"), rdist.any_rank(False, "cpu")]
+    with open(os.path.join(tmpdir, f"mismatch_{rank}.txt"), "w") as f:
+        f.write(f"{outcome} {flags}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_concat_length_mismatch_raises_on_every_rank_after_a_good_call(tmp_path):
+    world = 2
+    mp.spawn(_mismatch_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"mismatch_{r}.txt").read_text() == "ValueError [True, False]"

@@ -128,3 +128,43 @@ def test_sharded_step_record_exchange_equals_single_process(tmp_path):
     st = stats.risk_stats_device(r["Z"], 0.1).cpu().numpy()
     np.testing.assert_array_equal(a[n:n + stats.N_STATS], st)                                   # exact selection on the same Z
     np.testing.assert_allclose(a[:n], r["sums"].cpu().numpy(), rtol=1e-6, atol=1e-4)  # fp32 block partials differ
+
+
+def _poison_worker(rank, world, port, M, S, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from riskaversetrajopt_amd import dist as rdist, drone_risk
+    rdist.init_from_env(backend="gloo")
+    DWs, masses, Q = _samples(M, S)
+    lo, hi = rdist.shard_bounds(M, rank, world)
+    model = drone_risk.Model(S, DWs[lo:hi], masses[lo:hi], Q[lo:hi], 'saa', 0.1).shard()
+    us = model.initial_guess_us_mat()
+    for k in range(6):
+        if k == 3 and rank == 1:
+            # ONE rank's selection workspace holds a stale count: its one-launch selection gives up (NaN record) while
+            # rank 0's succeeds -- the redo contains collectives, so both ranks must take it together
+            model._cut_solver.ws.view(torch.int32)[100] = 7
+            torch.cuda.synchronize()
+        us, t_risk, info = model.solve_reduced(us, k)
+    np.save(os.path.join(tmpdir, f"poison_us_{rank}.npy"), us)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_oracle_recovers_together_when_one_rank_gives_up(tmp_path):
+    """the NaN-recovery branch of CvarCutSolver.evaluate re-runs collectives, so whether it is taken must be
+    the same on every rank (decided from the rank-ordered sum of the ranks' thresholds, not from a rank's own record)."""
+    import torch.multiprocessing as mp
+    from riskaversetrajopt_amd import drone_risk
+    M, S, world = 16000, 20, 2                       # M_total > 12,288: the one-launch cooperative selection
+    mp.spawn(_poison_worker, args=(world, _free_port(), M, S, str(tmp_path)), nprocs=world, join=True)
+    us0, us1 = np.load(tmp_path / "poison_us_0.npy"), np.load(tmp_path / "poison_us_1.npy")
+    assert np.array_equal(us0, us1)
+    DWs, masses, Q = _samples(M, S)
+    single = drone_risk.Model(S, DWs, masses, Q, 'saa', 0.1)
+    us = single.initial_guess_us_mat()
+    for k in range(6):
+        us, _, _ = single.solve_reduced(us, k)
+    np.testing.assert_allclose(us0, us, rtol=0, atol=2e-5)
