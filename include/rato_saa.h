@@ -66,6 +66,10 @@ extern "C" {
                                 Raised by the facades (check_finite=True) from rato_count_nonfinite_acc. */
 #define RATO_EINFEASIBLE (-4) /* rato_master_solve: the rows of the master QP admit no point */
 #define RATO_ENOCOMM (-3)    /* librccl could not be bound at run time (rato_comm_*) */
+#define RATO_ERANK (-6)      /* rato_cut_solve: the final rows are rank deficient / not fewer than the variables */
+#define RATO_ESELECT (-7)    /* rato_cut_solve: an oracle round trip came back with NaN statistics (the one-launch tail
+                                selection gave up, or the m values hold NaN): repeat with the recovering host loop */
+#define RATO_ENNLS (-8)      /* rato_cut_solve: the NNLS of the master did not converge */
 #define RATO_EHIP (-1000)    /* RATO_EHIP - hipError_t */
 #define RATO_ERCCL (-2000)   /* RATO_ERCCL - ncclResult_t */
 
@@ -82,9 +86,10 @@ extern "C" {
  * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
  * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
  * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
+ * (9: rato_cut_solver_* / rato_cut_begin / rato_cut_solve -- the cutting-plane loop of a subproblem as one call)
  * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 8
+#define RATO_ABI_VERSION 9
 int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
@@ -451,6 +456,87 @@ int rato_cut_oracle_rollout(int32_t system, const void* params, const double* uk
                             const float* s2, const float* s3, const double* x_host, double* x_dev, float* m_out,
                             int32_t* arg_out, double alpha, float thr, double alphaM, void* workspace,
                             size_t workspace_bytes, double* res_dev, double* part_dev, double* res_host, void* stream);
+
+/* ------------------------------------------------- the cutting-plane loop of one SCP subproblem (host, csrc/cutloop.hip)
+ *
+ * The reference hands every SCP subproblem to OSQP (drone_risk.py:425-469, driving.py:423-456).  Here the subproblem is
+ * that QP reduced exactly to (u, slack) and solved by Kelley cuts on the linearized CVaR constraint: master QP on the
+ * host (rato_master_*), cut oracle on the device (rato_cut_oracle_rollout, the table-free forms).  rato_cut_solve is
+ * that whole loop -- master, lazily entering control bounds, "the last evaluated cut joins the master", the keep rule
+ * for cuts recycled into the next subproblem, the multipliers -- as ONE call (statement for statement the loop of
+ * riskaversetrajopt_amd/cvar_cuts.py::CvarCutSolver._solve, which remains for sharded batches and the table forms; both
+ * produce bitwise the same iterates).
+ *
+ * rato_cut_config: sizes, constants and the CALLER-OWNED buffers of a solver (nothing is allocated on the device here):
+ *   system 0 drone (n_u 3, params = rato_drone_params*, s0..s2 = dW, mass, Qsym), 1 driving (n_u 2, rato_car_params*,
+ *   s0..s3 = dW, x0_ped, w_speed, w_rep); params is copied.  nU = n_u S, n = nU + 1 (u, slack), nc = 2(S-1) + 1,
+ *   nres = RATO_N_STATS + nc, nblk = ceil(M / 256).
+ *   device: uk_dev, x_dev [nU] doubles; ring_m [cap][M] floats, ring_arg [cap][M] int32, ring_res [cap][nres] doubles
+ *   (slot cap-1 is scratch); workspace of rato_risk_stats (initialised); part [nblk][nc], part_b [nblk][keep_max nc]
+ *   doubles; slots_dev [keep_max] int32.
+ *   pinned host (device-visible: the reductions write into them directly): uk_host, x_host [nU], res_host [nres],
+ *   sums_b_host [keep_max nc] doubles, slots_host [keep_max] int32.
+ *   p_diag, q [n]: the objective 1/2 z' diag(p_diag) z + q' z (copied).
+ *   mode_saa 1: CVaR_alpha(m(u)) - c_s slack <= rhs0 with the row -slack <= 0; 0 ('baseline'): max_i m_i(u) <= rhs0.
+ */
+typedef struct {
+  int32_t system, S, cap, keep_max, keep_recent, keep_idle, mode_saa, recycle;
+  int64_t M;
+  double alpha, alphaM, c_s, rhs0, u_min, u_max;
+  float thr;
+  const void* params;
+  const float *s0, *s1, *s2, *s3;
+  double *uk_dev, *uk_host, *x_host, *x_dev;
+  float* ring_m;
+  int32_t* ring_arg;
+  double* ring_res;
+  void* workspace;
+  size_t workspace_bytes;
+  double *part, *part_b, *sums_b_host;
+  int32_t *slots_dev, *slots_host;
+  double* res_host;
+  const double *p_diag, *q;
+} rato_cut_config;
+
+/* What a solve returns.  Caller-provided arrays: us [nU]; cut_slot / cut_lambda [cut_capacity] (ring slot and
+ * multiplier of every cut row of the last master: the data of a KKT certificate against the full QP); bound_var /
+ * bound_sign / bound_lambda [bound_capacity] (the control bounds that entered: variable, +1 upper / -1 lower,
+ * multiplier).  status 0 solved, 1 maximum cuts reached. */
+typedef struct {
+  double* us;
+  double slack, t_risk, phi, oracle_s, master_s, lam_slack;
+  int32_t cuts, recycled, status, uncertified_cuts;
+  int32_t* cut_slot;
+  double* cut_lambda;
+  int32_t cut_capacity, n_cut_rows;
+  int32_t* bound_var;
+  double* bound_sign;
+  double* bound_lambda;
+  int32_t bound_capacity, n_bounds;
+} rato_cut_result;
+
+typedef struct rato_cut_solver rato_cut_solver;
+int rato_cut_solver_create(rato_cut_solver** out, const rato_cut_config* cfg);
+void rato_cut_solver_destroy(rato_cut_solver* s);
+size_t rato_cut_config_bytes(void); /* sizeof the two structs as this library was built: a binding checks its layout */
+size_t rato_cut_result_bytes(void);
+
+/* Stream-ordered prologue of a subproblem, NO synchronisation: u_lin [nU] (host) -> uk_dev; for the n_keep ring slots
+ * kept from the previous subproblem, their tail-row sums under the new linearization point, reduced into sums_b_host. */
+int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep, int32_t n_keep, void* stream);
+
+/* The loop.  final_du (n_c x nU, row-major), final_rhs (n_c): the equality rows;  u_lin: the linearization point (the
+ * one given to rato_cut_begin);  with_cvar 0: the reference's relaxed first iterations (no CVaR rows: one master solve);
+ * tol: a cut is added while CVaR - c_s slack - rhs0 > tol, at most max_cuts; a last cut with violation in
+ * (final_cut_above, tol] still joins the master, which is solved once more.  keep / keep_idle_count [keep_max] and
+ * *n_keep_io: in -- the slots kept from the previous subproblem (+ for how many solves each has carried no multiplier);
+ * out -- the same for the next one.  kept_in_flight 1: rato_cut_begin was called for these slots on this stream.
+ * SYNCHRONISES the stream (every oracle round trip is read by the host master).  Returns RATO_OK, RATO_ERANK,
+ * RATO_EINFEASIBLE, RATO_ENNLS, RATO_ESELECT, RATO_ENONFINITE (check_finite: an oracle call saw non-finite m values). */
+int rato_cut_solve(rato_cut_solver* s, const double* final_du, const double* final_rhs, int32_t n_c, const double* u_lin,
+                   int32_t with_cvar, double tol, int32_t max_cuts, double final_cut_above, int32_t check_finite,
+                   int32_t* keep, int32_t* keep_idle_count, int32_t* n_keep_io, int32_t kept_in_flight,
+                   rato_cut_result* out, void* stream);
 
 /* ------------------------------------------------------------ device sampler */
 

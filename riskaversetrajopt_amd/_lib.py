@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 8              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 9              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -28,6 +28,28 @@ class CarParams(C.Structure):
                 ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32),   # 16 words
                 ("dt64", C.c_double), ("beta64", C.c_double), ("speed_ped_des64", C.c_double), ("d_min64", C.c_double),
                 ("ego_init64", C.c_double * 4)]
+
+
+class CutConfig(C.Structure):
+    """rato_cut_config (include/rato_saa.h)"""
+    _fields_ = [(k, C.c_int32) for k in ("system", "S", "cap", "keep_max", "keep_recent", "keep_idle", "mode_saa",
+                                         "recycle")] + \
+               [("M", C.c_int64)] + [(k, C.c_double) for k in ("alpha", "alphaM", "c_s", "rhs0", "u_min", "u_max")] + \
+               [("thr", C.c_float), ("params", C.c_void_p)] + [(k, C.c_void_p) for k in ("s0", "s1", "s2", "s3")] + \
+               [(k, C.c_void_p) for k in ("uk_dev", "uk_host", "x_host", "x_dev", "ring_m", "ring_arg", "ring_res",
+                                          "workspace")] + [("workspace_bytes", C.c_size_t)] + \
+               [(k, C.c_void_p) for k in ("part", "part_b", "sums_b_host", "slots_dev", "slots_host", "res_host",
+                                          "p_diag", "q")]
+
+
+class CutResult(C.Structure):
+    """rato_cut_result (include/rato_saa.h)"""
+    _fields_ = [("us", C.c_void_p)] + \
+               [(k, C.c_double) for k in ("slack", "t_risk", "phi", "oracle_s", "master_s", "lam_slack")] + \
+               [(k, C.c_int32) for k in ("cuts", "recycled", "status", "uncertified_cuts")] + \
+               [("cut_slot", C.c_void_p), ("cut_lambda", C.c_void_p), ("cut_capacity", C.c_int32),
+                ("n_cut_rows", C.c_int32), ("bound_var", C.c_void_p), ("bound_sign", C.c_void_p),
+                ("bound_lambda", C.c_void_p), ("bound_capacity", C.c_int32), ("n_bounds", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
@@ -55,6 +77,14 @@ SIGNATURES = {
                                    [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_cut_oracle_rollout": (C.c_int, [C.c_int32] + [c_float_p] * 10 + [C.c_double, C.c_float, C.c_double, C.c_void_p,
                                           C.c_size_t, c_float_p, c_float_p, c_float_p, c_stream]),
+    "rato_cut_solver_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CutConfig)]),
+    "rato_cut_solver_destroy": (None, [C.c_void_p]),
+    "rato_cut_config_bytes": (C.c_size_t, []),
+    "rato_cut_result_bytes": (C.c_size_t, []),
+    "rato_cut_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
+    "rato_cut_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
+                                 C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
+                                 C.POINTER(CutResult), c_stream]),
     "rato_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
     "rato_stream_synchronize": (C.c_int, [c_stream]),
     "rato_master_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -122,6 +152,9 @@ SIGNATURES = {
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }
+
+
+RATO_ENONFINITE, RATO_EINFEASIBLE, RATO_ERANK, RATO_ESELECT, RATO_ENNLS = -2, -4, -6, -7, -8     # rato_saa.h
 
 
 class RatoError(RuntimeError):

@@ -1,0 +1,410 @@
+// Host side of the boundary, continued (nnls.hip, master.hip): the CUTTING-PLANE LOOP of one reduced SCP subproblem as
+// ONE library call -- HOST code only; the device work it issues is the table-free cut oracle of cvar.hip.
+//
+// The reference hands every SCP subproblem to OSQP as one QP with M auxiliary variables (drone_risk.py:425-469,
+// driving.py:423-456).  Here the subproblem is that QP reduced exactly to (u, slack) (riskaversetrajopt_amd/cvar_cuts.py
+// has the derivation) and solved by Kelley cuts: master QP on the host (rato_master_*), oracle on the device
+// (rato_cut_oracle_rollout: rowmax -> exact tail selection -> tail-row sums -> read-back, one round trip per cut).
+// Round 3 drove that loop from Python (cvar_cuts.CvarCutSolver._solve): ~20 ms of interpreter time per 60 SCP iterations
+// against ~35 ms of device time.  This file is the same loop, statement for statement -- lazy control bounds, the "last
+// cut joins the master" rule, the keep rule for recycled cuts, the multipliers for the KKT certificate -- so that ONE
+// ctypes call per subproblem remains (rato_cut_begin is its stream-ordered prologue).  The Python loop stays as the
+// implementation for sharded batches and the table forms of the oracle, and as the checker: both produce BITWISE the
+// same iterates (tests/test_gpu_scp.py), which is why every inner product that feeds the master is an exactly rounded
+// sum here and there (fsum below == math.fsum).
+#pragma clang fp contract(off)   // the exactly-rounded sums below must see individually rounded products
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <utility>
+#include <vector>
+
+#include "rato_saa.h"
+
+namespace {
+
+// Shewchuk's exact summation (the algorithm of CPython's math.fsum, Modules/mathmodule.c): the correctly rounded value
+// of the exact sum of the inputs -- independent of their order, hence identical to math.fsum on the same numbers.
+double fsum(const double* v, int n) {
+  std::vector<double> p;
+  p.reserve(32);
+  for (int k = 0; k < n; ++k) {
+    double x = v[k];
+    size_t i = 0;
+    for (size_t j = 0; j < p.size(); ++j) {
+      double y = p[j];
+      if (fabs(x) < fabs(y)) std::swap(x, y);
+      const double hi = x + y;
+      const double lo = y - (hi - x);
+      if (lo != 0.0) p[i++] = lo;
+      x = hi;
+    }
+    p.resize(i);
+    p.push_back(x);
+  }
+  double hi = 0.0;
+  size_t n_p = p.size();
+  if (n_p > 0) {
+    hi = p[--n_p];
+    double lo = 0.0;
+    while (n_p > 0) {
+      const double x = hi;
+      const double y = p[--n_p];
+      hi = x + y;
+      const double yr = hi - x;
+      lo = y - yr;
+      if (lo != 0.0) break;
+    }
+    // round half to even across the remaining partials
+    if (n_p > 0 && ((lo < 0.0 && p[n_p - 1] < 0.0) || (lo > 0.0 && p[n_p - 1] > 0.0))) {
+      const double y = lo * 2.0;
+      const double x = hi + y;
+      const double yr = x - hi;
+      if (y == yr) hi = x;
+    }
+  }
+  return hi;
+}
+
+double dot_exact(const double* a, const double* b, int n, std::vector<double>& prod) {
+  prod.resize(n);
+  for (int i = 0; i < n; ++i) prod[i] = a[i] * b[i];
+  return fsum(prod.data(), n);
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+struct rato_cut_solver {
+  rato_cut_config c;
+  rato_drone_params drone;
+  rato_car_params car;
+  int nU = 0, n = 0, nc = 0, nres = 0, nblk = 0;
+  std::vector<double> p_diag, q;
+  const void* params() const { return c.system == 0 ? (const void*)&drone : (const void*)&car; }
+};
+
+extern "C" int rato_cut_solver_create(rato_cut_solver** out, const rato_cut_config* cfg) {
+  if (!out || !cfg) return RATO_EINVAL;
+  const rato_cut_config& c = *cfg;
+  if ((c.system != 0 && c.system != 1) || !c.params || c.S < 1 || c.M < 1 || c.cap < 2 || c.keep_max < 0 ||
+      c.keep_recent < 0 || c.keep_idle < 0 || !(c.alphaM > 0.0) || !c.s0 || !c.s1 || !c.s2 || (c.system == 1 && !c.s3) ||
+      !c.uk_dev || !c.uk_host || !c.x_host || !c.x_dev || !c.ring_m || !c.ring_arg || !c.ring_res || !c.workspace ||
+      !c.res_host || !c.p_diag || !c.q)
+    return RATO_EINVAL;
+  if (c.S > 1 && (!c.part || (c.keep_max > 0 && (!c.part_b || !c.sums_b_host || !c.slots_dev || !c.slots_host))))
+    return RATO_EINVAL;
+  rato_cut_solver* s = new rato_cut_solver;
+  s->c = c;
+  int n_u;
+  if (c.system == 0) {
+    s->drone = *static_cast<const rato_drone_params*>(c.params);
+    if (s->drone.S != c.S || s->drone.M != c.M) { delete s; return RATO_EINVAL; }
+    n_u = 3;
+  } else {
+    s->car = *static_cast<const rato_car_params*>(c.params);
+    if (s->car.S != c.S || s->car.M != c.M) { delete s; return RATO_EINVAL; }
+    n_u = 2;
+  }
+  s->nU = n_u * c.S;
+  s->n = s->nU + 1;
+  s->nc = 2 * std::max(c.S - 1, 0) + 1;
+  s->nres = RATO_N_STATS + s->nc;
+  s->nblk = (int)((c.M + 255) / 256);
+  s->p_diag.assign(c.p_diag, c.p_diag + s->n);
+  s->q.assign(c.q, c.q + s->n);
+  s->c.params = nullptr;   // (the copy above is what is used)
+  *out = s;
+  return RATO_OK;
+}
+
+extern "C" void rato_cut_solver_destroy(rato_cut_solver* s) { delete s; }
+
+extern "C" size_t rato_cut_config_bytes(void) { return sizeof(rato_cut_config); }
+extern "C" size_t rato_cut_result_bytes(void) { return sizeof(rato_cut_result); }
+
+namespace {
+
+int tail_rows_launch(rato_cut_solver* s, const float* m_base, const int32_t* arg_base, const double* res_base,
+                     const int32_t* slots, int K, double* part, void* stream) {
+  const rato_cut_config& c = s->c;
+  return c.system == 0 ? rato_drone_tail_rows_rollout(&s->drone, c.uk_dev, c.s0, c.s1, c.s2, m_base, arg_base, res_base,
+                                                      s->nres, slots, K, c.alphaM, part, stream)
+                       : rato_car_tail_rows_rollout(&s->car, c.uk_dev, c.s0, c.s1, c.s2, c.s3, m_base, arg_base,
+                                                    res_base, s->nres, slots, K, c.alphaM, part, stream);
+}
+
+}  // namespace
+
+// Stream-ordered prologue of a subproblem: u_k -> device (fp64), and -- when cuts were kept from the previous
+// subproblem -- their tail-row sums under the NEW linearization point, reduced straight into pinned host memory
+// (sums_b_host).  Nothing is synchronised: the caller's own read-back of the linearization's sample sums waits for
+// this work too (one device round trip per "define" instead of two).
+extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep, int32_t n_keep, void* stream) {
+  if (!s || !u_lin || n_keep < 0 || n_keep > s->c.keep_max || (n_keep > 0 && !keep)) return RATO_EINVAL;
+  const rato_cut_config& c = s->c;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  memcpy(c.uk_host, u_lin, sizeof(double) * (size_t)s->nU);
+  hipError_t e = hipMemcpyAsync(c.uk_dev, c.uk_host, sizeof(double) * (size_t)s->nU, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  if (n_keep == 0 || c.S < 2) return RATO_OK;
+  for (int k = 0; k < n_keep; ++k) {
+    if (keep[k] < 0 || keep[k] >= c.cap - 1) return RATO_EINVAL;
+    c.slots_host[k] = keep[k];
+  }
+  e = hipMemcpyAsync(c.slots_dev, c.slots_host, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  int rc = tail_rows_launch(s, c.ring_m, c.ring_arg, c.ring_res, c.slots_dev, n_keep, c.part_b, stream);
+  if (rc != RATO_OK) return rc;
+  return rato_sum_partials_f64(c.part_b, s->nblk, n_keep * s->nc, 1.0, c.sums_b_host, stream);
+}
+
+extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const double* final_rhs, int32_t n_c,
+                              const double* u_lin, int32_t with_cvar, double tol, int32_t max_cuts,
+                              double final_cut_above, int32_t check_finite, int32_t* keep, int32_t* keep_idle_count,
+                              int32_t* n_keep_io, int32_t kept_in_flight, rato_cut_result* out, void* stream) {
+  if (!s || !final_du || !final_rhs || n_c < 0 || !u_lin || !out || !out->us || !keep || !keep_idle_count || !n_keep_io ||
+      max_cuts < 0)
+    return RATO_EINVAL;
+  const rato_cut_config& c = s->c;
+  const int nU = s->nU, n = s->n, S = c.S, nc = s->nc, n_u = nU / S;
+  const bool saa = c.mode_saa != 0;
+  const bool cvar = with_cvar != 0;
+  const bool slack_row = cvar && saa;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double oracle_s = 0.0, master_s = 0.0;
+  std::vector<double> prod, row(n), g(nU), x(nU), z(n), lam, lam_tmp;
+
+  auto t0 = std::chrono::steady_clock::now();
+  // master: equalities [final_du | 0] z = final_rhs
+  std::vector<double> F((size_t)n_c * n, 0.0);
+  for (int r = 0; r < n_c; ++r) memcpy(&F[(size_t)r * n], final_du + (size_t)r * nU, sizeof(double) * nU);
+  rato_master* master = nullptr;
+  int rc = rato_master_create(&master, n, s->p_diag.data(), s->q.data(), n_c, F.data(), final_rhs);
+  if (rc != RATO_OK) return RATO_ERANK;
+  struct Guard {
+    rato_master* m;
+    ~Guard() { rato_master_destroy(m); }
+  } guard{master};
+  int n_rows = 0;
+  if (slack_row) {   // -slack <= 0
+    std::fill(row.begin(), row.end(), 0.0);
+    row[nU] = -1.0;
+    const double zero = 0.0;
+    if ((rc = rato_master_add_rows(master, 1, row.data(), &zero)) != RATO_OK) return rc;
+    n_rows = 1;
+  }
+  std::vector<std::pair<int, int>> cut_rows;   // (row of the master, ring slot)
+  const int n_kept = (cvar && c.recycle) ? *n_keep_io : 0;
+  if (n_kept < 0 || n_kept > c.keep_max) return RATO_EINVAL;
+  master_s += seconds_since(t0);
+
+  if (n_kept > 0 && S >= 2) {
+    t0 = std::chrono::steady_clock::now();
+    if (!kept_in_flight) {
+      if ((rc = rato_cut_begin(s, u_lin, keep, n_kept, stream)) != RATO_OK) return rc;
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+    oracle_s += seconds_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    // cut k under the current linearization (delta form):  rows_k . (u - u_k) + c0_k - c_s s <= rhs0
+    std::vector<double> rows((size_t)n_kept * n, 0.0), rhs(n_kept);
+    for (int k = 0; k < n_kept; ++k) {
+      const double* r = c.sums_b_host + (size_t)k * nc;
+      double* rk = &rows[(size_t)k * n];
+      for (int t = 0; t < S - 1; ++t) {
+        rk[t * n_u + 0] = r[2 * t + 0] / c.alphaM;
+        rk[t * n_u + 1] = r[2 * t + 1] / c.alphaM;
+      }
+      rk[nU] = -c.c_s;
+      const double d = dot_exact(rk, u_lin, nU, prod);
+      rhs[k] = (c.rhs0 + d) - 1.0 * (r[nc - 1] / c.alphaM);
+      cut_rows.emplace_back(n_rows + k, keep[k]);
+    }
+    if ((rc = rato_master_add_rows(master, n_kept, rows.data(), rhs.data())) != RATO_OK) return rc;
+    n_rows += n_kept;
+    master_s += seconds_since(t0);
+  }
+  std::vector<int> free_slots;   // ascending; the loop takes from the back
+  {
+    std::vector<uint8_t> is_kept(c.cap, 0);
+    for (int k = 0; k < n_kept; ++k) is_kept[keep[k]] = 1;
+    for (int sl = 0; sl < c.cap - 1; ++sl)
+      if (!is_kept[sl]) free_slots.push_back(sl);
+  }
+  std::vector<uint8_t> in_master(2 * (size_t)nU, 0);
+  struct BoundRows {
+    int r0;
+    std::vector<int> idx;
+    double sgn;
+  };
+  std::vector<BoundRows> bound_rows;
+
+  auto solve_master = [&]() -> int {   // the master with the control bounds entering lazily: only the violated ones
+    for (;;) {
+      lam.assign(n_rows, 0.0);
+      const int r = rato_master_solve(master, z.data(), lam.data());
+      if (r == RATO_EINFEASIBLE) return RATO_EINFEASIBLE;
+      if (r != 1) return RATO_ENNLS;
+      std::vector<int> hi, lo;
+      for (int i = 0; i < nU; ++i) {
+        if (z[i] > c.u_max + 1e-9 && !in_master[i]) hi.push_back(i);
+        if (z[i] < c.u_min - 1e-9 && !in_master[nU + i]) lo.push_back(i);
+      }
+      if (hi.empty() && lo.empty()) return RATO_OK;
+      for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<int>& idx = pass == 0 ? hi : lo;
+        if (idx.empty()) continue;
+        const double sgn = pass == 0 ? 1.0 : -1.0;
+        std::vector<double> R((size_t)idx.size() * n, 0.0), b(idx.size(), pass == 0 ? c.u_max : -c.u_min);
+        for (size_t k = 0; k < idx.size(); ++k) {
+          R[k * n + idx[k]] = sgn;
+          in_master[(pass == 0 ? 0 : nU) + idx[k]] = 1;
+        }
+        const int r2 = rato_master_add_rows(master, (int)idx.size(), R.data(), b.data());
+        if (r2 != RATO_OK) return r2;
+        bound_rows.push_back({n_rows, idx, sgn});
+        n_rows += (int)idx.size();
+      }
+    }
+  };
+
+  double phi = NAN, tstar = NAN;
+  int n_cuts = 0, status = 0;
+  const int scratch = c.cap - 1;
+  const size_t M = (size_t)c.M;
+  for (int it = 0; it <= max_cuts; ++it) {
+    t0 = std::chrono::steady_clock::now();
+    if ((rc = solve_master()) != RATO_OK) return rc;
+    master_s += seconds_since(t0);
+    if (!cvar) break;
+    t0 = std::chrono::steady_clock::now();
+    int slot = -1;
+    if (!free_slots.empty()) {
+      slot = free_slots.back();
+      free_slots.pop_back();
+    }
+    const int ring = slot >= 0 ? slot : scratch;
+    for (int i = 0; i < nU; ++i) {
+      x[i] = z[i] - u_lin[i];
+      c.x_host[i] = x[i];
+    }
+    rc = rato_cut_oracle_rollout(c.system, s->params(), c.uk_dev, c.s0, c.s1, c.s2, c.s3, c.x_host, c.x_dev,
+                                 c.ring_m + (size_t)ring * M, c.ring_arg + (size_t)ring * M, c.alpha, c.thr, c.alphaM,
+                                 c.workspace, c.workspace_bytes, c.ring_res + (size_t)ring * s->nres, c.part, c.res_host,
+                                 stream);
+    if (rc != RATO_OK) return rc;
+    const double* r = c.res_host;
+    if (isnan(r[0])) return RATO_ESELECT;     // the one-launch selection gave up (or the m values hold NaN): the caller
+    //                                           repeats the subproblem with the recovering Python loop
+    if (check_finite && !(isfinite(r[3]) && isfinite(r[4]))) return RATO_ENONFINITE;
+    std::fill(g.begin(), g.end(), 0.0);
+    if (S > 1) {
+      for (int t = 0; t < S - 1; ++t) {
+        g[t * n_u + 0] = r[RATO_N_STATS + 2 * t + 0] / c.alphaM;
+        g[t * n_u + 1] = r[RATO_N_STATS + 2 * t + 1] / c.alphaM;
+      }
+      phi = dot_exact(g.data(), x.data(), nU, prod) + 1.0 * (r[RATO_N_STATS + nc - 1] / c.alphaM);
+    } else {
+      phi = r[1];
+    }
+    tstar = r[0];
+    oracle_s += seconds_since(t0);
+    const double slack = z[nU];
+    const double viol = phi - c.c_s * slack - c.rhs0;
+    auto add_cut = [&]() -> int {   // phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= rhs0 + g_k.u_k - phi_k
+      memcpy(row.data(), g.data(), sizeof(double) * nU);
+      row[nU] = -c.c_s;
+      const double rhs = c.rhs0 + (dot_exact(g.data(), z.data(), nU, prod) - phi);
+      const int r2 = rato_master_add_rows(master, 1, row.data(), &rhs);
+      if (r2 != RATO_OK) return r2;
+      if (slot >= 0) cut_rows.emplace_back(n_rows, slot);
+      n_rows += 1;
+      n_cuts += 1;
+      return RATO_OK;
+    };
+    if (viol <= tol) {
+      if (viol > final_cut_above && it < max_cuts) {   // the cut just evaluated is paid for: it joins the master
+        t0 = std::chrono::steady_clock::now();
+        if ((rc = add_cut()) != RATO_OK) return rc;
+        if ((rc = solve_master()) != RATO_OK) return rc;
+        master_s += seconds_since(t0);
+      }
+      break;
+    }
+    if (it == max_cuts) {
+      status = 1;
+      break;
+    }
+    if ((rc = add_cut()) != RATO_OK) return rc;
+  }
+
+  // multipliers of the last master solve, for whoever certifies the solution against the full QP
+  std::vector<double> lam_full(n_rows, 0.0);
+  for (size_t i = 0; i < lam.size() && i < (size_t)n_rows; ++i) lam_full[i] = lam[i];
+  if (cvar && c.recycle) {
+    // keep rule: the cuts that carry a multiplier (newest first; keep_idle > 0: or did within the last keep_idle solves),
+    // plus the newest keep_recent
+    std::vector<int> idle(c.cap, -1);
+    for (int k = 0; k < *n_keep_io; ++k) idle[keep[k]] = keep_idle_count[k];
+    for (auto& cr : cut_rows) {
+      const bool active = cr.first < (int)lam.size() && lam[cr.first] > 1e-12;
+      idle[cr.second] = active ? 0 : (idle[cr.second] < 0 ? 0 : idle[cr.second]) + 1;
+    }
+    std::vector<int> new_keep;
+    auto push = [&](int sl) {
+      if (std::find(new_keep.begin(), new_keep.end(), sl) == new_keep.end()) new_keep.push_back(sl);
+    };
+    for (auto it2 = cut_rows.rbegin(); it2 != cut_rows.rend(); ++it2)
+      if (idle[it2->second] <= c.keep_idle) push(it2->second);
+    int cnt = 0;
+    for (auto it2 = cut_rows.rbegin(); it2 != cut_rows.rend() && cnt < c.keep_recent; ++it2, ++cnt) push(it2->second);
+    if ((int)new_keep.size() > c.keep_max) new_keep.resize(c.keep_max);
+    for (size_t k = 0; k < new_keep.size(); ++k) {
+      keep[k] = new_keep[k];
+      keep_idle_count[k] = idle[new_keep[k]];
+    }
+    *n_keep_io = (int)new_keep.size();
+  }
+  memcpy(out->us, z.data(), sizeof(double) * nU);
+  out->slack = z[nU];
+  out->t_risk = slack_row ? tstar + z[nU] : 0.0;
+  out->phi = phi;
+  out->oracle_s = oracle_s;
+  out->master_s = master_s;
+  out->cuts = n_cuts;
+  out->recycled = n_kept;
+  out->status = status;
+  out->lam_slack = slack_row ? lam_full[0] : 0.0;
+  out->uncertified_cuts = n_cuts + n_kept - (int)cut_rows.size();
+  out->n_cut_rows = 0;
+  if (out->cut_slot && out->cut_lambda) {
+    for (auto& cr : cut_rows) {
+      if (out->n_cut_rows >= out->cut_capacity) break;
+      out->cut_slot[out->n_cut_rows] = cr.second;
+      out->cut_lambda[out->n_cut_rows] = lam_full[cr.first];
+      ++out->n_cut_rows;
+    }
+  }
+  out->n_bounds = 0;
+  if (out->bound_var && out->bound_sign && out->bound_lambda) {
+    for (auto& br : bound_rows)
+      for (size_t k = 0; k < br.idx.size(); ++k) {
+        if (out->n_bounds >= out->bound_capacity) break;
+        out->bound_var[out->n_bounds] = br.idx[k];
+        out->bound_sign[out->n_bounds] = br.sgn;
+        out->bound_lambda[out->n_bounds] = lam_full[br.r0 + (int)k];
+        ++out->n_bounds;
+      }
+  }
+  return RATO_OK;
+}

@@ -47,6 +47,7 @@ Jacobian of its samples; a cut costs one all-gather of the m shards (the exact V
 then runs the same selection), and one rank-ordered sum of the 2(S-1) subgradient partial sums.  Every rank
 solves the same tiny master; rank 0's solution is broadcast so that the ranks cannot drift apart.
 """
+import math
 import os
 import time
 
@@ -122,6 +123,8 @@ class CvarCutSolver:
         self.keep_idle = int(os.environ.get("RATO_KEEP_IDLE", 0))        # (A/B knobs: profiles/EXPERIMENTS.md, "2-cycles")
         self.u_lin = None                                # linearization point of the delta form (None: reference form)
         self._relin_pending = None                       # kept cuts whose re-linearization is already in flight
+        self._native = None                              # (key, rato_cut_solver handle, its output arrays)
+        self.use_native_loop = True
         if self.world > 1:
             # every collective of the loop moves buffers whose lengths follow from (M, S, n_u, keep_max): agreed on here,
             # once, by every rank (the solver is built collectively, in the first solve_reduced after Model.shard()) --
@@ -204,7 +207,10 @@ class CvarCutSolver:
         if S > 1:
             sums = r[stats.N_STATS:] / self.alphaM
             g.reshape(S, n_u)[:S - 1, 0:2] = sums[:self.nc - 1].reshape(S - 1, 2)
-            phi = float(g @ x + sign * sums[self.nc - 1])   # the cut's own value at the candidate (fp64, consistent with g)
+            # the cut's own value at the candidate (fp64, consistent with g).  Every inner product that feeds the master
+            # is an exactly rounded sum (math.fsum): independent of summation order, so the native loop
+            # (csrc/cutloop.hip, rato_cut_solve) reproduces this one bit for bit
+            phi = math.fsum(g * x) + sign * sums[self.nc - 1]
         else:
             phi = float(r[1])                               # no control enters row t = 0: the value is a constant
         return phi, float(r[0]), g
@@ -294,6 +300,23 @@ class CvarCutSolver:
             self._uk_np[:] = self.u_lin.reshape(self.S, self.n_u)    # (pinned; every solve ends synchronised, so the
             _lib.copy_async(self.uk_dev, self.uk_host)               #  previous upload from it has long completed)
 
+    def begin(self, u_lin, relinearize, G=None, W=None, tile=0, base=None):
+        """Stream-ordered prologue of a subproblem: the linearization point (``set_linearization_point``) and, when
+        ``relinearize``, the kept cuts against it (``enqueue_relinearize``) -- one library call (rato_cut_begin) where the
+        native loop applies."""
+        if u_lin is not None and self.native_loop_applies():
+            self.u_lin = np.asarray(u_lin, dtype=np.float64).reshape(-1).copy()
+            h = self._native_solver()
+            K = len(self.keep) if (relinearize and self.recycle and self.S >= 2) else 0
+            out = self._keep_arrays()
+            _lib.check(self.lib.rato_cut_begin(h, self.u_lin.ctypes.data, out["keep"].ctypes.data, K,
+                                               _lib.current_stream()), "rato_cut_begin")
+            self._relin_pending = K if K else None
+            return
+        self.set_linearization_point(u_lin)
+        if relinearize:
+            self.enqueue_relinearize(G, W, tile, base)
+
     def enqueue_relinearize(self, G, W, tile, base):
         """Stream-ordered half of ``relinearize_kept_cuts`` (launches + the read-back into pinned memory, NO
         synchronisation): called right behind the linearize launch, so that the caller's own read-back of the sample
@@ -315,7 +338,8 @@ class CvarCutSolver:
         rows.reshape(K, S, n_u)[:, :S - 1, 0:2] = r[:, :self.nc - 1].reshape(K, S - 1, 2)
         # cut k:  rows[k].(u - x0) + sign c0_k - c_s s <= rhs0
         sign, x0 = self._form()
-        return rows, self.rhs0 + rows @ x0 - sign * r[:, self.nc - 1]
+        dots = np.array([math.fsum(rows[k] * x0) for k in range(K)])
+        return rows, (self.rhs0 + dots) - sign * r[:, self.nc - 1]
 
     def _relin_launch(self, G, W, tile, base):
         """-> number of kept cuts whose sums are on their way to ``sums_b_host`` (0: nothing to do)"""
@@ -361,10 +385,131 @@ class CvarCutSolver:
         with ctl.limit(limits=4):
             return self._solve(*args, **kwargs)
 
+    # ---- the loop as one library call (csrc/cutloop.hip) ------------------------------------------------------
+    def native_loop_applies(self):
+        """rato_cut_solve covers the benchmarked configuration: table-free oracle, one GPU, diagonal cost matrix, the
+        device oracle itself (a subclass that overrides ``evaluate`` -- the host checker of tests/_host_cuts.py -- keeps
+        the Python loop, as do sharded batches and the table forms).  RATO_PY_CUT_LOOP=1 forces the Python loop (A/B)."""
+        return (self.rollout is not None and self.world == 1 and self._p_diag is not None and self.device is not None
+                and type(self).evaluate is CvarCutSolver.evaluate and os.environ.get("RATO_PY_CUT_LOOP") != "1"
+                and self.use_native_loop)
+
+    def _native_solver(self):
+        """the rato_cut_solver for the current samples (rebuilt when they, or the parameters, change)"""
+        kind, p, *samples = self.rollout
+        key = (kind, bytes(p)) + tuple(a.data_ptr() for a in samples)
+        if self._native is not None and self._native[0] == key:
+            return self._native[1]
+        self._native_destroy()
+        C = _lib.C
+        cfg = _lib.CutConfig()
+        cfg.system, cfg.S, cfg.cap = (0 if kind == "drone" else 1), self.S, self.cap
+        cfg.keep_max, cfg.keep_recent, cfg.keep_idle = self.keep_max, self.keep_recent, self.keep_idle
+        cfg.mode_saa, cfg.recycle, cfg.M = int(self.mode == 'saa'), int(bool(self.recycle)), self.M
+        cfg.alpha, cfg.alphaM, cfg.c_s, cfg.rhs0 = float(self.alpha), float(self.alphaM), float(self.c_s), float(self.rhs0)
+        cfg.u_min, cfg.u_max, cfg.thr = self.u_min, self.u_max, float(stats.SATISFIED_THRESHOLD)
+        cfg.params = C.cast(C.pointer(p), C.c_void_p)
+        for name, a in zip(("s0", "s1", "s2", "s3"), samples):
+            setattr(cfg, name, a.data_ptr())
+        q = np.ascontiguousarray(self.q, dtype=np.float64)
+        for name, t in (("uk_dev", self.uk_dev), ("uk_host", self.uk_host), ("x_host", self.x_host), ("x_dev", self.x_dev),
+                        ("ring_m", self.ring_m), ("ring_arg", self.ring_arg), ("ring_res", self.ring_res),
+                        ("workspace", self.ws), ("part", self.part), ("part_b", self.part_b),
+                        ("sums_b_host", self.sums_b_host), ("slots_dev", self.slots_dev), ("slots_host", self.slots_host),
+                        ("res_host", self.res_host)):
+            setattr(cfg, name, None if t is None else t.data_ptr())
+        cfg.workspace_bytes = self.ws.numel() * self.ws.element_size()
+        cfg.p_diag, cfg.q = self._p_diag.ctypes.data, q.ctypes.data
+        h = C.c_void_p()
+        _lib.check(self.lib.rato_cut_solver_create(C.byref(h), C.byref(cfg)), "rato_cut_solver_create")
+        nU = self.nU
+        out = {"us": np.zeros(nU), "cut_slot": np.zeros(self.cap + 8, dtype=np.int32), "cut_lambda": np.zeros(self.cap + 8),
+               "bound_var": np.zeros(2 * nU, dtype=np.int32), "bound_sign": np.zeros(2 * nU), "bound_lambda": np.zeros(2 * nU),
+               "keep": np.zeros(max(self.keep_max, 1), dtype=np.int32), "idle": np.zeros(max(self.keep_max, 1), dtype=np.int32),
+               "n_keep": C.c_int32(0), "samples": samples, "q": q}     # (samples, q: kept alive with the handle)
+        res = _lib.CutResult()
+        res.us, res.cut_slot, res.cut_lambda = out["us"].ctypes.data, out["cut_slot"].ctypes.data, out["cut_lambda"].ctypes.data
+        res.cut_capacity = out["cut_slot"].size
+        res.bound_var, res.bound_sign = out["bound_var"].ctypes.data, out["bound_sign"].ctypes.data
+        res.bound_lambda, res.bound_capacity = out["bound_lambda"].ctypes.data, out["bound_var"].size
+        out["res"] = res
+        self._native = (key, h, out)
+        return h
+
+    def _native_destroy(self):
+        nat, self._native = getattr(self, "_native", None), None
+        if nat is not None:
+            self.lib.rato_cut_solver_destroy(nat[1])
+
+    def __del__(self):
+        try:
+            self._native_destroy()
+        except Exception:                         # pragma: no cover  (interpreter shutdown)
+            pass
+
+    def _keep_arrays(self):
+        out = self._native[2]
+        K = len(self.keep)
+        out["keep"][:K] = self.keep
+        out["idle"][:K] = [self.idle.get(sl, 0) for sl in self.keep]
+        out["n_keep"].value = K
+        return out
+
+    def _solve_native(self, final_du, final_rhs, u_lin, with_cvar, tol, max_cuts, final_cut_above):
+        """one rato_cut_solve call -> the same ``info`` dict as the Python loop below"""
+        h = self._native_solver()
+        out = self._keep_arrays()
+        fdu = np.ascontiguousarray(final_du, dtype=np.float64)
+        frhs = np.ascontiguousarray(final_rhs, dtype=np.float64)
+        u_lin = np.ascontiguousarray(u_lin, dtype=np.float64).reshape(-1)
+        in_flight, self._relin_pending = self._relin_pending, None
+        res = out["res"]
+        rc = self.lib.rato_cut_solve(h, fdu.ctypes.data, frhs.ctypes.data, fdu.shape[0], u_lin.ctypes.data, int(with_cvar),
+                                     float(tol), int(max_cuts), float(final_cut_above), int(self.check_finite),
+                                     out["keep"].ctypes.data, out["idle"].ctypes.data, _lib.C.byref(out["n_keep"]),
+                                     int(bool(in_flight)), _lib.C.byref(res), _lib.current_stream())
+        if rc in (_lib.RATO_ERANK, _lib.RATO_ESELECT):
+            return None                        # -> the Python loop (general master / recovering selection)
+        if rc == _lib.RATO_EINFEASIBLE:
+            raise dense_qp.InfeasibleError("master QP infeasible")
+        if rc == _lib.RATO_ENONFINITE:
+            raise _lib.RatoNonFiniteError("CVaR-cut oracle: non-finite constraint values m_i(u) (RATO_ENONFINITE)")
+        _lib.check(rc, "rato_cut_solve")
+        if self.recycle and with_cvar:
+            K = out["n_keep"].value
+            self.keep = [int(v) for v in out["keep"][:K]]
+            self.idle = {int(sl): int(c) for sl, c in zip(out["keep"][:K], out["idle"][:K])}
+        nb = res.n_bounds
+        bounds = []
+        if nb:       # grouped by sign run, as the Python loop reports them
+            var, sgn, lam = out["bound_var"][:nb], out["bound_sign"][:nb], out["bound_lambda"][:nb]
+            cut_at = np.flatnonzero(np.diff(sgn) != 0) + 1
+            for idx, sg, la in zip(np.split(var, cut_at), np.split(sgn, cut_at), np.split(lam, cut_at)):
+                bounds.append((idx.astype(np.int64).copy(), float(sg[0]), la.copy()))
+        nc = res.n_cut_rows
+        info = {"oracle_s": res.oracle_s, "master_s": res.master_s,
+                "multipliers": {"cuts": [(int(sl), float(la)) for sl, la in zip(out["cut_slot"][:nc], out["cut_lambda"][:nc])],
+                                "slack": float(res.lam_slack), "bounds": bounds,
+                                "uncertified_cuts": int(res.uncertified_cuts)},
+                "us": out["us"].reshape(self.S, self.n_u).copy(), "slack": float(res.slack), "t_risk": float(res.t_risk),
+                "cuts": int(res.cuts), "phi": float(res.phi),
+                "status": "solved" if res.status == 0 else "maximum cuts reached", "loop": "native"}
+        if self.recycle and with_cvar:
+            info["recycled"] = int(res.recycled)
+        return info
+
     def _solve(self, G, W, tile, base, final_du, final_rhs, *, u_lin=None, with_cvar=True, tol=1e-8, max_cuts=400,
                verbose=False, final_cut_above=1e-11):
         """``base``: g_up [R][S][ld] of the linearize call (reference form), or -- with ``u_lin`` = the controls the
         linearization was taken at -- its g output (delta form, params.rows_out = 1)."""
+        if u_lin is not None and not verbose and self.native_loop_applies():
+            new_lin = np.asarray(u_lin, dtype=np.float64).reshape(-1)
+            if self.u_lin is None or not np.array_equal(new_lin, self.u_lin):
+                self.set_linearization_point(new_lin)
+                self._relin_pending = None
+            info = self._solve_native(final_du, final_rhs, new_lin, with_cvar, tol, max_cuts, final_cut_above)
+            if info is not None:
+                return info
         nU, n = self.nU, self.nU + 1
         new_lin = None if u_lin is None else np.asarray(u_lin, dtype=np.float64).reshape(-1)
         if (new_lin is None) != (self.u_lin is None) or (new_lin is not None and not np.array_equal(new_lin, self.u_lin)):
@@ -447,7 +592,7 @@ class CvarCutSolver:
                 # leave no violation and nothing is added.
                 if viol > final_cut_above and it < max_cuts:
                     t0 = time.perf_counter()
-                    master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + float(g @ u_vec - phi)])
+                    master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + (math.fsum(g * u_vec) - phi)])
                     if slot is not None:
                         cut_rows.append((n_rows, slot))
                     n_rows += 1
@@ -460,7 +605,7 @@ class CvarCutSolver:
                 status = "maximum cuts reached"
                 break
             # phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= rhs0 + g_k.u_k - phi_k
-            master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + float(g @ u_vec - phi)])
+            master.add_rows(np.concatenate([g, [-self.c_s]])[None, :], [self.rhs0 + (math.fsum(g * u_vec) - phi)])
             if slot is not None:
                 cut_rows.append((n_rows, slot))
             n_rows += 1
@@ -502,5 +647,5 @@ class CvarCutSolver:
                                "bounds": [(idx, sgn, lam_full[r0:r0 + idx.size].copy()) for r0, idx, sgn in bound_rows],
                                "uncertified_cuts": n_cuts + len(kept) - len(cut_rows)}
         info.update(us=u_vec.reshape(self.S, self.n_u).copy(), slack=float(s), t_risk=t_risk,
-                    cuts=n_cuts, phi=float(phi), status=status)
+                    cuts=n_cuts, phi=float(phi), status=status, loop="python")
         return info

@@ -452,9 +452,7 @@ class Model:
                 raise _lib.RatoNonFiniteError("driving final rows: non-finite values (RATO_ENONFINITE)")
             # unconditionally: the upload of u_k to the device happens only while cs.rollout is set, so a table-form call
             # at the same u before this one must not leave the rollout kernels reading a stale uk_dev
-            cs.set_linearization_point(u_lin)
-            if scp_iter >= 1 and getattr(self, "_world", 1) == 1:
-                cs.enqueue_relinearize(None, None, 0, None)
+            cs.begin(u_lin, scp_iter >= 1 and getattr(self, "_world", 1) == 1)
             info = cs.solve(None, None, 0, None, final_du, final_rhs, u_lin=u_lin, with_cvar=(scp_iter >= 1), tol=tol,
                             verbose=verbose)
             return info["us"], info["t_risk"], info

@@ -637,11 +637,10 @@ class Model:
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
         if rollout:
             cs.rollout = ("drone", self._params(M, mass.numel()), dW, mass, Qsym)
-        cs.set_linearization_point(np.asarray(us_mat_p, dtype=np.float64) if delta else None)
-        if scp_iter >= 2 and world == 1:
-            # the kept cuts against this linearization: launched now, so that the read-back of the sample sums below
-            # waits for both (one device round trip instead of two)
-            cs.enqueue_relinearize(r["G"], r["_W"], r["tile"], r["_g_up"])
+        # the linearization point and the kept cuts against this linearization: launched now, so that the read-back of the
+        # sample sums below waits for both (one device round trip instead of two)
+        cs.begin(np.asarray(us_mat_p, dtype=np.float64) if delta else None, scp_iter >= 2 and world == 1,
+                 r["G"], r["_W"], r["tile"], r["_g_up"])
         sums = r["sums"]
         if world > 1:                                     # sample means over ALL shards, summed in rank order
             from . import dist as rdist

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_size_queries(lib):
     from riskaversetrajopt_amd import _lib
-    assert lib.rato_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.rato_abi_version() == _lib.ABI_VERSION == 9
     import ctypes as C
     cpt, spl, tile = C.c_int32(8), C.c_int32(1), C.c_int32(0)
     assert lib.rato_drone_linearize_plan(1000, 50, 1000, C.byref(cpt), C.byref(spl), C.byref(tile)) == 4
@@ -63,6 +63,12 @@ def test_params_struct_layout_matches_header():
     # 2 int32 + 6 float + 6 + 6 + 6 floats
     assert ctypes.sizeof(_lib.DroneParams) == 4 * (3 + 6 + 18 + 1) + 8 * (6 + 6 + 6 + 6)   # + the fp64 constants
     assert ctypes.sizeof(_lib.CarParams) == 4 * (2 + 5 + 8 + 1) + 8 * (4 + 4)   # + the fp64 constants
+
+
+def test_cut_loop_struct_layouts_match_the_library(lib):
+    from riskaversetrajopt_amd import _lib
+    assert ctypes.sizeof(_lib.CutConfig) == lib.rato_cut_config_bytes()
+    assert ctypes.sizeof(_lib.CutResult) == lib.rato_cut_result_bytes()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -830,3 +830,39 @@ def test_reduced_subproblems_at_the_benchmarked_size(system):
     print(system, "M=1e5 per-subproblem max |du|:", " ".join("%.1e" % v for v in du), "| |dt_risk|:",
           " ".join("%.1e" % v for v in dtr), "| cuts (device, fp64):", cuts)
     assert max(du) < 1e-5 and max(dtr) < 1e-5
+
+
+@pytest.mark.parametrize("system,M,S,alpha,method", [("drone", 2000, 20, 0.1, "saa"), ("drone", 3001, 50, 0.05, "saa"),
+                                                     ("driving", 2000, 20, 0.1, "saa"), ("driving", 3001, 40, 0.05, "saa"),
+                                                     ("drone", 64, 20, 0.2, "baseline"), ("driving", 64, 20, 0.1, "baseline")])
+def test_native_cut_loop_equals_the_python_loop_bitwise(system, M, S, alpha, method):
+    """rato_cut_solve (csrc/cutloop.hip: the cutting-plane loop of a subproblem as one library call -- what bench.py's SCP
+    blocks time) against cvar_cuts.CvarCutSolver._solve (the Python loop every parity test of this file was established
+    on): same master, same oracle round trips, exactly rounded inner products on both sides -> the free-running SCP
+    sequences agree BIT FOR BIT, iterate by iterate, with the same cut counts, keep lists and multipliers."""
+    mk = (lambda: _drone(M, S, alpha=alpha, method=method, seed=3)[1]) if system == "drone" else \
+         (lambda: _car(M, S, alpha=alpha, method=method, seed=3)[1])
+    a, b = mk(), mk()
+    us_a = us_b = a.initial_guess_us_mat()
+    iters = 10 if system == "drone" else 7
+    for k in range(iters):
+        us_a, t_a, ia = a.solve_reduced(us_a, k)
+        if b.__dict__.get("_cut_solver") is not None:
+            b._cut_solver.use_native_loop = False
+        else:                                     # the solver is created by the first call: switch it before any loop runs
+            import os
+            os.environ["RATO_PY_CUT_LOOP"] = "1"
+        try:
+            us_b, t_b, ib = b.solve_reduced(us_b, k)
+        finally:
+            import os
+            os.environ.pop("RATO_PY_CUT_LOOP", None)
+        b._cut_solver.use_native_loop = False
+        assert ia["loop"] == "native" and ib["loop"] == "python"
+        assert np.array_equal(us_a, us_b), (k, np.abs(us_a - us_b).max())
+        assert t_a == t_b and ia["slack"] == ib["slack"] and ia["cuts"] == ib["cuts"] and ia["status"] == ib["status"]
+        assert a._cut_solver.keep == b._cut_solver.keep and a._cut_solver.idle == b._cut_solver.idle
+        ma, mb = ia["multipliers"], ib["multipliers"]
+        assert ma["cuts"] == mb["cuts"] and ma["slack"] == mb["slack"] and ma["uncertified_cuts"] == mb["uncertified_cuts"]
+        flat = lambda bs: sorted((int(i), float(sg), float(la)) for idx, sg, lam in bs for i, la in zip(idx, lam))
+        assert flat(ma["bounds"]) == flat(mb["bounds"])
