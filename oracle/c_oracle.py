@@ -77,6 +77,12 @@ def drone_stream(us, DWs, masses, obs_Qs, dt, nthreads=0):
     return out
 
 
+def default_threads():
+    """threads of the streaming cut oracle: given EXPLICITLY to every call -- the cutting-plane loop that calls it runs
+    under threadpoolctl's 4-thread limit (cvar_cuts.CvarCutSolver.solve), which would otherwise clamp OpenMP too"""
+    return max(1, min(128, os.cpu_count() or 1))
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -91,7 +97,8 @@ class DroneCutOracle:
 
     def __init__(self, DWs, masses, obs_Qs, dt, nthreads=0):
         self.DWs, self.masses, self.obs_Qs = _f64(DWs), _f64(masses), _f64(obs_Qs)
-        self.M, self.S, self.dt, self.nU, self.nthreads = self.DWs.shape[0], self.DWs.shape[1], float(dt), 3 * self.DWs.shape[1], nthreads
+        self.M, self.S, self.dt, self.nU = self.DWs.shape[0], self.DWs.shape[1], float(dt), 3 * self.DWs.shape[1]
+        self.nthreads = nthreads or default_threads()
 
     def rowmax(self, us_k, u):
         """-> (m (M,), arg (M,)):  m_i = max_r (G_i(u_k) u - g_up_i(u_k))_r"""
@@ -130,7 +137,8 @@ class CarCutOracle:
 
     def __init__(self, states_init, omegas_speed, omegas_rep, DWs, nthreads=0):
         self.x0, self.ws, self.wr, self.DWs = _f64(states_init), _f64(omegas_speed), _f64(omegas_rep), _f64(DWs)
-        self.M, self.S, self.nU, self.nthreads = self.DWs.shape[0], self.DWs.shape[1], 2 * self.DWs.shape[1], nthreads
+        self.M, self.S, self.nU = self.DWs.shape[0], self.DWs.shape[1], 2 * self.DWs.shape[1]
+        self.nthreads = nthreads or default_threads()
 
     def rowmax(self, us_k, u):
         m, arg = np.empty(self.M), np.empty(self.M, dtype=np.int32)

@@ -223,8 +223,9 @@ void rato_oracle_drone_rowmax(int M, int S, double dt, const double* us_k, const
       int arg = 0;
       for (int r = 0; r < R; ++r) {
         const double* row = gdu + (size_t)r * nU;
+        const int nz = NU * (r % S);                   /* row (j, t): d g_t / d u_s = 0 for s >= t (exact zeros) */
         double dot = 0.0;
-        for (int c = 0; c < nU; ++c) dot += row[c] * u[c];
+        for (int c = 0; c < nz; ++c) dot += row[c] * u[c];
         const double v = dot - gup[r];
         if (v > best) { best = v; arg = r; }          /* first maximum, as numpy.argmax */
       }

@@ -77,6 +77,8 @@ SIGNATURES = {
                                    [C.c_int64, c_float_p, C.c_int32, C.c_double, c_float_p, c_stream]),
     "rato_cut_oracle_rollout": (C.c_int, [C.c_int32] + [c_float_p] * 10 + [C.c_double, C.c_float, C.c_double, C.c_void_p,
                                           C.c_size_t, c_float_p, c_float_p, c_float_p, c_stream]),
+    "rato_kkt_sums": (C.c_int, [c_float_p, C.c_int64, c_float_p, c_float_p, C.c_int64, c_float_p, c_float_p, C.c_int32,
+                                C.c_double, C.c_double, c_float_p, c_stream]),
     "rato_cut_solver_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CutConfig)]),
     "rato_cut_solver_destroy": (None, [C.c_void_p]),
     "rato_cut_config_bytes": (C.c_size_t, []),

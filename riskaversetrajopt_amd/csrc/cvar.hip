@@ -984,6 +984,63 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_tail_rows_rollout_kernel(
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
+
+// ---- sums of the matrix-free KKT certificate (rato_kkt_sums) ------------------------------------------------------
+// The reduced solution (u*, slack) of a subproblem, lifted to the reference's QP (y_i = max(-slack, m_i(u*) - t)), is
+// certified against that QP without forming it: every residual is a sum over the samples of quantities the oracle holds
+// -- the m values at u* and, per cut k with a multiplier, its tail weighting w_k (from the m values and the statistics
+// record of the ring slot it was generated in).  With v = t - slack, per block and in fp64:
+//   part[blk][k]         = sum_i w_ki (m_i* - v)^+        k < K     (obstacle-row and y-row complementarity)
+//   part[blk][K + k]     = sum_i w_ki                               (= alpha M: the t- and slack-stationarity)
+//   part[blk][2K]        = sum_i (m_i* - v)^+                       (the CVaR row: sum_i y_i = -slack M + this)
+//   part[blk][2K + 1]    = max_i sum_k lam_k w_ki                   (<= sum_k lam_k: sign of the y-row multipliers)
+__global__ __launch_bounds__(RATO_BLOCK) void kkt_sums_kernel(const float* __restrict__ m_star, long M,
+                                                              const float* __restrict__ m_base,
+                                                              const double* __restrict__ stats_base, long stats_stride,
+                                                              const int* __restrict__ slots,
+                                                              const double* __restrict__ lam, int K, double alphaM,
+                                                              double v, double* __restrict__ part) {
+  extern __shared__ double ks_lds[];   // [4 waves][2K + 2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+  const bool valid = i < M;
+  const float ms = valid ? m_star[i] : 0.0f;
+  const double ex = valid ? fmax((double)ms - v, 0.0) : 0.0;
+  const int nc = 2 * K + 2;
+  double* mine = ks_lds + (size_t)wave * nc;
+  double lw = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const long slot = slots[k];
+    float tstar, lambda;
+    tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
+    const double w = valid ? (double)tail_weight(m_base[slot * M + i], tstar, lambda) : 0.0;
+    lw += lam[k] * w;
+    const double a = rato::wave_sum_dpp(w * ex), b = rato::wave_sum_dpp(w);
+    if (lane == 63) {
+      mine[k] = a;
+      mine[K + k] = b;
+    }
+  }
+  const double e = rato::wave_sum_dpp(ex);
+  double mx = lw;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, RATO_WAVE));
+  if (lane == 63) {
+    mine[2 * K] = e;
+    mine[2 * K + 1] = mx;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < nc; c += RATO_BLOCK) {
+    double r;
+    if (c == nc - 1) {
+      r = fmax(fmax(ks_lds[c], ks_lds[nc + c]), fmax(ks_lds[2 * nc + c], ks_lds[3 * nc + c]));
+    } else {
+      r = (ks_lds[c] + ks_lds[nc + c]) + (ks_lds[2 * nc + c] + ks_lds[3 * nc + c]);
+    }
+    part[(size_t)blockIdx.x * nc + c] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int rato_drone_rowmax_implicit(const rato_drone_params* p, const float* mass, const float* A22,
@@ -1244,3 +1301,18 @@ extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const
   return RATO_OK;
 }
 
+// rato_kkt_sums: see kkt_sums_kernel.  part: [ceil(M/256)][2K + 2] doubles; reduce columns 0 .. 2K with
+// rato_sum_partials_f64 and column 2K + 1 with a maximum.
+extern "C" int rato_kkt_sums(const float* m_star, int64_t M, const float* m_base, const double* stats_base,
+                             int64_t stats_stride, const int32_t* slots, const double* lam, int32_t K, double alphaM,
+                             double v, double* part, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!m_star || M < 1 || K < 0 || K > 512 || !part || (K > 0 && (!m_base || !stats_base || !slots || !lam)))
+    return RATO_EINVAL;
+  const int nblk = rato::nblocks_for((int32_t)M);
+  const size_t lds = sizeof(double) * 4 * (size_t)(2 * K + 2);
+  hipLaunchKernelGGL(kkt_sums_kernel, dim3(nblk), dim3(RATO_BLOCK), lds, rato::as_stream(stream), m_star, (long)M, m_base,
+                     stats_base, (long)stats_stride, slots, lam, (int)K, alphaM, v, part);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}

@@ -455,6 +455,7 @@ class Model:
             cs.begin(u_lin, scp_iter >= 1 and getattr(self, "_world", 1) == 1)
             info = cs.solve(None, None, 0, None, final_du, final_rhs, u_lin=u_lin, with_cvar=(scp_iter >= 1), tol=tol,
                             verbose=verbose)
+            info["final_du"], info["final_rhs"] = final_du, final_rhs    # (the equality rows: certificate.certify)
             return info["us"], info["t_risk"], info
         cs.rollout = None
         r = self.linearize_device(us_mat_p, out=getattr(self, "_lin_buffers", None), rows_out=1 if delta else 0)
@@ -466,6 +467,12 @@ class Model:
                         r["final_rhs"].double().cpu().numpy(), u_lin=u_lin,
                         with_cvar=(scp_iter >= 1), tol=tol, verbose=verbose)
         return info["us"], info["t_risk"], info
+
+    def certify_reduced(self, info):
+        """Matrix-free KKT certificate of the last ``solve_reduced`` (table-free oracle, an iteration with the CVaR rows)
+        against the reference's full QP (driving.py:330-373): certificate.py."""
+        from . import certificate
+        return certificate.certify(self._cut_solver, info, info["final_du"], info["final_rhs"], kappa=1.0)
 
     # ---- Monte-Carlo validation (driving.py:623-671) -----------------------
     def monte_carlo_cost(self, us_mat):

@@ -665,7 +665,14 @@ class Model:
         info = cs.solve(r["G"], r["_W"], r["tile"], r["_g_up"], final_du, final_rhs,
                         u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
                         with_cvar=(scp_iter >= 2), tol=tol, verbose=verbose)
+        info["final_du"], info["final_rhs"] = final_du, final_rhs        # (the equality rows: certificate.certify)
         return info["us"], info["t_risk"], info
+
+    def certify_reduced(self, info):
+        """Matrix-free KKT certificate of the last ``solve_reduced`` (its ``info``; an iteration with the CVaR rows,
+        before any other solve) against the reference's full QP (drone_risk.py:327-368): certificate.py."""
+        from . import certificate
+        return certificate.certify(self._cut_solver, info, info["final_du"], info["final_rhs"], kappa=self.MULTIPLIER)
 
     # ---- Monte-Carlo validation (drone_risk.py:649-695) --------------------
     def monte_carlo_cost(self, us_mat):

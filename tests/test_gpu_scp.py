@@ -866,3 +866,70 @@ def test_native_cut_loop_equals_the_python_loop_bitwise(system, M, S, alpha, met
         assert ma["cuts"] == mb["cuts"] and ma["slack"] == mb["slack"] and ma["uncertified_cuts"] == mb["uncertified_cuts"]
         flat = lambda bs: sorted((int(i), float(sg), float(la)) for idx, sg, lam in bs for i, la in zip(idx, lam))
         assert flat(ma["bounds"]) == flat(mb["bounds"])
+
+
+@pytest.mark.parametrize("system,M,alpha", [("drone", 200, 0.1), ("drone", 1000, 0.05), ("driving", 200, 0.1),
+                                            ("driving", 1000, 0.05)])
+def test_matrix_free_certificate_agrees_with_the_full_qp_certificate(system, M, alpha):
+    """certificate.certify (sums over the samples formed on the device: what bench.py reports at M = 1e5) against
+    tests/_host_cuts.kkt_certificate on the reference-layout QP that the fp64 ORACLE assembles from the same fp32-rounded
+    samples -- the benchmarked path (table-free oracle, native loop).  Both certify the same lifted point: their
+    residuals are small together."""
+    from tests._host_cuts import kkt_certificate
+    from tests._oracle_qp import DroneOracleQP, DrivingOracleQP
+    S = 20
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    if system == "drone":
+        from oracle import drone as od
+        from riskaversetrajopt_amd import drone_risk
+        DWs, masses, Q = (r32(a) for a in od.sample_uncertain_parameters(np.random.RandomState(21), 'saa', M=M, S=S))
+        o, d = od.Model(S, DWs, masses, Q, 'saa', alpha), drone_risk.Model(S, DWs, masses, Q, 'saa', alpha)
+        oq, n_c, n_u, R, kappa, first = DroneOracleQP(o), 6, 3, 3, 0.01, 2
+    else:
+        from oracle import driving as ocar
+        from riskaversetrajopt_amd import driving
+        samples = tuple(r32(a) for a in ocar.sample_uncertain_parameters(np.random.RandomState(21), M, 'saa', S))
+        o, d = ocar.Model(*samples, method='saa', alpha=alpha), driving.Model(M, 'saa', alpha, S=S, samples=samples)
+        oq, n_c, n_u, R, kappa, first = DrivingOracleQP(o), 4, 2, 1, 1.0, 1
+    P, q = oq.get_objective_coeffs()
+    us = d.initial_guess_us_mat()
+    worst_dev, worst_host = {}, {}
+    for it in range(6):
+        nxt, _, info = d.solve_reduced(us, it, tol=1e-10)
+        if it >= first:
+            d._cut_solver._last_info = info
+            cut_data = _device_cut_data(d._cut_solver)                 # (before certify overwrites the scratch slot)
+            c = d.certify_reduced(info)
+            A, l, u = oq.get_constraints_coeffs(us, it)
+            hc = kkt_certificate(A, l, u, P, q, info, cut_data, n_c=n_c, n_u=n_u, S=S, M=M, R=R, kappa=kappa,
+                                 alphaM=d._cut_solver.alphaM, saa=True, u_max=None)
+            hs = max(1.0, hc["multiplier_scale"])
+            for k in ("primal", "stationarity", "dual_sign", "complementarity"):
+                worst_dev[k] = max(worst_dev.get(k, 0.0), c[k])
+                worst_host[k] = max(worst_host.get(k, 0.0), hc[k] / (1.0 if k == "primal" else hs))
+        us = nxt
+    print(system, M, "matrix-free:", {k: "%.1e" % v for k, v in worst_dev.items()},
+          "| full QP (fp64 oracle rows):", {k: "%.1e" % v for k, v in worst_host.items()})
+    # the device rows equal the fp64 oracle's up to the rounding of m to fp32 (6e-8 of |m| <= 1): both certificates see it
+    for k in ("primal", "stationarity", "dual_sign", "complementarity"):
+        assert worst_dev[k] < 1e-7, (k, worst_dev)
+        assert worst_host[k] < 2e-6, (k, worst_host)
+
+
+@pytest.mark.parametrize("system", ["drone", "driving"])
+def test_kkt_certificate_at_the_benchmarked_size(system):
+    """the reduced solution of every subproblem with CVaR rows on bench.py's own batch (M = 1e5)
+    satisfies the KKT conditions of the reference-layout QP (1.5e7 rows) to 1e-7 -- matrix-free, on the device."""
+    d, _ = _bench_batch(system)
+    first = 2 if system == "drone" else 1
+    us = d.initial_guess_us_mat()
+    worst = {}
+    for it in range(first + 6):
+        nxt, _, info = d.solve_reduced(us, it)
+        if it >= first:
+            c = d.certify_reduced(info)
+            for k in ("primal", "stationarity", "dual_sign", "complementarity"):
+                worst[k] = max(worst.get(k, 0.0), c[k])
+        us = nxt
+    print(system, "M=1e5 KKT residuals:", {k: "%.1e" % v for k, v in worst.items()})
+    assert max(worst.values()) < 1e-7, worst
