@@ -511,7 +511,8 @@ typedef struct {
 /* What a solve returns.  Caller-provided arrays: us [nU]; cut_slot / cut_lambda [cut_capacity] (ring slot and
  * multiplier of every cut row of the last master: the data of a KKT certificate against the full QP); bound_var /
  * bound_sign / bound_lambda [bound_capacity] (the control bounds that entered: variable, +1 upper / -1 lower,
- * multiplier).  status 0 solved, 1 maximum cuts reached. */
+ * multiplier).  status 0 solved, 1 maximum cuts reached, 2 solved: the last cut no longer moved the master's solution
+ * (violation <= 1e-7, step <= 1e-10: what is left is the accuracy of the master's own NNLS). */
 typedef struct {
   double* us;
   double slack, t_risk, phi, oracle_s, master_s, lam_slack;

@@ -280,6 +280,8 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
 
   double phi = NAN, tstar = NAN;
   int n_cuts = 0, status = 0;
+  std::vector<double> z_prev(n);
+  bool have_prev = false;
   const int scratch = c.cap - 1;
   const size_t M = (size_t)c.M;
   for (int it = 0; it <= max_cuts; ++it) {
@@ -321,6 +323,18 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
     oracle_s += seconds_since(t0);
     const double slack = z[nU];
     const double viol = phi - c.c_s * slack - c.rhs0;
+    // stall: the cut added last moved nothing although it was violated -- the oracle returns cuts the master already
+    // holds; what is left of the violation is the accuracy of the master's own NNLS (cvar_cuts.py: STALL_*)
+    if (have_prev && viol > tol && viol <= 1e-7) {
+      double step = 0.0;
+      for (int i = 0; i < n; ++i) step = fmax(step, fabs(z[i] - z_prev[i]));
+      if (step <= 1e-10) {
+        status = 2;
+        break;
+      }
+    }
+    z_prev = z;
+    have_prev = true;
     auto add_cut = [&]() -> int {   // phi(u) >= phi_k + g_k.(u - u_k)  =>  g_k.u - c_s s <= rhs0 + g_k.u_k - phi_k
       memcpy(row.data(), g.data(), sizeof(double) * nU);
       row[nU] = -c.c_s;

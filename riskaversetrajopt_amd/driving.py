@@ -418,7 +418,7 @@ class Model:
         goal = np.concatenate((P.position_ego_goal, P.velocity_ego_goal)).astype(np.float64)
         return E, -(xS - goal) + E @ us.reshape(-1)
 
-    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-8, verbose=False, delta=True, rollout=None):
+    def solve_reduced(self, us_mat_p, scp_iter=1, tol=1e-9, verbose=False, delta=True, rollout=None):
         """One SCP iteration without the O(M) QP (see cvar_cuts.py / drone_risk.Model.solve_reduced).
         scp_iter < 1 zeroes every separation row (driving.py:411-415), i.e. no CVaR constraint.
         ``method='baseline'`` (driving.py:320-329): the rows (G_i u)_t <= g_up_{i,t} of every sample as the one

@@ -580,7 +580,7 @@ class Model:
         self._cut_solver = self._gen_buffers = self._lin_buffers = self._define_host = None
         return self
 
-    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-8, verbose=False, implicit=True, generators_only=None,
+    def solve_reduced(self, us_mat_p, scp_iter=2, tol=1e-9, verbose=False, implicit=True, generators_only=None,
                       delta=True, factored=None, rollout=None):
         """One SCP iteration without the O(M) QP: linearize at ``us_mat_p`` on the device, eliminate the
         y_i / t_risk of the reference's QP exactly and solve the remaining problem in (u, slack) by cutting
