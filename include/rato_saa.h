@@ -448,8 +448,8 @@ int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const
  * Qsym, s3 unused; 1 = driving: s0..s3 = dW, x0_ped, w_speed, w_rep):
  *   x_host [S][n_u] doubles (pinned for an asynchronous copy) -> x_dev;  m_out / arg_out = rato_*_rowmax_rollout;
  *   res_dev[0..11) = rato_risk_stats(m_out, alpha, thr);  S > 1: part_dev = rato_*_tail_rows_rollout (K = 1, record =
- *   res_dev, stride 11 + nc), res_dev[11..11+nc) = its column sums, nc = 2(S-1) + 1;  res_dev -> res_host;  the stream
- *   is SYNCHRONISED before the call returns.  Replaces two copies, four calls and a synchronize of the host loop
+ *   res_dev, stride 11 + nc), res_dev[11..11+nc) = its column sums, nc = 2(S-1) + 1;  res_dev -> res_host (PINNED,
+ *   device-visible host memory: the last launch writes it directly, no copy node follows);  the stream is SYNCHRONISED before the call returns.  Replaces two copies, four calls and a synchronize of the host loop
  *   (drone_risk.py:425-469 hands the whole QP to OSQP; here every cut of the reduced subproblem is one such trip).
  */
 int rato_cut_oracle_rollout(int32_t system, const void* params, const double* uk, const float* s0, const float* s1,

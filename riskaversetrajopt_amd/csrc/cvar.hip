@@ -1291,11 +1291,11 @@ extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const
                      : rato_car_tail_rows_rollout(static_cast<const rato_car_params*>(params), uk, s0, s1, s2, s3, m_out,
                                                   arg_out, res_dev, stride, nullptr, 1, alphaM, part_dev, stream);
     if (rc != RATO_OK) return rc;
-    rc = rato_sum_partials_f64(part_dev, (int32_t)rato::nblocks_for(M), nc, 1.0, res_dev + RATO_N_STATS, stream);
-    if (rc != RATO_OK) return rc;
   }
-  e = hipMemcpyAsync(res_host, res_dev, sizeof(double) * (size_t)(RATO_N_STATS + (S > 1 ? nc : 0)), hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  // column sums of the cut + the statistics, written by ONE launch into the device record and into its pinned host copy
+  // (res_host must be device-visible host memory: no copy node follows)
+  rc = rato::launch_cut_finish(part_dev, (int)rato::nblocks_for(M), S > 1 ? nc : 0, res_dev, res_host, RATO_N_STATS, st);
+  if (rc != RATO_OK) return rc;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return RATO_EHIP - (int)e;
   return RATO_OK;

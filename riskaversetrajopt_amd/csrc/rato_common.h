@@ -212,6 +212,11 @@ class TileQueuePool {
   PerDev dev_[kMaxDev];
 };
 
+// stats.hip: column sums of `part` [nblocks][ncols] into rec_dev[n_stats ..) and rec_host[n_stats ..), and
+// rec_host[0 .. n_stats) = rec_dev[0 .. n_stats) -- one launch (rec_host: pinned, device-visible host memory)
+int launch_cut_finish(const double* part, int nblocks, int ncols, double* rec_dev, double* rec_host, int n_stats,
+                      hipStream_t st);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember, per device, the largest size a
 // launch site has raised its kernels to (the first, uncaptured call of a shape makes the runtime call; later calls --
 // including those recorded into a hipGraph -- make none).

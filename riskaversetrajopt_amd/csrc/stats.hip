@@ -59,6 +59,25 @@ __global__ __launch_bounds__(SP_COLS* SP_ROWS) void sum_partials_kernel(const T*
   sum_partials_block(blockIdx.x, part, nblocks, ncols, scale, out);
 }
 
+// The last launch of an oracle round trip (cvar.hip: rato_cut_oracle_rollout): the column sums of the cut's block
+// partials, written to the record on the device AND straight into the pinned host copy of it, while one more workgroup
+// copies the statistics the selection left in the record -- instead of a reduction launch followed by a device-to-host
+// copy (a copy node costs more than this whole kernel).  Same fixed-order sums as sum_partials_kernel<double>.
+__global__ __launch_bounds__(SP_COLS* SP_ROWS) void cut_finish_kernel(const double* __restrict__ part, int nblocks, int ncols,
+                                                                     double* __restrict__ rec_dev,
+                                                                     double* __restrict__ rec_host, int n_stats) {
+  const int col_blocks = (ncols + SP_COLS - 1) / SP_COLS;
+  if ((int)blockIdx.x == col_blocks) {
+    if ((int)threadIdx.x < n_stats) rec_host[threadIdx.x] = rec_dev[threadIdx.x];
+    return;
+  }
+  sum_partials_block(blockIdx.x, part, nblocks, ncols, 1.0, rec_dev + n_stats);
+  // (sum_partials_block ends with thread row 0 holding the sums: re-read what it just wrote)
+  const int cx = threadIdx.x % SP_COLS, ry = threadIdx.x / SP_COLS;
+  const int c = blockIdx.x * SP_COLS + cx;
+  if (ry == 0 && c < ncols) rec_host[n_stats + c] = rec_dev[n_stats + c];
+}
+
 // ------------------------------------------------------------ non-finite check
 __global__ __launch_bounds__(RATO_BLOCK) void count_nonfinite_kernel(const float* __restrict__ x, long n,
                                                                      unsigned* __restrict__ count) {
@@ -764,6 +783,17 @@ extern "C" int rato_sum_partials_f64(const double* part, int32_t nblocks, int32_
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
+
+namespace rato {
+int launch_cut_finish(const double* part, int nblocks, int ncols, double* rec_dev, double* rec_host, int n_stats,
+                      hipStream_t st) {
+  const int col_blocks = ncols > 0 ? (ncols + SP_COLS - 1) / SP_COLS : 0;
+  hipLaunchKernelGGL(cut_finish_kernel, dim3(col_blocks + 1), dim3(SP_COLS * SP_ROWS), 0, st, part, nblocks, ncols, rec_dev,
+                     rec_host, n_stats);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+}  // namespace rato
 
 extern "C" int rato_count_nonfinite(const float* x, int64_t n, uint32_t* count, void* stream) {
   RATO_CLEAR_ERROR();
