@@ -562,6 +562,33 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             "sclk_mhz": sclk}
 
 
+def kkt_block(model, us_final, iters, first_cvar, where):
+    """Optimality of what an SCP block timed, against the reference-layout QP (1.5e7 rows at M = 1e5) and without
+    forming it: the matrix-free KKT certificate (riskaversetrajopt_amd/certificate.py) of (a) the subproblem at the final
+    iterate and (b) the subproblem where the CVaR rows switch on (the hardest one: an O(1) step from the initial guess)
+    -- after and outside the timed loop."""
+    kkt = {}
+    try:
+        keys = ("primal", "stationarity", "dual_sign", "complementarity", "multiplier_scale", "active_cuts")
+        _, _, info = model.solve_reduced(us_final, iters)
+        c = model.certify_reduced(info)
+        kkt["final_subproblem"] = {k: c[k] for k in keys}
+        model._cut_solver = None
+        us = model.initial_guess_us_mat()
+        for k in range(first_cvar + 1):
+            us, _, info = model.solve_reduced(us, k)
+        c = model.certify_reduced(info)
+        kkt["switch_on_subproblem"] = {k: c[k] for k in keys}
+        kkt["residuals"] = (f"KKT conditions of the reference's full QP ({where}) at the lifted reduced solution; rows "
+                            "scaled to unit largest coefficient, dual residuals relative to the multiplier scale; every "
+                            "sum over the samples formed on the device (rato_kkt_sums)")
+        for k in ("primal", "stationarity", "complementarity"):
+            kkt[k] = max(kkt["final_subproblem"][k], kkt["switch_on_subproblem"][k])
+    except Exception as e:                           # a diagnostic must never take the bench line down
+        kkt["error"] = f"{type(e).__name__}: {e}"
+    return kkt
+
+
 def scp_block(work, args):
     """The second half of the BASELINE metric: SCP wall-clock for the drone at the bench's M and S, with the
     reference's timing protocol (drone_times.py:509-550 / drone_risk.py:510-532: a fixed 60 iterations from the
@@ -578,7 +605,9 @@ def scp_block(work, args):
     out = scp.run_drone_reduced(model, num_scp_iters_max=args.scp_iters, verbose=False)
     wall = time.perf_counter() - t0
     st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)
-    return {"system": "drone_risk", "M": work.M, "S": work.S, "alpha": args.alpha, "iters": args.scp_iters,
+    kkt = kkt_block(model, out["us"], args.scp_iters, 2, "drone_risk.py:327-368")
+    return {"system": "drone_risk", "M": work.M, "S": work.S, "alpha": args.alpha, "iters": args.scp_iters, "kkt": kkt,
+            "cut_tolerance": 1e-9, "loop": "rato_cut_solve (native cutting-plane loop, one library call per subproblem)",
             "protocol": "drone_times.py:509-550: fixed iteration count from the initial guess, per-iteration define / "
                         "solve wall-clock, medians + cumulative; run after the timed throughput region",
             "subproblem": "reference QP reduced exactly to (u, slack): device CVaR cuts (Jacobian-free oracle) + host "
@@ -606,6 +635,7 @@ def scp_driving_block(device):
     out = scp.run_driving_reduced(model, num_scp_iters_max=iters, verbose=False)
     st = model.monte_carlo_statistics(out["us"], alpha=alpha)
     return {"system": "driving", "M": M, "S": S, "alpha": alpha, "iters": iters,
+            "kkt": kkt_block(model, out["us"], iters, 1, "driving.py:330-373"),
             "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
             "cumulative_s": float(out["cumulative_s"][-1]), "cuts_max": int(out["cuts"].max()),
             "L2_error_last": float(out["L2_error"][-1]),

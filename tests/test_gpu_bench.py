@@ -29,6 +29,9 @@ def test_default_blocks_at_a_small_size():
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["achieved"] > 0 and 0 < r["frac"] < 1
     assert d["roofline_regenerated"]["algorithmic_bytes_per_launch"] < d["roofline"]["algorithmic_bytes_per_launch"]
     assert d["scp"]["iters"] == 3 and d["scp"]["cumulative_s"] > 0
+    kkt = d["scp"]["kkt"]                               # matrix-free certificate against the reference-layout QP
+    assert "error" not in kkt, kkt
+    assert max(kkt["primal"], kkt["stationarity"], kkt["complementarity"]) < 1e-7, kkt
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["device"]["sclk_mhz_beside_hot_kernel"] > 500
 
