@@ -9,6 +9,8 @@ STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the
 G_RTOL, G_ATOL = 2e-5, 3e-5                # constraint values (drone g reaches ~ -90; measured max 1e-5 abs)
 JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (drone: measured <= 1.8e-5, RATO_TOL_REPORT=1)
 JAC_REL_ROWMAX_DRIVING = 1e-4              # driving: measured <= 3.7e-5 (the 1/r repulsion amplifies the fp32 rollout)
+GUP_RTOL, GUP_ATOL = 5e-5, 2e-4            # g_up = -g + G u_k (|g_up| up to ~1e2: fp32 sums of S products)
+LINEARITY_ABS_DRIVING = 2e-3               # |g_up + g - G.u| recomputed in fp32 from the packed Jacobian (S = 40, |G u| ~ 1e2)
 MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
 RISK_ATOL = 1e-4                           # VaR / CVaR
 NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this
@@ -30,3 +32,22 @@ def assert_satisfied_close(flags, Z_ref, thr=1e-6):
     ref = Z_ref <= thr
     diff = flags != ref
     assert np.all(np.abs(Z_ref[diff] - thr) < NEAR_THRESHOLD), "satisfied flags differ away from the threshold"
+
+
+def assert_below(value, limit, what):
+    """value < limit, printing the measured value under RATO_TOL_REPORT=1 (how the limits of this file were set: 3x the
+    largest value measured on MI355X)"""
+    value = float(value)
+    if os.environ.get("RATO_TOL_REPORT"):
+        print(f"[tol] {what}: measured {value:.2e} (limit {limit:.0e})")
+    assert value < limit, f"{what}: {value:.3e} >= {limit:.0e}"
+
+
+def assert_gup_close(actual, desired, rtol, atol, what="g_up"):
+    """np.testing.assert_allclose with the worst |error| / (atol + rtol |desired|) reported under RATO_TOL_REPORT=1"""
+    actual, desired = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+    err = np.abs(actual - desired)
+    if os.environ.get("RATO_TOL_REPORT"):
+        print(f"[tol] {what}: max abs err {err.max():.2e}; worst err / (atol + rtol |ref|) = "
+              f"{np.max(err / (atol + rtol * np.abs(desired))):.2f} (rtol {rtol:.0e}, atol {atol:.0e})")
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=atol)

@@ -67,7 +67,7 @@ def check_against_oracle(o, d, us, r, idx):
         tol.assert_jac_close(gdu, gdu_o, what="g_obs_du (sampled)")
         assert np.array_equal(gdu == 0.0, gdu_o == 0.0)                           # causal zeros, z column
     gup = r["g_up"][:, :, torch.as_tensor(idx, device=r["g_up"].device)].permute(2, 0, 1).double().cpu().numpy()
-    np.testing.assert_allclose(gup, gup_o, rtol=5e-5, atol=2e-4)
+    tol.assert_gup_close(gup, gup_o, rtol=tol.GUP_RTOL, atol=tol.GUP_ATOL, what="g_up")
     fdu_o, rhs_o = oracle_means(o, us)
     np.testing.assert_allclose(d.expand_final_du(r["du_sum"].cpu().numpy(), 1.0 / M), fdu_o,
                                rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)

@@ -55,7 +55,7 @@ def test_drone_vs_reference_execution(name):
         gdu, gup = d.get_all_constraints_coeffs_batched(us)
         tol.assert_jac_close(gdu, f[f"{kind}_g_obs_du"], what="g_obs_du")
         assert np.array_equal(gdu == 0.0, f[f"{kind}_g_obs_du"] == 0.0)
-        np.testing.assert_allclose(gup, f[f"{kind}_g_up"], rtol=5e-5, atol=2e-4)
+        tol.assert_gup_close(gup, f[f"{kind}_g_up"], rtol=tol.GUP_RTOL, atol=tol.GUP_ATOL, what=f"{name} {kind} g_up")
         fdu, flo, fup = d.sample_means(us)
         np.testing.assert_allclose(fdu, f[f"{kind}_final_du"].mean(0), rtol=tol.MEAN_RTOL, atol=tol.MEAN_ATOL)
         np.testing.assert_allclose(flo, f[f"{kind}_final_low"].mean(0), rtol=tol.MEAN_RTOL, atol=2e-5)
@@ -101,7 +101,7 @@ def test_driving_vs_reference_execution(name):
         gdu, gup = d.get_all_constraints_coeffs_batched(us)
         tol.assert_jac_close(gdu, f[f"{kind}_g_obs_du"], what="g_obs_du")
         assert np.array_equal(gdu == 0.0, f[f"{kind}_g_obs_du"] == 0.0)
-        np.testing.assert_allclose(gup, f[f"{kind}_g_up"], rtol=5e-5, atol=2e-4)
+        tol.assert_gup_close(gup, f[f"{kind}_g_up"], rtol=tol.GUP_RTOL, atol=tol.GUP_ATOL, what=f"{name} {kind} g_up")
         fdu, flo, _ = d.sample_means(us)
         tol.assert_jac_close(fdu, f[f"{kind}_final_du"].mean(0), what="final_du")
         np.testing.assert_allclose(flo, f[f"{kind}_final_low"].mean(0), rtol=1e-5, atol=5e-5)

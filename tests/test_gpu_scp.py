@@ -933,3 +933,38 @@ def test_kkt_certificate_at_the_benchmarked_size(system):
         us = nxt
     print(system, "M=1e5 KKT residuals:", {k: "%.1e" % v for k, v in worst.items()})
     assert max(worst.values()) < 1e-7, worst
+
+
+@pytest.mark.parametrize("system,bound", [("drone", 0.12), ("driving", 0.15)])
+def test_reduced_subproblems_with_controls_pinned_at_their_bounds(system, bound):
+    """|u| <= u_max (drone_risk.py:221-237, driving.py:243-258) ACTIVE: with the bound pulled inside the unconstrained
+    solution, several controls sit at +-u_max; the lazily entering bound rows of the native loop against the fp64 leg
+    (same iterate, every subproblem), and the bound multipliers in the KKT certificate of the full QP."""
+    from tests._host_cuts import DroneReducedOracle, DrivingReducedOracle
+    M, S = 200, 20
+    if system == "drone":
+        o, d = _drone(M, S, alpha=0.1, seed=11)
+        h, iters, first = DroneReducedOracle(o), 5, 2
+    else:
+        o, d = _car(M, S, alpha=0.1, seed=11)
+        h, iters, first = DrivingReducedOracle(o), 5, 1
+    d.u_max, d.u_min = bound, -bound
+    h.cs.u_max, h.cs.u_min = bound, -bound
+    us = h.initial_guess_us_mat()
+    pinned = 0
+    for k in range(iters):
+        ud, td, idv = d.solve_reduced(us, k)
+        uh, th, ih = h.solve_reduced(us, k)
+        assert idv["loop"] == "native" and np.abs(ud).max() <= bound + 1e-9
+        assert np.abs(ud - uh).max() < 1e-5 and abs(td - th) < 1e-5, (k, np.abs(ud - uh).max())
+        at_bound = np.abs(np.abs(ud) - bound) < 1e-9
+        assert np.array_equal(at_bound, np.abs(np.abs(uh) - bound) < 1e-9)
+        if k >= first:
+            n_mult = sum(int((np.asarray(la) > 0).sum()) for _, _, la in idv["multipliers"]["bounds"])
+            assert n_mult <= at_bound.sum()
+            c = d.certify_reduced(idv)
+            assert max(c["primal"], c["stationarity"], c["dual_sign"], c["complementarity"]) < 1e-7, c
+            pinned = max(pinned, int(at_bound.sum()))
+        us = uh
+    print(system, "controls pinned at the bound:", pinned)
+    assert pinned >= 3

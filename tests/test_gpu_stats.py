@@ -333,3 +333,20 @@ def test_facades_recover_from_a_selection_that_gave_up():
     assert rec["var"] == good["var"] and rec["count_satisfied"] == good["count_satisfied"]
     again = stats.risk_stats(Z, 0.1, workspace=ws)                     # and the workspace is usable again
     assert again == good
+
+
+@pytest.mark.parametrize("M", [7, 5000, 20000, 1500000])
+def test_tail_of_less_than_one_sample(M):
+    """floor(alpha M) = 0 (drone_main_plot.py:640-652: index M - 0 - 1 = the maximum; drone_risk.py:694: the closed form
+    with an empty tail sum): VaR = CVaR's threshold = max(Z), in every launch form of the selection."""
+    import torch
+    from oracle import stats as ostats
+    from riskaversetrajopt_amd import stats
+    Z = torch.randn(M, device="cuda") * 0.3 - 0.1
+    alpha = 0.5 / M
+    st = stats.risk_stats(Z, alpha)
+    Zh = Z.double().cpu().numpy()
+    assert st["rank"] == M - 1 and st["var"] == Zh.max() and st["count_above_var"] == 0
+    assert st["var"] == ostats.monte_carlo_var(Zh, alpha)
+    assert abs(st["cvar"] - ostats.monte_carlo_avar(Zh, alpha)) <= 1e-12 * max(1.0, abs(st["cvar"]))
+    assert st["cvar"] == st["var"]                       # empty tail: t + 0 / (alpha M)

@@ -20,7 +20,8 @@ rows = rows[skip:]
 dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
 prev_end = None
 for s, e, name in rows:
-    short = name.split("(")[0].split("<")[0].replace("(anonymous namespace)::", "")
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    short = short.split("<")[0] + ("<" + short.split("<", 1)[1] if "<" in short else "")
     dur[short] += e - s
     cnt[short] += 1
     if prev_end is not None:
