@@ -435,8 +435,29 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         if dist.is_initialized():
             dist.barrier()
 
+    selfcheck = None
     if dist.is_initialized():
         rdist.check_equal_shards(M)       # collective, once, outside the timed region: every step's all-gather relies on it
+        # The first multi-GPU run validates the exchange it is about to time (dist.comm_selfcheck): one untimed step, then
+        # the product exchange of its record against torch.distributed's own all-gather of the same bytes, bit for bit, and
+        # the gathered Z / rank-ordered totals identical on every rank.  A mismatch fails the run on every rank.
+        r0 = work.hot_kernel(slot=0)
+        recs = getattr(work, "records", None)
+        if recs:
+            rec = recs[0]
+        else:
+            sums0 = work.sums(r0).reshape(-1).to(torch.float64)
+            rec = rdist.Record(sums0.numel(), M, device)
+            rec.sums.copy_(sums0)
+            rec.Z.copy_(r0["Z"][:M])
+        torch.cuda.synchronize()
+        selfcheck = rdist.comm_selfcheck(rec)
+        strict = os.environ.get("RATO_STRICT_COMM") == "1"
+        if not selfcheck["ok"] or (strict and selfcheck["rccl_ranks"] != world):
+            if rank == 0:
+                print(f"bench.py: exchange self-check FAILED: {json.dumps(selfcheck)}", file=sys.stderr)
+            barrier()
+            raise SystemExit(3)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     use_graph = world == 1 and not args.overlap and (args.graph == "on" or (args.graph == "auto" and M <= 50000))
@@ -558,8 +579,13 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
                 "GPU, host issue rate excluded), mean over K launches" if use_graph
                 else "HIP events around the launch, mean over the timed steps")
+    kern_ranks = None
+    if dist.is_initialized():             # the dominant kernel on every rank (a straggler GPU shows here, not in the max-over-ranks clock)
+        every = [None] * world
+        dist.all_gather_object(every, float(kern_ms))
+        kern_ranks = {"min": min(every), "max": max(every), "per_rank": every}
     return {"elapsed": elapsed, "kern_ms": kern_ms, "kern_src": kern_src, "stats": final_stats, "launch": launch,
-            "sclk_mhz": sclk}
+            "sclk_mhz": sclk, "comm_selfcheck": selfcheck, "kernel_ms_ranks": kern_ranks}
 
 
 def kkt_block(model, us_final, iters, first_cvar, where):
@@ -760,6 +786,9 @@ def main():
                                          if jacobian == "factored" else "the whole step")),
                        "parallelism": f"sample-sharded x{world}, one all-gather of [sums|Z] per step",
                        "transport": rdist.transport(),
+                       "comm_selfcheck": head["comm_selfcheck"],
+                       "rccl_ranks": (head["comm_selfcheck"] or {}).get("rccl_ranks", 0),
+                       "kernel_ms_ranks": head["kernel_ms_ranks"],
                        "launch": head["launch"]},
             "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
                                        head["kern_src"]),

@@ -254,6 +254,51 @@ def exchange_record(rec, group=None):
     return total, Z_all
 
 
+def comm_selfcheck(rec, group=None, exchange_fn=None):
+    """Collective, before a multi-rank timed region: is the exchange the run is about to time CORRECT?
+
+    The product exchange of ``rec`` (``exchange_record``: rato_comm_exchange -- RCCL behind the C ABI -- when every rank
+    owns a GPU) is compared, bit for bit, with torch.distributed's own all-gather of the same records unpacked by
+    plain tensor views; then the ranks compare digests of what they hold (the gathered Z and the rank-ordered totals
+    must be IDENTICAL on every rank: each runs the same exact selection on them).  Every verdict is agreed with
+    MIN / SUM all-reduces, so all ranks return the same dict:
+      ok, bitwise_vs_torch_all_gather, identical_on_every_rank, rccl_ranks (ranks whose exchange went through
+      rato_comm), world, transport.
+    ``exchange_fn``: the exchange under test (default ``exchange_record``; the gloo tests inject a corrupted one)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ok": True, "world": 1, "rccl_ranks": 0, "transport": transport(group), "skipped": "single process"}
+    world = dist.get_world_size(group)
+    total, Z_all = (exchange_fn or exchange_record)(rec, group)
+    total, Z_all = total.clone(), Z_all.clone()
+    # reference leg: torch's collective on the raw records, unpacked on the host with views (control plane + plumbing)
+    buf = rec.buf.cpu() if (rec.buf.is_cuda and dist.get_backend(group) == "gloo") else rec.buf
+    ref = torch.empty(world * rec.rec_bytes, dtype=torch.uint8, device=buf.device)
+    dist.all_gather_into_tensor(ref, buf.contiguous(), group=group)
+    v = ref.cpu().view(world, rec.rec_bytes)
+    sums = v[:, :8 * rec.n_sums].contiguous().view(torch.float64).view(world, rec.n_sums)
+    total_ref = sums[0].clone()
+    for r in range(1, world):
+        total_ref += sums[r]
+    Z_ref = v[:, 8 * rec.n_sums:].contiguous().view(torch.float32)[:, :rec.M_local].reshape(-1)
+    same = (torch.equal(total.cpu().view(torch.int64), total_ref.view(torch.int64))
+            and torch.equal(Z_all.cpu().view(torch.int32), Z_ref.view(torch.int32)))
+    # digest of what this rank holds: exact integer sums of the bit patterns
+    digest = torch.stack([Z_all.cpu().view(torch.int32).to(torch.int64).sum(),
+                          (total.cpu().view(torch.int64) >> 11).sum()])
+    dev = "cpu" if dist.get_backend(group) == "gloo" else rec.buf.device
+    every = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(every, digest.to(dev), group=group)
+    every = every.cpu().view(world, 2)
+    identical = bool((every == every[0:1]).all())
+    flags = torch.tensor([1 if same else 0, 1 if identical else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+    n_rccl = torch.tensor([1 if _COMMS.get(group) is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(n_rccl, op=dist.ReduceOp.SUM, group=group)
+    same, identical = bool(int(flags[0])), bool(int(flags[1]))
+    return {"ok": same and identical, "bitwise_vs_torch_all_gather": same, "identical_on_every_rank": identical,
+            "rccl_ranks": int(n_rccl.item()), "world": world, "transport": transport(group)}
+
+
 # ---- small helpers for the sharded cutting-plane oracle (cvar_cuts.py) ---------------------------------------
 def _staged(t, group):
     """gloo has no device collectives: stage through the host (tests: two ranks on one GPU)."""

@@ -122,3 +122,43 @@ def test_gather_concat_length_mismatch_raises_on_every_rank_after_a_good_call(tm
     mp.spawn(_mismatch_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"mismatch_{r}.txt").read_text() == "ValueError [True, False]"
+
+
+def _selfcheck_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from riskaversetrajopt_amd import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    rng = np.random.RandomState(5 + rank)
+    rec = rdist.Record(7, 1000, "cpu", z_row=1003)
+    rec.sums.copy_(torch.from_numpy(rng.randn(7)))
+    rec.Z.copy_(torch.from_numpy(rng.randn(1000).astype(np.float32)))
+    good = rdist.comm_selfcheck(rec)
+
+    def corrupted(r, group=None):                    # an exchange that delivers ONE wrong float, on rank 1 only
+        total, Z_all = rdist.exchange_record(r, group)
+        Z_all = Z_all.clone()
+        if rank == 1:
+            Z_all[17] += 1.0
+        return total, Z_all
+    bad = rdist.comm_selfcheck(rec, exchange_fn=corrupted)
+    import json
+    with open(os.path.join(tmpdir, f"selfcheck_{rank}.json"), "w") as f:
+        json.dump({"good": good, "bad": bad}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_selfcheck_agrees_on_every_rank(tmp_path):
+    """bench.py --gpus N validates the exchange before it times it (dist.comm_selfcheck): every rank returns the same
+    verdict, a single wrong float on one rank fails the run on ALL ranks."""
+    import json
+    world = 2
+    mp.spawn(_selfcheck_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / f"selfcheck_{r}.json")) for r in range(world)]
+    assert res[0] == res[1]
+    assert res[0]["good"]["ok"] and res[0]["good"]["world"] == 2 and res[0]["good"]["rccl_ranks"] == 0
+    assert res[0]["good"]["bitwise_vs_torch_all_gather"] and res[0]["good"]["identical_on_every_rank"]
+    assert not res[0]["bad"]["ok"] and not res[0]["bad"]["identical_on_every_rank"]
+    from riskaversetrajopt_amd import dist as rdist
+    assert rdist.comm_selfcheck(None)["ok"]                 # single process: nothing to check

@@ -40,3 +40,28 @@ def test_default_blocks_at_a_small_size():
 def test_other_configs_run(config):
     d = _run(["--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     assert d["value"] > 0 and d["config"]["baseline_config"] == config and d["roofline"]["kernel_ms"] > 0
+
+
+def test_two_ranks_validate_their_exchange_before_timing():
+    """`bench.py --gpus 2` (two ranks sharing the one GPU of the test box over gloo): before the timed region the run
+    validates the exchange it is about to time (dist.comm_selfcheck) and reports it with the per-rank kernel times."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RATO_DIST_BACKEND="gloo", RATO_SINGLE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--M", "3000", "--S", "20",
+                          "--steps", "3", "--warmup", "1", "--jacobian", "products"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["M_total"] == 6000 and d["value"] > 0
+    sc = cfg["comm_selfcheck"]
+    assert sc["ok"] and sc["bitwise_vs_torch_all_gather"] and sc["identical_on_every_rank"] and sc["world"] == 2
+    assert cfg["rccl_ranks"] == 0 and "gloo" in cfg["transport"]          # two ranks on one device: RCCL refuses that
+    assert len(cfg["kernel_ms_ranks"]["per_rank"]) == 2 and cfg["kernel_ms_ranks"]["min"] > 0
+    # --strict-comm: a run whose exchange is not the library's RCCL communicator on every rank must not report a number
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--M", "3000", "--S", "20",
+                          "--steps", "3", "--warmup", "1", "--jacobian", "products", "--strict-comm"], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
