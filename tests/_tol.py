@@ -8,9 +8,10 @@ import numpy as np
 STATE_RTOL, STATE_ATOL = 1e-5, 2e-5        # trajectories (|x| up to ~40 for the car)
 G_RTOL, G_ATOL = 2e-5, 3e-5                # constraint values (drone g reaches ~ -90; measured max 1e-5 abs)
 JAC_REL_ROWMAX = 3e-5                      # Jacobian entries, relative to the row's max |entry| (drone: measured <= 1.8e-5, RATO_TOL_REPORT=1)
-JAC_REL_ROWMAX_DRIVING = 1e-4              # driving: measured <= 3.7e-5 (the 1/r repulsion amplifies the fp32 rollout)
-GUP_RTOL, GUP_ATOL = 5e-5, 2e-4            # g_up = -g + G u_k (|g_up| up to ~1e2: fp32 sums of S products)
-LINEARITY_ABS_DRIVING = 2e-3               # |g_up + g - G.u| recomputed in fp32 from the packed Jacobian (S = 40, |G u| ~ 1e2)
+JAC_REL_ROWMAX_DRIVING = 6e-5              # driving: measured <= 3.7e-5 over all rounds (round 4 run: <= 9.7e-6); the 1/r repulsion amplifies the fp32 rollout
+GUP_RTOL, GUP_ATOL = 5e-5, 2e-4            # g_up = -g + G u_k (|g_up| up to ~1e2: fp32 sums of S products); measured worst
+#                                            error / (atol + rtol |ref|) = 0.63 (profiles/r04_tolerances.txt): 1.6x margin
+LINEARITY_ABS_DRIVING = 2e-5               # |g_up + g - G.u| recomputed in fp32 from the packed Jacobian (S = 40): measured 3.8e-6
 MEAN_RTOL, MEAN_ATOL = 1e-5, 1e-6          # sample means (fp64 accumulation across blocks)
 RISK_ATOL = 1e-4                           # VaR / CVaR
 NEAR_THRESHOLD = 1e-4                      # satisfied-flag may differ only if |Z - thr| < this

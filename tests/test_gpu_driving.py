@@ -207,12 +207,12 @@ def test_C5_shard_size_properties():
                          what="C5 shard g_up (sampled)")
 
 
-@pytest.mark.parametrize("gap", [1e-2, 1.0])
+@pytest.mark.parametrize("gap", [4e-3, 1.0])
 def test_pedestrian_near_contact(gap):
     """The reference's singular edge: force_on_pedestrian divides by |p_ego - p_ped| (driving.py:154) and the separation
     distance differentiates the same norm (driving.py:228).  Pedestrians are placed so that the ego passes within ``gap``
-    of them (1e-2: the unit normal turns by O(1) within one step and dn/dp ~ 1/gap = 100; 1.0: deep inside the minimum
-    separation distance, constraint strongly violated).  HIP vs the fp64 oracle on the same numbers: finite everywhere,
+    of them (4e-3: closest approach < 1e-2 -- the unit normal turns by O(1) within one step and dn/dp ~ 1/r > 100; 1.0: deep
+    inside the minimum separation distance, constraint strongly violated).  HIP vs the fp64 oracle on the same numbers: finite everywhere,
     states / distances to the usual tolerances away from the singular step, Jacobian rows to 1/gap times the usual one."""
     from oracle import driving as ocar
     from riskaversetrajopt_amd import driving
@@ -236,10 +236,10 @@ def test_pedestrian_near_contact(gap):
     xs_o = o.us_to_state_trajectories(us)
     delta = np.linalg.norm(xs_o[:, :, 0:2] - xs_o[:, :, 4:6], axis=-1)
     print(f"gap {gap}: closest approach {delta.min():.3e}")
-    assert delta.min() < 3 * gap
+    assert delta.min() < max(1e-2, 3 * gap)
     xs = d.us_to_state_trajectories(us)
     assert np.isfinite(xs).all()
-    amp = max(1.0, 1.0 / gap)
+    amp = max(1.0, 1.0 / delta.min())
     np.testing.assert_allclose(xs, xs_o, rtol=tol.STATE_RTOL * amp, atol=tol.STATE_ATOL * amp)
     r = d.linearize_device(us)
     gdu = d.expand_g_obs_du(r["G"], M)
@@ -284,5 +284,6 @@ def test_ragged_last_tile_at_the_C5_shard_size():
     st = stats.risk_stats(r["Z"], 0.05)
     srt = np.sort(Zh)
     assert st["var"] == srt[M - int(np.floor(0.05 * M)) - 1] and st["max"] == srt[-1]
-    again = d.linearize_device(us)
-    assert bool((again["G"] == r["G"]).all()) and bool((again["Z"] == r["Z"]).all())
+    again = d.linearize_device(us)                     # (lanes >= M of the last tile are not written: compare the samples)
+    assert bool((untile(again["G"], M) == Gp).all()) and bool((again["Z"] == r["Z"]).all())
+    assert bool((again["g_up"] == r["g_up"]).all())

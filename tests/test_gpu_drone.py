@@ -353,5 +353,5 @@ def test_ragged_last_tile_at_the_C2_size():
     st = stats.risk_stats(r["Z"][:M], 0.1)
     srt = np.sort(Zh)
     assert st["var"] == srt[M - int(np.floor(0.1 * M)) - 1] and st["max"] == srt[-1]
-    again = d.linearize_device(us)
-    assert bool((again["G"] == r["G"]).all()) and bool((again["Z"] == r["Z"]).all())
+    again = d.linearize_device(us)                     # (lanes >= M of the last tile are not written: compare the samples)
+    assert bool((d.packed_jacobian(again) == d.packed_jacobian(r)).all()) and bool((again["Z"][:M] == r["Z"][:M]).all())
