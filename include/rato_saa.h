@@ -86,7 +86,8 @@ extern "C" {
  * (rato_sum_partials_f64), rato_saa_tail_rows folded into rato_saa_tail_rows_batch (slots == NULL), params.rows_out,
  * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
  * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
- * (9: rato_cut_solver_* / rato_cut_begin / rato_cut_solve -- the cutting-plane loop of a subproblem as one call)
+ * (9: rato_cut_solver_* / rato_cut_begin / rato_cut_solve -- the cutting-plane loop of a subproblem as one call;
+ * params.signal + rato_*_companion -- the statistics beside the kernel that produces their input)
  * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
 #define RATO_ABI_VERSION 9
@@ -142,6 +143,9 @@ typedef struct rato_drone_params {
   double x_init64[6];
   double x_final64[6];
   double obs_xy64[RATO_DRONE_NOBS][2];
+  uint32_t* signal;     /* NULL, or rato_risk_stats_signal(workspace): the row-parallel linearize kernel then tells a
+                           COMPANION statistics launch (rato_*_companion, started beside it on another stream) when
+                           every tile's Z has landed and when its last workgroup has left -- see the statistics section */
 } rato_drone_params;
 
 /*
@@ -226,6 +230,7 @@ typedef struct rato_car_params {
   /* the same constants in double precision, for the entry points that compute in fp64 (rato_car_*_rollout) */
   double dt64, beta64, speed_ped_des64, d_min64;
   double ego_init64[4];
+  uint32_t* signal;      /* as rato_drone_params.signal */
 } rato_car_params;
 
 /* Scratch floats needed by the driving entry points for the shared ego
@@ -730,6 +735,28 @@ int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
  * unclean by an aborted call.  The Python facades do this by themselves (stats.risk_stats, CvarCutSolver.evaluate). */
 int rato_risk_stats_recover(const float* Z, int64_t M, double alpha, float thr,
                             void* workspace, size_t workspace_bytes, double* out, void* stream);
+
+/*
+ * COMPANION statistics (round 4).  The exact selection is a chain of short dependent phases (9-15 us) that needs nothing
+ * but Z -- and a row-parallel linearize kernel has written every tile's Z long before it has finished storing the
+ * Jacobian (Z is the maximum over the rollout; the rows are swept afterwards).  So the statistics can run BESIDE the
+ * kernel that produces their input instead of behind it:
+ *   1. give the linearize call  params.signal = rato_risk_stats_signal(workspace)  (row-parallel kernels only:
+ *      cols_per_thread = -1; Z must be requested) and launch it on stream A;
+ *   2. launch rato_risk_stats_companion / rato_sums_and_risk_stats_companion with the same workspace on stream B, ordered
+ *      behind whatever stream A ran BEFORE the linearize call (an event) but NOT behind the call itself.
+ * The statistics workgroups wait (clock-bounded, like the one-launch selection) until the producer has counted every
+ * tile's Z in, the partial-sum workgroups until its last workgroup has left; both lower the flags again, so a workspace
+ * serves one step at a time.  Results are those of rato_risk_stats / rato_sums_and_risk_stats bit for bit (same kernels).
+ * M <= 1,048,576 (the one-launch forms); RATO_EINVAL beyond.  Works under hipGraph capture as a fork / join of two streams.
+ */
+#define RATO_SIGNAL_WORDS 8
+uint32_t* rato_risk_stats_signal(void* workspace);
+int rato_risk_stats_companion(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
+                              double* out, void* stream);
+int rato_sums_and_risk_stats_companion(const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
+                                       const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                                       size_t workspace_bytes, double* out, void* stream);
 
 /* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
  * M <= 1,048,576 (the partial-sum workgroups ride along with the selection workgroups; two stream-ordered calls

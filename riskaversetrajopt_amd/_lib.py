@@ -19,7 +19,8 @@ class DroneParams(C.Structure):
                 ("obs_xy", (C.c_float * 2) * 3), ("rows_out", C.c_int32),      # 28 words: the doubles start 8-byte aligned
                 ("dt64", C.c_double), ("beta64", C.c_double), ("drag64", C.c_double), ("kp64", C.c_double),
                 ("kd64", C.c_double), ("tol64", C.c_double), ("x_init64", C.c_double * 6),
-                ("x_final64", C.c_double * 6), ("obs_xy64", (C.c_double * 2) * 3)]
+                ("x_final64", C.c_double * 6), ("obs_xy64", (C.c_double * 2) * 3),
+                ("signal", C.c_void_p)]      # companion statistics: rato_risk_stats_signal(workspace), or NULL
 
 
 class CarParams(C.Structure):
@@ -27,7 +28,7 @@ class CarParams(C.Structure):
                 ("speed_ped_des", C.c_float), ("d_min", C.c_float), ("tol", C.c_float),
                 ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32),   # 16 words
                 ("dt64", C.c_double), ("beta64", C.c_double), ("speed_ped_des64", C.c_double), ("d_min64", C.c_double),
-                ("ego_init64", C.c_double * 4)]
+                ("ego_init64", C.c_double * 4), ("signal", C.c_void_p)]
 
 
 class CutConfig(C.Structure):
@@ -151,6 +152,12 @@ SIGNATURES = {
                                            C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
+    "rato_risk_stats_signal": (C.c_void_p, [C.c_void_p]),
+    "rato_risk_stats_companion": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
+                                            c_float_p, c_stream]),
+    "rato_sums_and_risk_stats_companion": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_float_p,
+                                                     C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p,
+                                                     c_stream]),
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }

@@ -677,6 +677,16 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
           zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
         }
         if (valid) Z[m] = zmax - P.tol;
+        if (P.signal) {   // companion statistics (rato_saa.h): this tile's Z has landed; the last one raises z_ready
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (lane == 0) {
+            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == (unsigned)n_tiles_total - 1u) {
+              __hip_atomic_store(P.signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
       }
     } else {
       const int t = task;
@@ -757,6 +767,17 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     if (gone == gridDim.x - 1) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (P.signal) {   // companion statistics: the workgroup that leaves last raises all_ready (every output is complete)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned c = __hip_atomic_fetch_add(P.signal + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (c == gridDim.x - 1) {
+        __hip_atomic_store(P.signal + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.signal + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -868,6 +889,7 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
   int32_t spt = cols_per_thread, tile = 0;
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
   if (!dW && spt != -1) return RATO_EINVAL;
+  if (p->signal && (spt != -1 || !Z)) return RATO_EINVAL;   // companion statistics: row-parallel kernel, Z requested
   // the ego prologue (trajectory + per-step tangents Epos, Eu) serves the forward/column kernel; the row-parallel
   // kernel builds its ego tables itself, under the latency of its noise loads
   if (spt != -1)

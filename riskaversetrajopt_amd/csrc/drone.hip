@@ -935,6 +935,16 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
           }
         }
         if (valid) Z[m] = zmax - P.tol;
+        if (P.signal) {   // companion statistics (rato_saa.h): this tile's Z has landed; the last one raises z_ready
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (lane == 0) {
+            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == (unsigned)n_tiles_total - 1u) {
+              __hip_atomic_store(P.signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
       }
     } else {
       const int t = task;
@@ -1021,6 +1031,17 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     if (gone == gridDim.x - 1) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (P.signal) {   // companion statistics: the workgroup that leaves last raises all_ready (every output is complete)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned c = __hip_atomic_fetch_add(P.signal + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (c == gridDim.x - 1) {
+        __hip_atomic_store(P.signal + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.signal + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -1167,6 +1188,7 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   if (!dW && cpt != -1) return RATO_EINVAL;
   if (W && cpt != -1) return RATO_EINVAL;  // the factored output exists for the row-parallel kernel only
+  if (p->signal && (cpt != -1 || !Z)) return RATO_EINVAL;   // companion statistics: row-parallel kernel, Z requested
   if (A22 && !W) return RATO_EINVAL;       // the step-Jacobian table goes with the factored output
   hipStream_t st = rato::as_stream(stream);
   if (cpt == -1) {

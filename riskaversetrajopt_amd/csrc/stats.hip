@@ -91,6 +91,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void count_nonfinite_kernel(const float
 }
 
 // ------------------------------------------------------------- risk stats
+constexpr unsigned long long RS_COOP_WAIT_TICKS = 10ull * 100000000ull;   // 10 s of s_memrealtime (100 MHz)
 constexpr int B1 = 2048, B2 = 2048, B3 = 1024;  // 11 + 11 + 10 key bits
 constexpr int RS_MAX_BLOCKS = 1024;
 
@@ -103,7 +104,13 @@ struct Workspace {
   unsigned nblocks;
   unsigned magic;   // set by rato_risk_stats_init: the histograms start zeroed and every call leaves them zeroed
   unsigned ticket;  // rs_coop: completion tickets (0 between calls)
+  // Signal words of a COMPANION launch (rato_*_companion: the statistics started beside the kernel that produces Z, on
+  // another stream): the producer (a row-parallel linearize kernel given params.signal = these words) counts the tiles
+  // whose Z has landed / the workgroups that have left, and raises z_ready / all_ready; the statistics wait for them
+  // and lower them again.  All zero between steps.
+  unsigned sig[RATO_SIGNAL_WORDS];
 };
+constexpr int SIG_Z_COUNT = 0, SIG_WG_COUNT = 1, SIG_Z_READY = 2, SIG_ALL_READY = 3, SIG_SUM_DONE = 4;
 constexpr unsigned RS_MAGIC = 0x52A70517u;
 
 // order-preserving map float -> uint32 (ascending)
@@ -331,6 +338,46 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 //  was built and measured at 25-108 us for M = 1e4-1e5 against 20 us for six launches: one CU needs 11-23 us of issue
 //  time for 1e5 elements, and constraint values cluster in 4 key bins per binade, so almost nothing is filtered by the
 //  first pass.  Removed; git history has it.)
+// Companion launches: every workgroup waits (thread 0 polls, bounded by the clock like find_bin_coop) until the
+// producer has raised `flag`; -> false when the wait expired (the caller then reports NaN statistics).
+__device__ bool wait_signal(unsigned* flag) {
+  __shared__ unsigned s_ok;
+  if (threadIdx.x == 0) {
+    const unsigned long long t_start = wall_clock64();
+    unsigned ok = 1;
+    for (unsigned tries = 0; __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++tries) {
+      if ((tries & 255u) == 255u && wall_clock64() - t_start > RS_COOP_WAIT_TICKS) {
+        ok = 0;
+        break;
+      }
+      if (tries < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __syncthreads();
+  return ok;
+}
+
+// the partial-sum workgroups of a companion launch: wait for the producer's LAST workgroup, sum, and the one that
+// finishes last lowers the flag again
+template <typename T>
+__device__ void sum_partials_companion(int col_block, int n_col_blocks, const T* __restrict__ part, int nblocks, int ncols,
+                                       double scale, double* __restrict__ out, unsigned* sig) {
+  const bool ok = wait_signal(sig + SIG_ALL_READY);
+  if (ok) sum_partials_block(col_block, part, nblocks, ncols, scale, out);
+  else if (threadIdx.x == 0 && col_block == 0) out[0] = __longlong_as_double(0x7ff8000000000000LL);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(sig + SIG_SUM_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)n_col_blocks - 1u) {
+      __hip_atomic_store(sig + SIG_SUM_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sig + SIG_ALL_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 constexpr int RS1_T = 1024;
 constexpr long RS_SMALL_MAX = 12 * 1024;   // crossover with rs_coop (below): 14.0 vs 14.7 us at M = 1e4, 19.1 vs 15.6 us at M = 2e4
 
@@ -339,10 +386,19 @@ constexpr int RS_SMALL_KEYS = (int)(RS_SMALL_MAX / RS1_T);   // keys per thread 
 __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                   int var_is_max, float thr, double* __restrict__ out,
                                                   const float* __restrict__ part, int nblocks, int ncols,
-                                                  double scale, double* __restrict__ sums_out) {
+                                                  double scale, double* __restrict__ sums_out, unsigned* sig) {
   if (blockIdx.x > 0) {   // the sample-mean second stage rides along (independent workgroups)
-    sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
+    if (sig) sum_partials_companion((int)blockIdx.x - 1, (int)gridDim.x - 1, part, nblocks, ncols, scale, sums_out, sig);
+    else sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
     return;
+  }
+  if (sig) {   // companion launch: Z is being produced beside this kernel
+    const bool ok = wait_signal(sig + SIG_Z_READY);
+    if (threadIdx.x == 0) __hip_atomic_store(sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) {
+      if (threadIdx.x < RATO_N_STATS) out[threadIdx.x] = __longlong_as_double(0x7ff8000000000000LL);
+      return;
+    }
   }
   __shared__ unsigned h[B1];
   __shared__ double red[5][RS1_T / RATO_WAVE];
@@ -505,7 +561,6 @@ constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 1
 //     not all resident yet (another stream holds the CUs) is NOT a failure: its waiting workgroups keep polling until
 //     the rest has been scheduled and has added its keys, however long the other stream's kernel takes (the first
 //     version gave up after 2^18 polls ~ 0.5 s and poisoned the statistics of a merely delayed launch).
-constexpr unsigned long long RS_COOP_WAIT_TICKS = 10ull * 100000000ull;   // 10 s of s_memrealtime (100 MHz)
 template <int NB, int NT>
 __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, unsigned expected, unsigned& bin,
                               unsigned& krem, unsigned& bincount) {
@@ -569,9 +624,11 @@ __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, uns
 __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                  int var_is_max, float thr, int G, Workspace* __restrict__ ws,
                                                  double* __restrict__ out, const float* __restrict__ part, int nblocks,
-                                                 int ncols, double scale, double* __restrict__ sums_out) {
+                                                 int ncols, double scale, double* __restrict__ sums_out, int companion) {
   if ((int)blockIdx.x >= G) {   // the sample-mean second stage rides along (independent workgroups, no barriers)
-    sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
+    if (companion)
+      sum_partials_companion((int)blockIdx.x - G, (int)gridDim.x - G, part, nblocks, ncols, scale, sums_out, ws->sig);
+    else sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
     return;
   }
   const int tid = threadIdx.x;
@@ -579,6 +636,9 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
     if (blockIdx.x == 0 && tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
     return;
   }
+  // companion launch: Z is being produced beside this kernel (the flag is lowered by the workgroup that finishes last;
+  // a wait that expires leaves the histogram protocol short of keys, which ends in NaN statistics below)
+  const bool z_ok = companion ? wait_signal(ws->sig + SIG_Z_READY) : true;
   __shared__ unsigned h[B1];
   __shared__ double red[6][RS1_T / RATO_WAVE];
   __shared__ unsigned last_flag;
@@ -617,7 +677,7 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
   }
   flush_hist<B1, RS1_T>(h, ws->hist1);
   unsigned b1 = 0, k1 = 0, c1 = 0, b2 = 0, k2 = 0, c2 = 0, b3 = 0, k3 = 0, c3 = 0;   // (a failed pass leaves them unset)
-  bool ok = find_bin_coop<B1, RS1_T>(ws->hist1, k, (unsigned)n, b1, k1, c1);
+  bool ok = z_ok && find_bin_coop<B1, RS1_T>(ws->hist1, k, (unsigned)n, b1, k1, c1);
   for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
   __syncthreads();
 #pragma unroll
@@ -639,7 +699,10 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
   ok = ok && find_bin_coop<B3, RS1_T>(ws->hist3, k2, c2, b3, k3, c3);
   if (!ok) {   // the histograms never added up: the workspace was not clean.  NaN out, un-tag the workspace.
     if (tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
-    if (tid == 0) ws->magic = 0;
+    if (tid == 0) {
+      ws->magic = 0;
+      if (companion) __hip_atomic_store(ws->sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
@@ -684,7 +747,10 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
   if (!last_flag) return;
   // every workgroup has read hist3 before taking its ticket: zero the histograms and the counters for the next call
   for (int i = tid; i < B1 + B2 + B3; i += RS1_T) ws->hist1[i] = 0;   // hist1..3 are contiguous
-  if (tid == 0) ws->ticket = 0;
+  if (tid == 0) {
+    ws->ticket = 0;
+    if (companion) __hip_atomic_store(ws->sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (tid >= RATO_WAVE) return;
   double s = 0, c = 0, m = -INFINITY, tl = 0, g = 0, e = 0;
   if (tid < G) {   // G <= 64: one partial per lane, folded by the fixed shuffle tree (independent of who came last)
@@ -827,7 +893,7 @@ extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
 namespace {
 int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
                     double* out, const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
-                    void* stream, bool recover = false) {
+                    void* stream, bool recover = false, bool companion = false) {
   RATO_CLEAR_ERROR();
   if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
     return RATO_EINVAL;
@@ -851,7 +917,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   static const int force_coop = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'c') ? 1 : 0; }();
   if (M <= RS_SMALL_MAX && !force_multi && !force_coop) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
     hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out,
-                       part, (int)nblocks, (int)ncols, scale, sums_out);
+                       part, (int)nblocks, (int)ncols, scale, sums_out, companion ? ws->sig : (unsigned*)nullptr);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
@@ -862,10 +928,11 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     long G = (M + RS1_T * kpt - 1) / (RS1_T * kpt);
     if (G > RS_COOP_MAX_WG) G = RS_COOP_MAX_WG;
     hipLaunchKernelGGL(rs_coop, dim3((unsigned)G + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr,
-                       (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out);
+                       (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out, companion ? 1 : 0);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
+  if (companion) return RATO_EINVAL;   // the launch-per-pass form waits for nothing: M <= 1,048,576 only
   if (part) {
     hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sp_blocks), dim3(SP_COLS * SP_ROWS), 0, st, part, (int)nblocks,
                        (int)ncols, scale, sums_out);
@@ -921,4 +988,23 @@ extern "C" int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int3
   if (!part) return RATO_EINVAL;
   return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, part, nblocks, ncols, scale, sums_out,
                          stream);
+}
+
+// ---- companion launches (round 4) -----------------------------------------------------------------------------------
+extern "C" uint32_t* rato_risk_stats_signal(void* workspace) {
+  return workspace ? static_cast<Workspace*>(workspace)->sig : nullptr;
+}
+
+extern "C" int rato_risk_stats_companion(const float* Z, int64_t M, double alpha, float thr, void* workspace,
+                                         size_t workspace_bytes, double* out, void* stream) {
+  if (M > RS_COOP_MAX) return RATO_EINVAL;
+  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream, false, true);
+}
+
+extern "C" int rato_sums_and_risk_stats_companion(const float* part, int32_t nblocks, int32_t ncols, double scale,
+                                                  double* sums_out, const float* Z, int64_t M, double alpha, float thr,
+                                                  void* workspace, size_t workspace_bytes, double* out, void* stream) {
+  if (!part || M > RS_COOP_MAX) return RATO_EINVAL;
+  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, part, nblocks, ncols, scale, sums_out, stream,
+                         false, true);
 }

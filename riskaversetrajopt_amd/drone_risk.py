@@ -236,7 +236,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0):
+                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0, signal=None):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -256,6 +256,8 @@ class Model:
         reduction into the single launch of the risk statistics.
         ``rows_out=1``: the ``g_up`` buffer receives the constraint values g at ``us_mat`` instead of
         g_up = -g + (grad g).u (the base of the cut oracle's delta form, cvar_cuts.py).
+        ``signal`` (``stats.signal_ptr(workspace)``; row-parallel kernel only): the kernel tells a companion statistics
+        launch on another stream when Z / everything has landed (``step_device(companion=...)``).
         """
         dW, mass, Qsym, M = self._inputs(inputs)
         ld, S = mass.numel(), self.S
@@ -298,6 +300,8 @@ class Model:
         if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
             o = dict(o, sums=None)
         p = self._params(M, ld, rows_out)
+        if signal:
+            p.signal = signal
         if events is not None:
             events[0].record()
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
@@ -438,21 +442,37 @@ class Model:
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
-    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, **kw):
+    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, companion=None, **kw):
         """One single-GPU SAA step in TWO launches: the linearize kernel, then ONE launch that reduces the sample
         sums (drone_risk.py:294-296) and computes fraction satisfied / VaR / CVaR of Z (:661, :663-695,
-        drone_main_plot.py:640-652) -- rato_sums_and_risk_stats.  -> (linearize result dict, stats double[N_STATS])."""
+        drone_main_plot.py:640-652) -- rato_sums_and_risk_stats.  -> (linearize result dict, stats double[N_STATS]).
+        ``companion`` (a ``stats.Companion``; row-parallel kernel, M <= 1,048,576, ``workspace`` given): the second launch
+        runs BESIDE the first on the companion's stream -- the selection starts when the last tile's Z has landed, long
+        before the Jacobian has been stored, and only the tiny reduction of the sample sums is left behind the kernel."""
+        alpha = self.alpha if alpha is None else alpha
+        M = self._inputs(kw.get("inputs"))[3]
+        if companion is not None and workspace is not None and M <= stats.COMPANION_MAX_M and \
+                self.linearize_plan(M, self._inputs(kw.get("inputs"))[1].numel(), kw.get("cols_per_thread", 0),
+                                    kw.get("samples_per_lane", 0))[1] == -1:
+            companion.fork()
+            r = self.linearize_device(us_mat, out=out, events=events, reduce=False, signal=stats.signal_ptr(workspace), **kw)
+            with torch.cuda.stream(companion.stream):
+                _, st = stats.sums_and_risk_stats_companion_device(r["part"], r["Z"], alpha, workspace=workspace,
+                                                                   sums_out=r["sums"], out=stats_out)
+            companion.join()
+            return r, st
         r = self.linearize_device(us_mat, out=out, events=events, reduce=False, **kw)
-        _, st = stats.sums_and_risk_stats_device(r["part"], r["Z"], self.alpha if alpha is None else alpha,
-                                                 workspace=workspace, sums_out=r["sums"], out=stats_out)
+        _, st = stats.sums_and_risk_stats_device(r["part"], r["Z"], alpha, workspace=workspace, sums_out=r["sums"],
+                                                 out=stats_out)
         return r, st
 
     # ---- hipGraph: one SCP-iteration's device work as a single replayable graph -------------
-    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None):
+    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None, companion=False):
         """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
         only the capture/replay plumbing; the nodes are this library's kernels).  Returns a
         ``StepGraph``: write the controls into ``.us`` (device tensor, (S, n_u)), call ``.replay()``
-        and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[10], rato_saa.h)."""
+        and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[10], rato_saa.h).
+        ``companion``: the statistics as a second BRANCH of the graph, beside the linearize node (``step_device``)."""
         alpha = self.alpha if alpha is None else alpha
         us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
         out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane,
@@ -461,12 +481,15 @@ class Model:
         st = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
         kw = dict(cols_per_thread=out["cols_per_thread"], samples_per_lane=out["samples_per_lane"],
                   factored=out["factored"])
-        self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, **kw)      # warm-up: uncaptured first call
+        comp = stats.Companion(self.device) if companion else None
+        self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, companion=comp, **kw)   # warm-up: uncaptured first call
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            res, _ = self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, **kw)
-        return StepGraph(graph, us, res, st)
+            res, _ = self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, companion=comp, **kw)
+        sg = StepGraph(graph, us, res, st)
+        sg.workspace, sg.companion = ws, comp
+        return sg
 
     # ---- L3: sparse QP assembly (drone_risk.py:221-237, 282-423) -----------
     MULTIPLIER = 0.01           # drone_risk.py:307,353: constraint rows are scaled by 0.01
