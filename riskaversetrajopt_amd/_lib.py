@@ -155,9 +155,6 @@ SIGNATURES = {
     "rato_risk_stats_signal": (C.c_void_p, [C.c_void_p]),
     "rato_risk_stats_companion": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                             c_float_p, c_stream]),
-    "rato_sums_and_risk_stats_companion": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_double, c_float_p, c_float_p,
-                                                     C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p,
-                                                     c_stream]),
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }

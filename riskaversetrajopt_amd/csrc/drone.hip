@@ -934,14 +934,22 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
             zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
           }
         }
-        if (valid) Z[m] = zmax - P.tol;
-        if (P.signal) {   // companion statistics (rato_saa.h): this tile's Z has landed; the last one raises z_ready
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!P.signal) {
+          if (valid) Z[m] = zmax - P.tol;
+        } else {
+          // Companion statistics (rato_saa.h): a selection kernel on another stream is waiting for every tile's Z.  Z goes
+          // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
+          // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
+          // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
+          if (valid)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
-            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c == (unsigned)n_tiles_total - 1u) {
               __hip_atomic_store(P.signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -1031,17 +1039,6 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     if (gone == gridDim.x - 1) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (P.signal) {   // companion statistics: the workgroup that leaves last raises all_ready (every output is complete)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const unsigned c = __hip_atomic_fetch_add(P.signal + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (c == gridDim.x - 1) {
-        __hip_atomic_store(P.signal + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(P.signal + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
   }
 }

@@ -104,13 +104,13 @@ struct Workspace {
   unsigned nblocks;
   unsigned magic;   // set by rato_risk_stats_init: the histograms start zeroed and every call leaves them zeroed
   unsigned ticket;  // rs_coop: completion tickets (0 between calls)
-  // Signal words of a COMPANION launch (rato_*_companion: the statistics started beside the kernel that produces Z, on
-  // another stream): the producer (a row-parallel linearize kernel given params.signal = these words) counts the tiles
-  // whose Z has landed / the workgroups that have left, and raises z_ready / all_ready; the statistics wait for them
-  // and lower them again.  All zero between steps.
+  // Signal words of a COMPANION launch (rato_risk_stats_companion: the statistics started beside the kernel that
+  // produces Z, on another stream): the producer (a row-parallel linearize kernel given params.signal = these words)
+  // counts the tiles whose Z has landed in sig[0] and raises sig[2] (z_ready) with the last one; the statistics wait
+  // for it and lower it again.  All zero between steps.
   unsigned sig[RATO_SIGNAL_WORDS];
 };
-constexpr int SIG_Z_COUNT = 0, SIG_WG_COUNT = 1, SIG_Z_READY = 2, SIG_ALL_READY = 3, SIG_SUM_DONE = 4;
+constexpr int SIG_Z_COUNT = 0, SIG_Z_READY = 2;
 constexpr unsigned RS_MAGIC = 0x52A70517u;
 
 // order-preserving map float -> uint32 (ascending)
@@ -360,24 +360,6 @@ __device__ bool wait_signal(unsigned* flag) {
   return ok;
 }
 
-// the partial-sum workgroups of a companion launch: wait for the producer's LAST workgroup, sum, and the one that
-// finishes last lowers the flag again
-template <typename T>
-__device__ void sum_partials_companion(int col_block, int n_col_blocks, const T* __restrict__ part, int nblocks, int ncols,
-                                       double scale, double* __restrict__ out, unsigned* sig) {
-  const bool ok = wait_signal(sig + SIG_ALL_READY);
-  if (ok) sum_partials_block(col_block, part, nblocks, ncols, scale, out);
-  else if (threadIdx.x == 0 && col_block == 0) out[0] = __longlong_as_double(0x7ff8000000000000LL);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(sig + SIG_SUM_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == (unsigned)n_col_blocks - 1u) {
-      __hip_atomic_store(sig + SIG_SUM_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sig + SIG_ALL_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 constexpr int RS1_T = 1024;
 constexpr long RS_SMALL_MAX = 12 * 1024;   // crossover with rs_coop (below): 14.0 vs 14.7 us at M = 1e4, 19.1 vs 15.6 us at M = 2e4
 
@@ -388,8 +370,7 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
                                                   const float* __restrict__ part, int nblocks, int ncols,
                                                   double scale, double* __restrict__ sums_out, unsigned* sig) {
   if (blockIdx.x > 0) {   // the sample-mean second stage rides along (independent workgroups)
-    if (sig) sum_partials_companion((int)blockIdx.x - 1, (int)gridDim.x - 1, part, nblocks, ncols, scale, sums_out, sig);
-    else sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
+    sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
     return;
   }
   if (sig) {   // companion launch: Z is being produced beside this kernel
@@ -626,9 +607,7 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
                                                  double* __restrict__ out, const float* __restrict__ part, int nblocks,
                                                  int ncols, double scale, double* __restrict__ sums_out, int companion) {
   if ((int)blockIdx.x >= G) {   // the sample-mean second stage rides along (independent workgroups, no barriers)
-    if (companion)
-      sum_partials_companion((int)blockIdx.x - G, (int)gridDim.x - G, part, nblocks, ncols, scale, sums_out, ws->sig);
-    else sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
+    sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
     return;
   }
   const int tid = threadIdx.x;
@@ -899,6 +878,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     return RATO_EINVAL;
   if (workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
   if (part && (!sums_out || nblocks <= 0 || ncols <= 0)) return RATO_EINVAL;
+  if (part && companion) return RATO_EINVAL;   // the partial sums are complete at the END of the producer: not beside it
   // ascending 0-based rank of sort(Z)[M - floor(alpha*M) - 1]  (drone_main_plot.py:649-651)
   long xth = (long)floor(alpha * (double)M);
   long kk = M - xth - 1;
@@ -999,12 +979,4 @@ extern "C" int rato_risk_stats_companion(const float* Z, int64_t M, double alpha
                                          size_t workspace_bytes, double* out, void* stream) {
   if (M > RS_COOP_MAX) return RATO_EINVAL;
   return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream, false, true);
-}
-
-extern "C" int rato_sums_and_risk_stats_companion(const float* part, int32_t nblocks, int32_t ncols, double scale,
-                                                  double* sums_out, const float* Z, int64_t M, double alpha, float thr,
-                                                  void* workspace, size_t workspace_bytes, double* out, void* stream) {
-  if (!part || M > RS_COOP_MAX) return RATO_EINVAL;
-  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, part, nblocks, ncols, scale, sums_out, stream,
-                         false, true);
 }

@@ -447,8 +447,9 @@ class Model:
         sums (drone_risk.py:294-296) and computes fraction satisfied / VaR / CVaR of Z (:661, :663-695,
         drone_main_plot.py:640-652) -- rato_sums_and_risk_stats.  -> (linearize result dict, stats double[N_STATS]).
         ``companion`` (a ``stats.Companion``; row-parallel kernel, M <= 1,048,576, ``workspace`` given): the second launch
-        runs BESIDE the first on the companion's stream -- the selection starts when the last tile's Z has landed, long
-        before the Jacobian has been stored, and only the tiny reduction of the sample sums is left behind the kernel."""
+        statistics run BESIDE the kernel on the companion's stream -- the selection starts when the last tile's Z has
+        landed, long before the Jacobian has been stored -- and only the tiny reduction of the sample sums (complete when
+        the kernel ends) is left behind it."""
         alpha = self.alpha if alpha is None else alpha
         M = self._inputs(kw.get("inputs"))[3]
         if companion is not None and workspace is not None and M <= stats.COMPANION_MAX_M and \
@@ -457,8 +458,8 @@ class Model:
             companion.fork()
             r = self.linearize_device(us_mat, out=out, events=events, reduce=False, signal=stats.signal_ptr(workspace), **kw)
             with torch.cuda.stream(companion.stream):
-                _, st = stats.sums_and_risk_stats_companion_device(r["part"], r["Z"], alpha, workspace=workspace,
-                                                                   sums_out=r["sums"], out=stats_out)
+                st = stats.risk_stats_companion_device(r["Z"], alpha, workspace=workspace, out=stats_out)
+            stats.sum_partials(r["part"], out=r["sums"])      # complete only when the kernel ends: stream-ordered behind it
             companion.join()
             return r, st
         r = self.linearize_device(us_mat, out=out, events=events, reduce=False, **kw)

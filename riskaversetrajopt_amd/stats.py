@@ -112,26 +112,6 @@ def risk_stats_companion_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=Non
     return out
 
 
-def sums_and_risk_stats_companion_device(part, Z, alpha, thr=SATISFIED_THRESHOLD, scale=1.0, workspace=None,
-                                         sums_out=None, out=None, stream=None):
-    """``sums_and_risk_stats_device`` beside the producer of ``part`` and ``Z`` (rato_sums_and_risk_stats_companion)."""
-    lib = _lib.load()
-    _lib.require_f32_device(part, "part")
-    Z = _as_device_f32(Z)
-    if workspace is None:
-        raise _lib.RatoError("a companion launch needs the workspace whose signal words the producer was given")
-    if sums_out is None:
-        sums_out = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
-    if out is None:
-        out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
-    _lib.check(lib.rato_sums_and_risk_stats_companion(_lib.ptr(part), part.shape[0], part[0].numel(), float(scale),
-                                                      _lib.ptr(sums_out), _lib.ptr(Z), Z.numel(), float(alpha), float(thr),
-                                                      _lib.ptr(workspace), workspace.numel(), _lib.ptr(out),
-                                                      _lib.current_stream() if stream is None else stream),
-               "rato_sums_and_risk_stats_companion")
-    return sums_out, out
-
-
 def risk_stats_recover_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):
     """The same record by the launch-per-pass form on a re-initialised workspace (rato_risk_stats_recover): what to call
     when ``risk_stats_device`` came back NaN on finite input -- the one-launch forms give up, loudly, when the workgroups
