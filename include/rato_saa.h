@@ -87,7 +87,7 @@ extern "C" {
  * rato_drone_rowmax_rollout / rato_drone_tail_rows_rollout, rato_comm_available, rato_device_occupy; 8: fp64 constants in
  * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
  * (9: rato_cut_solver_* / rato_cut_begin / rato_cut_solve -- the cutting-plane loop of a subproblem as one call;
- * params.signal + rato_risk_stats_companion -- the statistics beside the kernel that produces their input)
+ * params.stats_* -- the statistics of Z in extra workgroups of the row-parallel linearize launch itself)
  * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
 #define RATO_ABI_VERSION 9
@@ -143,9 +143,17 @@ typedef struct rato_drone_params {
   double x_init64[6];
   double x_final64[6];
   double obs_xy64[RATO_DRONE_NOBS][2];
-  uint32_t* signal;     /* NULL, or rato_risk_stats_signal(workspace): the row-parallel linearize kernel then tells a
-                           COMPANION statistics launch (rato_risk_stats_companion, started beside it on another stream)
-                           when every tile's Z has landed -- see the statistics section */
+  /* Statistics in the SAME launch (round 4).  stats_workspace != NULL (an initialised rato_risk_stats workspace; row-parallel
+     kernel only: cols_per_thread = -1; Z requested; M <= 524,288): the linearize launch carries a few extra workgroups
+     that compute the rato_risk_stats record of the Z it produces -- double stats_out[RATO_N_STATS], tail level stats_alpha,
+     threshold stats_thr -- as soon as the last tile's Z has landed, while the Jacobian is still being stored: the
+     dependent statistics launch behind the kernel disappears.  Same selection, same record (fp64 sums equal to summation
+     order).  Ignored by every other entry point. */
+  void* stats_workspace;
+  double* stats_out;
+  double stats_alpha;
+  float stats_thr;
+  int32_t stats_reserved;
 } rato_drone_params;
 
 /*
@@ -230,7 +238,11 @@ typedef struct rato_car_params {
   /* the same constants in double precision, for the entry points that compute in fp64 (rato_car_*_rollout) */
   double dt64, beta64, speed_ped_des64, d_min64;
   double ego_init64[4];
-  uint32_t* signal;      /* as rato_drone_params.signal */
+  void* stats_workspace;  /* statistics in the same launch: as rato_drone_params.stats_* */
+  double* stats_out;
+  double stats_alpha;
+  float stats_thr;
+  int32_t stats_reserved;
 } rato_car_params;
 
 /* Scratch floats needed by the driving entry points for the shared ego
@@ -735,28 +747,6 @@ int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr,
  * unclean by an aborted call.  The Python facades do this by themselves (stats.risk_stats, CvarCutSolver.evaluate). */
 int rato_risk_stats_recover(const float* Z, int64_t M, double alpha, float thr,
                             void* workspace, size_t workspace_bytes, double* out, void* stream);
-
-/*
- * COMPANION statistics (round 4).  The exact selection is a chain of short dependent phases (9-15 us) that needs nothing
- * but Z -- and a row-parallel linearize kernel has written every tile's Z long before it has finished storing the
- * Jacobian (Z is the maximum over the rollout; the rows are swept afterwards).  So the statistics can run BESIDE the
- * kernel that produces their input instead of behind it:
- *   1. give the linearize call  params.signal = rato_risk_stats_signal(workspace)  (row-parallel kernels only:
- *      cols_per_thread = -1; Z must be requested) and launch it on stream A.  The kernel then writes Z with agent-scope
- *      atomic stores, counts every tile in and raises a flag with the last one (no fence: a release fence per tile would
- *      write back an XCD's whole L2 in the middle of the Jacobian's store stream);
- *   2. launch rato_risk_stats_companion with the same workspace on stream B, ordered behind whatever stream A ran
- *      BEFORE the linearize call (an event) but NOT behind the call itself.
- * The statistics workgroups wait (clock-bounded, like the one-launch selection) for the flag and lower it again, so a
- * workspace serves one step at a time.  The record is that of rato_risk_stats bit for bit (same kernels).  The partial
- * sums of the sample mean are complete only when the producer ENDS: rato_sum_partials stays a stream-ordered launch
- * behind it.  M <= 1,048,576 (the one-launch forms); RATO_EINVAL beyond.  Works under hipGraph capture as a fork / join
- * of two streams.
- */
-#define RATO_SIGNAL_WORDS 8
-uint32_t* rato_risk_stats_signal(void* workspace);
-int rato_risk_stats_companion(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
-                              double* out, void* stream);
 
 /* rato_sum_partials(part, nblocks, ncols, scale, sums_out) and rato_risk_stats(Z, ...) in ONE launch when
  * M <= 1,048,576 (the partial-sum workgroups ride along with the selection workgroups; two stream-ordered calls

@@ -20,7 +20,9 @@ class DroneParams(C.Structure):
                 ("dt64", C.c_double), ("beta64", C.c_double), ("drag64", C.c_double), ("kp64", C.c_double),
                 ("kd64", C.c_double), ("tol64", C.c_double), ("x_init64", C.c_double * 6),
                 ("x_final64", C.c_double * 6), ("obs_xy64", (C.c_double * 2) * 3),
-                ("signal", C.c_void_p)]      # companion statistics: rato_risk_stats_signal(workspace), or NULL
+                # statistics in the same launch (row-parallel linearize kernel): workspace, record, tail level, threshold
+                ("stats_workspace", C.c_void_p), ("stats_out", C.c_void_p), ("stats_alpha", C.c_double),
+                ("stats_thr", C.c_float), ("stats_reserved", C.c_int32)]
 
 
 class CarParams(C.Structure):
@@ -28,7 +30,9 @@ class CarParams(C.Structure):
                 ("speed_ped_des", C.c_float), ("d_min", C.c_float), ("tol", C.c_float),
                 ("ego_init", C.c_float * 4), ("ego_goal", C.c_float * 4), ("rows_out", C.c_int32),   # 16 words
                 ("dt64", C.c_double), ("beta64", C.c_double), ("speed_ped_des64", C.c_double), ("d_min64", C.c_double),
-                ("ego_init64", C.c_double * 4), ("signal", C.c_void_p)]
+                ("ego_init64", C.c_double * 4),
+                ("stats_workspace", C.c_void_p), ("stats_out", C.c_void_p), ("stats_alpha", C.c_double),
+                ("stats_thr", C.c_float), ("stats_reserved", C.c_int32)]
 
 
 class CutConfig(C.Structure):
@@ -152,9 +156,6 @@ SIGNATURES = {
                                            C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
-    "rato_risk_stats_signal": (C.c_void_p, [C.c_void_p]),
-    "rato_risk_stats_companion": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
-                                            c_float_p, c_stream]),
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }

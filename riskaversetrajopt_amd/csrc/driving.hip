@@ -18,6 +18,7 @@
 
 #include "philox.h"
 #include "rato_common.h"
+#include "rato_select.h"
 
 namespace {
 
@@ -389,8 +390,17 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     rato_car_params P, uint64_t seed, float noise_scale, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
-    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole) {
+    float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole,
+    const rato_sel::StatsTail tail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
+  // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
+  // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
+  const int n_prod = tail.ws ? tail.n_prod : (int)gridDim.x;
+  if ((int)blockIdx.x >= n_prod) {
+    rato_sel::stats_tail_run<CROWS_NW * RATO_WAVE>(tail, Z, (long)P.M, car_lds_raw);
+    return;
+  }
+  unsigned* const z_signal = tail.ws ? tail.ws->sig : nullptr;
   const size_t M = (size_t)P.M;
   const int S = P.S;
   constexpr int NT = CROWS_NW * RATO_WAVE;
@@ -676,10 +686,10 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
           const float dx = e.x - q.x, dy = e.y - q.y;
           zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
         }
-        if (!P.signal) {
+        if (!z_signal) {
           if (valid) Z[m] = zmax - P.tol;
         } else {
-          // Companion statistics (rato_saa.h): a selection kernel on another stream is waiting for every tile's Z.  Z goes
+          // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
           // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
           // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
           // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
@@ -688,10 +698,10 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
                                __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
-            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c == (unsigned)n_tiles_total - 1u) {
-              __hip_atomic_store(P.signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   }
 #endif
   if (threadIdx.x == 0)
-    head[2] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    head[2] = n_prod + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   unit = head[2];
 #if RATO_CDIAG >= 4
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
 #endif
   if (LOOP && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == gridDim.x - 1) {
+    if (gone == (unsigned)n_prod - 1u) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -886,7 +896,8 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
   int32_t spt = cols_per_thread, tile = 0;
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
   if (!dW && spt != -1) return RATO_EINVAL;
-  if (p->signal && (spt != -1 || !Z)) return RATO_EINVAL;   // companion statistics: row-parallel kernel, Z requested
+  if (p->stats_workspace && (spt != -1 || !Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0)))
+    return RATO_EINVAL;   // statistics in the same launch: row-parallel kernel, Z requested
   // the ego prologue (trajectory + per-step tangents Epos, Eu) serves the forward/column kernel; the row-parallel
   // kernel builds its ego tables itself, under the latency of its noise loads
   if (spt != -1)
@@ -942,7 +953,25 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       if (split < 1) split = 1;
       grid_x = n_tiles * split;
     }
-    dim3 grid(grid_x), block(CROWS_NW * RATO_WAVE);
+    // statistics of Z in extra workgroups of this launch (params.stats_*)
+    rato_sel::StatsTail tail = {};
+    size_t lds_launch = lds;
+    int grid_launch = grid_x;
+    if (p->stats_workspace) {
+      int Gs = 0;
+      const int extra = rato_sel::stats_tail_workgroups<CROWS_NW * RATO_WAVE>(p->M, Gs);
+      if (extra < 0) return RATO_EINVAL;   // beyond the one-launch forms of the selection: use rato_risk_stats
+      tail.ws = static_cast<rato_sel::Workspace*>(p->stats_workspace);
+      tail.out = p->stats_out;
+      tail.alpha = p->stats_alpha;
+      tail.thr = p->stats_thr;
+      tail.G = Gs;
+      tail.n_prod = grid_x;
+      rato_sel::stats_rank(p->M, p->stats_alpha, tail.k, tail.var_is_max);
+      grid_launch = grid_x + extra;
+      if (lds_launch < rato_sel::rs_body_lds_bytes<CROWS_NW * RATO_WAVE>()) lds_launch = rato_sel::rs_body_lds_bytes<CROWS_NW * RATO_WAVE>();
+    }
+    dim3 grid(grid_launch), block(CROWS_NW * RATO_WAVE);
     if (queue) {
       // the last `tail_tiles` tiles of the queue as `tail_split` parts each (RATO_CAR_TAIL_SPLIT / RATO_CAR_TAIL_TILES).
       // OFF by default: unlike the drone's products output it does not pay here -- C5 shard (M = 125,000, 1954 tiles
@@ -957,18 +986,18 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       if (tail_tiles > n_tiles) tail_tiles = n_tiles;
       const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
       if (dW)
-        hipLaunchKernelGGL((car_linearize_rows_kernel<true, false>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
-                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
+        hipLaunchKernelGGL((car_linearize_rows_kernel<true, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail);
       else
-        hipLaunchKernelGGL((car_linearize_rows_kernel<true, true>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
-                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole);
+        hipLaunchKernelGGL((car_linearize_rows_kernel<true, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail);
     } else {
       if (dW)
-        hipLaunchKernelGGL((car_linearize_rows_kernel<false, false>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
-                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
+        hipLaunchKernelGGL((car_linearize_rows_kernel<false, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail);
       else
-        hipLaunchKernelGGL((car_linearize_rows_kernel<false, true>), grid, block, lds, st, *p, seed, noise_scale, us, dW,
-                           x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0);
+        hipLaunchKernelGGL((car_linearize_rows_kernel<false, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail);
     }
     RATO_LAUNCH_CHECK();
     return RATO_OK;

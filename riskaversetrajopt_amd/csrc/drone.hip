@@ -15,6 +15,7 @@
 
 #include "philox.h"
 #include "rato_common.h"
+#include "rato_select.h"
 
 namespace {
 
@@ -714,8 +715,16 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     uint64_t seed, float noise_scale, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
-    float* __restrict__ part) {
+    float* __restrict__ part, const rato_sel::StatsTail tail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
+  // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
+  const int n_prod = tail.ws ? tail.n_prod : (int)gridDim.x;
+  if ((int)blockIdx.x >= n_prod) {
+    rato_sel::stats_tail_run<ROWS_NW * RATO_WAVE>(tail, Z, (long)P.M, lds_raw);
+    return;
+  }
+  unsigned* const z_signal = tail.ws ? tail.ws->sig : nullptr;
   const size_t M = (size_t)P.M, ld = (size_t)P.ld;
   const int S = P.S;
   const int lane = threadIdx.x & (RATO_WAVE - 1);
@@ -934,10 +943,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
             zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
           }
         }
-        if (!P.signal) {
+        if (!z_signal) {
           if (valid) Z[m] = zmax - P.tol;
         } else {
-          // Companion statistics (rato_saa.h): a selection kernel on another stream is waiting for every tile's Z.  Z goes
+          // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
           // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
           // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
           // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
@@ -946,10 +955,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
                                __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
-            const unsigned c = __hip_atomic_fetch_add(P.signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c == (unsigned)n_tiles_total - 1u) {
-              __hip_atomic_store(P.signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(P.signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   if (tile_queue) {
     __syncthreads();   // every wave has finished this tile's rows: the tables are dead, head[] may be rewritten
     if (threadIdx.x == 0)
-      next_tile[0] = (int)gridDim.x + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      next_tile[0] = n_prod + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     unit = next_tile[0];
   } else if (tile_stride > 0) {
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     // the queue cleans up after itself: the workgroup that leaves last (its own final fetch came back empty, like
     // everybody's before it) resets both words for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == gridDim.x - 1) {
+    if (gone == (unsigned)n_prod - 1u) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1185,7 +1194,8 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   if (!dW && cpt != -1) return RATO_EINVAL;
   if (W && cpt != -1) return RATO_EINVAL;  // the factored output exists for the row-parallel kernel only
-  if (p->signal && (cpt != -1 || !Z)) return RATO_EINVAL;   // companion statistics: row-parallel kernel, Z requested
+  if (p->stats_workspace && (cpt != -1 || !Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0)))
+    return RATO_EINVAL;   // statistics in the same launch: row-parallel kernel, Z requested
   if (A22 && !W) return RATO_EINVAL;       // the step-Jacobian table goes with the factored output
   hipStream_t st = rato::as_stream(stream);
   if (cpt == -1) {
@@ -1279,9 +1289,28 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
         }
       }
     }
-#define RATO_ROWS_LAUNCH(F, PH)                                                                                    \
-  hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid), dim3(ROWS_NW * RATO_WAVE), lds, st, *p, n_whole, \
-                     split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, Z, part)
+    // statistics of Z in extra workgroups of this launch (params.stats_*)
+    rato_sel::StatsTail tail = {};
+    size_t lds_launch = lds;
+    int grid_launch = grid;
+    if (p->stats_workspace) {
+      int Gs = 0;
+      const int extra = rato_sel::stats_tail_workgroups<ROWS_NW * RATO_WAVE>(p->M, Gs);
+      if (extra < 0) return RATO_EINVAL;   // beyond the one-launch forms of the selection: use rato_risk_stats
+      tail.ws = static_cast<rato_sel::Workspace*>(p->stats_workspace);
+      tail.out = p->stats_out;
+      tail.alpha = p->stats_alpha;
+      tail.thr = p->stats_thr;
+      tail.G = Gs;
+      tail.n_prod = grid;
+      rato_sel::stats_rank(p->M, p->stats_alpha, tail.k, tail.var_is_max);
+      grid_launch = grid + extra;
+      if (lds_launch < rato_sel::rs_body_lds_bytes<ROWS_NW * RATO_WAVE>()) lds_launch = rato_sel::rs_body_lds_bytes<ROWS_NW * RATO_WAVE>();
+    }
+#define RATO_ROWS_LAUNCH(F, PH)                                                                                     \
+  hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid_launch), dim3(ROWS_NW * RATO_WAVE), lds_launch, st, \
+                     *p, n_whole, split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, \
+                     Z, part, tail)
     if (W) {
       if (dW) RATO_ROWS_LAUNCH(true, false); else RATO_ROWS_LAUNCH(true, true);
     } else {

@@ -12,8 +12,10 @@
 #include <atomic>
 
 #include "rato_common.h"
+#include "rato_select.h"
 
 namespace {
+using namespace rato_sel;
 
 // ------------------------------------------------------------ sum partials
 // 1024 threads = 16 columns x 64 row lanes.  Row lanes stride over the blocks with 4
@@ -91,90 +93,6 @@ __global__ __launch_bounds__(RATO_BLOCK) void count_nonfinite_kernel(const float
 }
 
 // ------------------------------------------------------------- risk stats
-constexpr unsigned long long RS_COOP_WAIT_TICKS = 10ull * 100000000ull;   // 10 s of s_memrealtime (100 MHz)
-constexpr int B1 = 2048, B2 = 2048, B3 = 1024;  // 11 + 11 + 10 key bits
-constexpr int RS_MAX_BLOCKS = 1024;
-
-struct Workspace {
-  unsigned hist1[B1];
-  unsigned hist2[B2];
-  unsigned hist3[B3];
-  double blockpart[RS_MAX_BLOCKS][6];  // sum Z, count(Z<=thr), max Z, tail sum, count(Z>t), count(Z==t)
-  float tstar;
-  unsigned nblocks;
-  unsigned magic;   // set by rato_risk_stats_init: the histograms start zeroed and every call leaves them zeroed
-  unsigned ticket;  // rs_coop: completion tickets (0 between calls)
-  // Signal words of a COMPANION launch (rato_risk_stats_companion: the statistics started beside the kernel that
-  // produces Z, on another stream): the producer (a row-parallel linearize kernel given params.signal = these words)
-  // counts the tiles whose Z has landed in sig[0] and raises sig[2] (z_ready) with the last one; the statistics wait
-  // for it and lower it again.  All zero between steps.
-  unsigned sig[RATO_SIGNAL_WORDS];
-};
-constexpr int SIG_Z_COUNT = 0, SIG_Z_READY = 2;
-constexpr unsigned RS_MAGIC = 0x52A70517u;
-
-// order-preserving map float -> uint32 (ascending)
-// order-preserving key of a float.  -0.0 takes the key of +0.0, so that comparing keys (the one-launch forms) and
-// comparing values (rs_tail, the tail-row kernels of cvar.hip: m > t, m == t) give the same counts and tail weights
-// when the threshold is a zero of either sign.  (NaN has no place in a sorted order: callers check finiteness --
-// rato_count_nonfinite -- before the statistics mean anything.)
-__device__ __forceinline__ unsigned key_of(float f) {
-  unsigned u = __float_as_uint(f);
-  if (u == 0x80000000u) u = 0u;
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float value_of(unsigned k) {
-  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
-}
-
-// Whole block: find the bin containing ascending rank k in hist[0..NB) and the
-// rank remaining inside that bin.  Result is returned to every thread.
-template <int NB, int NT = RATO_BLOCK>
-__device__ void find_bin(const unsigned* __restrict__ hist, unsigned k, unsigned& bin, unsigned& krem) {
-  constexpr int PER = NB / NT;
-  static_assert(PER >= 1 && PER * NT == NB, "bins must divide evenly over the threads");
-  __shared__ unsigned wsum[NT / RATO_WAVE];
-  __shared__ unsigned res[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned local[PER], tot = 0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    local[i] = hist[tid * PER + i];
-    tot += local[i];
-  }
-  const unsigned incl = rato::wave_scan_dpp(tot);  // inclusive scan across the wave (DPP, no LDS round trips)
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  unsigned base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  unsigned excl = base + incl - tot;
-  if (k >= excl && k < excl + tot) {
-    unsigned run = excl;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      if (k >= run && k < run + local[i]) {
-        res[0] = tid * PER + i;
-        res[1] = k - run;
-      }
-      run += local[i];
-    }
-  }
-  __syncthreads();
-  bin = res[0];
-  krem = res[1];
-  __syncthreads();
-}
-
-template <int NB, int NT = RATO_BLOCK>
-__device__ void flush_hist(unsigned* lds_hist, unsigned* __restrict__ ghist) {
-  __syncthreads();
-  for (int i = threadIdx.x; i < NB; i += NT) {
-    const unsigned c = lds_hist[i];
-    if (c) atomicAdd(&ghist[i], c);
-  }
-}
-
 __global__ __launch_bounds__(RATO_BLOCK) void rs_pass1(const float* __restrict__ Z, long M, float thr,
                                                        Workspace* __restrict__ ws) {
   __shared__ unsigned h[B1];
@@ -338,32 +256,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void rs_final(long M, double alpha, uns
 //  was built and measured at 25-108 us for M = 1e4-1e5 against 20 us for six launches: one CU needs 11-23 us of issue
 //  time for 1e5 elements, and constraint values cluster in 4 key bins per binade, so almost nothing is filtered by the
 //  first pass.  Removed; git history has it.)
-// Companion launches: every workgroup waits (thread 0 polls, bounded by the clock like find_bin_coop) until the
-// producer has raised `flag`; -> false when the wait expired (the caller then reports NaN statistics).
-__device__ bool wait_signal(unsigned* flag) {
-  __shared__ unsigned s_ok;
-  if (threadIdx.x == 0) {
-    const unsigned long long t_start = wall_clock64();
-    unsigned ok = 1;
-    for (unsigned tries = 0; __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++tries) {
-      if ((tries & 255u) == 255u && wall_clock64() - t_start > RS_COOP_WAIT_TICKS) {
-        ok = 0;
-        break;
-      }
-      if (tries < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
-    }
-    s_ok = ok;
-  }
-  __syncthreads();
-  const bool ok = s_ok != 0;
-  __syncthreads();
-  return ok;
-}
-
 constexpr int RS1_T = 1024;
-constexpr long RS_SMALL_MAX = 12 * 1024;   // crossover with rs_coop (below): 14.0 vs 14.7 us at M = 1e4, 19.1 vs 15.6 us at M = 2e4
-
-constexpr int RS_SMALL_KEYS = (int)(RS_SMALL_MAX / RS1_T);   // keys per thread (registers)
 
 __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                   int var_is_max, float thr, double* __restrict__ out,
@@ -373,151 +266,10 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
     sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
     return;
   }
-  if (sig) {   // companion launch: Z is being produced beside this kernel
-    const bool ok = wait_signal(sig + SIG_Z_READY);
-    if (threadIdx.x == 0) __hip_atomic_store(sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!ok) {
-      if (threadIdx.x < RATO_N_STATS) out[threadIdx.x] = __longlong_as_double(0x7ff8000000000000LL);
-      return;
-    }
-  }
   __shared__ unsigned h[B1];
-  __shared__ double red[5][RS1_T / RATO_WAVE];
+  __shared__ double red[5 * (RS1_T / RATO_WAVE)];
   __shared__ float redmax[RS1_T / RATO_WAVE];
-  const int tid = threadIdx.x;
-  const int n = (int)M;
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 0] = (double)wall_clock64();
-#endif
-  // every load of the thread in flight before anything else (Z comes from HBM: its producer's L2 was written back)
-  float z[RS_SMALL_KEYS];
-#pragma unroll
-  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
-    const int i = tid + u * RS1_T;
-    z[u] = (i < n) ? Z[i] : 0.0f;
-  }
-  for (int i = tid; i < B1; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  unsigned key[RS_SMALL_KEYS];
-  double sum = 0.0, cnt = 0.0;
-  float mx = -INFINITY;
-  {
-    // constraint values cluster (a binade holds only 4 of the 2048 first-pass bins), and same-address LDS atomics
-    // serialise: a thread folds runs of equal bins of its own elements into one atomic (measured: 18 -> 12 us at
-    // M = 1e4 of clustered values)
-    unsigned run_bin = 0xffffffffu, run_cnt = 0;
-#pragma unroll
-    for (int u = 0; u < RS_SMALL_KEYS; ++u) {
-      const int i = tid + u * RS1_T;
-      key[u] = key_of(z[u]);
-      if (i < n) {
-        const unsigned bin = key[u] >> 21;
-        if (bin != run_bin) {
-          if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
-          run_bin = bin;
-          run_cnt = 0;
-        }
-        ++run_cnt;
-        sum += (double)z[u];
-        cnt += (z[u] <= thr) ? 1.0 : 0.0;
-        mx = fmaxf(mx, z[u]);
-      }
-    }
-    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
-  }
-  __syncthreads();
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 1] = (double)wall_clock64();
-#endif
-  unsigned b1, k1, b2, k2, b3, k3;
-  find_bin<B1, RS1_T>(h, k, b1, k1);
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 2] = (double)wall_clock64();
-#endif
-  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
-    const int i = tid + u * RS1_T;
-    if (i < n && (key[u] >> 21) == b1) atomicAdd(&h[(key[u] >> 10) & (B2 - 1)], 1u);
-  }
-  __syncthreads();
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 3] = (double)wall_clock64();
-#endif
-  find_bin<B2, RS1_T>(h, k1, b2, k2);
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 4] = (double)wall_clock64();
-#endif
-  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  const unsigned prefix = (b1 << 11) | b2;
-#pragma unroll
-  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
-    const int i = tid + u * RS1_T;
-    if (i < n && (key[u] >> 10) == prefix) atomicAdd(&h[key[u] & (B3 - 1)], 1u);
-  }
-  __syncthreads();
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 5] = (double)wall_clock64();
-#endif
-  find_bin<B3, RS1_T>(h, k2, b3, k3);
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 6] = (double)wall_clock64();
-#endif
-  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
-  const float t = value_of(tkey);
-  double tail = 0.0, ngt = 0.0, neq = 0.0;
-#pragma unroll
-  for (int u = 0; u < RS_SMALL_KEYS; ++u) {
-    const int i = tid + u * RS1_T;
-    if (i < n) {
-      tail += (key[u] > tkey) ? ((double)z[u] - (double)t) : 0.0;
-      ngt += (key[u] > tkey) ? 1.0 : 0.0;
-      neq += (key[u] == tkey) ? 1.0 : 0.0;
-    }
-  }
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 7] = (double)wall_clock64();
-#endif
-  // one barrier for all six block reductions; fixed order: DPP tree inside a wave, then the 16 wave totals through
-  // one DPP row of wave 0 (a serial fold by one thread + shuffle trees cost 3.8 us of the 12-14 us of this kernel)
-  sum = rato::wave_sum_dpp(sum);
-  cnt = rato::wave_sum_dpp(cnt);
-  tail = rato::wave_sum_dpp(tail);
-  ngt = rato::wave_sum_dpp(ngt);
-  neq = rato::wave_sum_dpp(neq);
-  mx = rato::wave_max_dpp(mx);
-  if ((tid & 63) == 0) {
-    const int w = tid >> 6;
-    red[0][w] = sum; red[1][w] = cnt; red[2][w] = tail; red[3][w] = ngt; red[4][w] = neq;
-    redmax[w] = mx;
-  }
-  __syncthreads();
-  if (tid < RATO_WAVE) {
-    static_assert(RS1_T / RATO_WAVE == 16, "one DPP row folds the wave totals");
-    const bool in = tid < RS1_T / RATO_WAVE;
-    const double S = rato::row16_sum_dpp(in ? red[0][tid] : 0.0), C = rato::row16_sum_dpp(in ? red[1][tid] : 0.0);
-    const double T = rato::row16_sum_dpp(in ? red[2][tid] : 0.0), NG = rato::row16_sum_dpp(in ? red[3][tid] : 0.0);
-    const double NE = rato::row16_sum_dpp(in ? red[4][tid] : 0.0);
-    const double m = (double)rato::row16_max_dpp(in ? redmax[tid] : -INFINITY);
-    if (tid == 15) {
-      out[0] = var_is_max ? m : (double)t;
-      out[1] = (double)t + (T / (double)M) / alpha;
-      out[2] = C / (double)M;                   // true divisions: the fraction is compared bit for bit with np.mean
-      out[3] = S / (double)M;
-      out[4] = m;
-      out[5] = C;
-      out[6] = T;
-      out[7] = (double)k;
-      out[8] = NG;
-      out[9] = NE;
-      out[10] = (double)t;
-#ifdef RATO_RS_DIAG
-      out[16 + 8] = (double)wall_clock64();
-#endif
-    }
-  }
+  rs_small_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, out, sig, h, red, redmax);   // rato_select.h
 }
 
 // ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
@@ -528,79 +280,7 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
 // fixed order and leaves the workspace clean.  All G workgroups must be resident at once for the waits to complete:
 // G <= 64 against 256 CUs x 2 workgroups of this size, launched on an in-order stream behind the producer of Z.
 // Same arithmetic as the other two forms: exact selection, fixed-order fp64 sums (deterministic run to run).
-constexpr int RS_COOP_KEYS = 16;                                  // keys per thread (registers)
-constexpr int RS_COOP_MAX_WG = 64;
 constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 1,048,576
-
-// find_bin on a histogram that OTHER workgroups of this launch are still adding to: device-scope loads, repeated until
-// the counters add up to `expected` (the number of keys this pass distributes: M, then the count of the chosen bin).
-// Every counter only grows during a pass, so total == expected means every add has landed -- the histogram itself is
-// the barrier, with no arrival counter and no fence (one memory round trip per try instead of three per barrier).
-// Two ways out without a result, both loud (NaN statistics, workspace un-tagged), neither a hang:
-//   * the counters EXCEED `expected`: they only grow, so the workspace was not clean when the launch started -- at once;
-//   * the counters stay short for RS_COOP_WAIT_S seconds of the constant 100 MHz clock.  A launch whose workgroups are
-//     not all resident yet (another stream holds the CUs) is NOT a failure: its waiting workgroups keep polling until
-//     the rest has been scheduled and has added its keys, however long the other stream's kernel takes (the first
-//     version gave up after 2^18 polls ~ 0.5 s and poisoned the statistics of a merely delayed launch).
-template <int NB, int NT>
-__device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, unsigned expected, unsigned& bin,
-                              unsigned& krem, unsigned& bincount) {
-  constexpr int PER = NB / NT;
-  static_assert(PER >= 1 && PER * NT == NB, "bins must divide evenly over the threads");
-  __shared__ unsigned wsum[NT / RATO_WAVE];
-  __shared__ unsigned res[3];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long t_start = wall_clock64();
-  for (unsigned tries = 0;; ++tries) {
-    unsigned local[PER], tot = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      local[i] = __hip_atomic_load(const_cast<unsigned*>(hist) + tid * PER + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tot += local[i];
-    }
-    const unsigned incl = rato::wave_scan_dpp(tot);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned base = 0, grand = 0;
-    for (int w = 0; w < NT / RATO_WAVE; ++w) {
-      const unsigned v = wsum[w];
-      if (w < wave) base += v;
-      grand += v;
-    }
-    if (grand == expected) {        // uniform over the workgroup (every thread summed the same LDS words)
-      const unsigned excl = base + incl - tot;
-      if (k >= excl && k < excl + tot) {
-        unsigned run = excl;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          if (k >= run && k < run + local[i]) {
-            res[0] = tid * PER + i;
-            res[1] = k - run;
-            res[2] = local[i];
-          }
-          run += local[i];
-        }
-      }
-      __syncthreads();
-      bin = res[0];
-      krem = res[1];
-      bincount = res[2];
-      __syncthreads();
-      return true;
-    }
-    // uniform over the workgroup: every thread summed the same LDS words / thread 0's clock is published through LDS
-    if (grand > expected) return false;                                   // unclean workspace
-    if ((tries & 1023u) == 1023u) {
-      if (tid == 0) res[0] = (wall_clock64() - t_start > RS_COOP_WAIT_TICKS) ? 1u : 0u;
-      __syncthreads();
-      const unsigned expired = res[0];
-      __syncthreads();
-      if (expired) return false;
-    }
-    __syncthreads();                // wsum is rewritten by the next try
-    if (tries < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
-  }
-}
 
 __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                  int var_is_max, float thr, int G, Workspace* __restrict__ ws,
@@ -610,155 +290,9 @@ __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, lo
     sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
     return;
   }
-  const int tid = threadIdx.x;
-  if (ws->magic != RS_MAGIC) {  // never initialised: the barrier counter is garbage -> do not wait on it, fail loudly
-    if (blockIdx.x == 0 && tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
-    return;
-  }
-  // companion launch: Z is being produced beside this kernel (the flag is lowered by the workgroup that finishes last;
-  // a wait that expires leaves the histogram protocol short of keys, which ends in NaN statistics below)
-  const bool z_ok = companion ? wait_signal(ws->sig + SIG_Z_READY) : true;
   __shared__ unsigned h[B1];
-  __shared__ double red[6][RS1_T / RATO_WAVE];
-  __shared__ unsigned last_flag;
-  const int n = (int)M;
-  unsigned key[RS_COOP_KEYS];
-  double sum = 0.0, cnt = 0.0;
-  float mx = -INFINITY;
-  {
-    float z[RS_COOP_KEYS];
-#pragma unroll
-    for (int u = 0; u < RS_COOP_KEYS; ++u) {                  // element (u, workgroup, thread): coalesced, all in flight
-      const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
-      z[u] = (i < n) ? Z[i] : 0.0f;
-    }
-    for (int i = tid; i < B1; i += RS1_T) h[i] = 0;           // while the loads are in flight
-    __syncthreads();
-    unsigned run_bin = 0xffffffffu, run_cnt = 0;             // runs of equal bins -> one LDS atomic (values cluster)
-#pragma unroll
-    for (int u = 0; u < RS_COOP_KEYS; ++u) {
-      const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
-      key[u] = key_of(z[u]);
-      if (i < n) {
-        const unsigned bin = key[u] >> 21;
-        if (bin != run_bin) {
-          if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
-          run_bin = bin;
-          run_cnt = 0;
-        }
-        ++run_cnt;
-        sum += (double)z[u];
-        cnt += (z[u] <= thr) ? 1.0 : 0.0;
-        mx = fmaxf(mx, z[u]);
-      }
-    }
-    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
-  }
-  flush_hist<B1, RS1_T>(h, ws->hist1);
-  unsigned b1 = 0, k1 = 0, c1 = 0, b2 = 0, k2 = 0, c2 = 0, b3 = 0, k3 = 0, c3 = 0;   // (a failed pass leaves them unset)
-  bool ok = z_ok && find_bin_coop<B1, RS1_T>(ws->hist1, k, (unsigned)n, b1, k1, c1);
-  for (int i = tid; i < B2; i += RS1_T) h[i] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < RS_COOP_KEYS; ++u) {
-    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
-    if (i < n && (key[u] >> 21) == b1) atomicAdd(&h[(key[u] >> 10) & (B2 - 1)], 1u);
-  }
-  flush_hist<B2, RS1_T>(h, ws->hist2);
-  ok = ok && find_bin_coop<B2, RS1_T>(ws->hist2, k1, c1, b2, k2, c2);
-  for (int i = tid; i < B3; i += RS1_T) h[i] = 0;
-  __syncthreads();
-  const unsigned prefix = (b1 << 11) | b2;
-#pragma unroll
-  for (int u = 0; u < RS_COOP_KEYS; ++u) {
-    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
-    if (i < n && (key[u] >> 10) == prefix) atomicAdd(&h[key[u] & (B3 - 1)], 1u);
-  }
-  flush_hist<B3, RS1_T>(h, ws->hist3);
-  ok = ok && find_bin_coop<B3, RS1_T>(ws->hist3, k2, c2, b3, k3, c3);
-  if (!ok) {   // the histograms never added up: the workspace was not clean.  NaN out, un-tag the workspace.
-    if (tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
-    if (tid == 0) {
-      ws->magic = 0;
-      if (companion) __hip_atomic_store(ws->sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
-  const float t = value_of(tkey);
-  double tail = 0.0, ngt = 0.0, neq = 0.0;
-#pragma unroll
-  for (int u = 0; u < RS_COOP_KEYS; ++u) {
-    const int i = (u * G + (int)blockIdx.x) * RS1_T + tid;
-    if (i < n) {
-      const float z = value_of(key[u]);
-      tail += (key[u] > tkey) ? ((double)z - (double)t) : 0.0;
-      ngt += (key[u] > tkey) ? 1.0 : 0.0;
-      neq += (key[u] == tkey) ? 1.0 : 0.0;
-    }
-  }
-  sum = rato::wave_sum_dpp(sum);
-  cnt = rato::wave_sum_dpp(cnt);
-  tail = rato::wave_sum_dpp(tail);
-  ngt = rato::wave_sum_dpp(ngt);
-  neq = rato::wave_sum_dpp(neq);
-  mx = rato::wave_max_dpp(mx);
-  if ((tid & 63) == 0) {
-    const int w = tid >> 6;
-    red[0][w] = sum; red[1][w] = cnt; red[2][w] = (double)mx; red[3][w] = tail; red[4][w] = ngt; red[5][w] = neq;
-  }
-  __syncthreads();
-  if (tid < RATO_WAVE) {   // the 16 wave totals through one DPP row (fixed order), result in lane 15
-    const bool in = tid < RS1_T / RATO_WAVE;
-    const double S = rato::row16_sum_dpp(in ? red[0][tid] : 0.0), C = rato::row16_sum_dpp(in ? red[1][tid] : 0.0);
-    const double T = rato::row16_sum_dpp(in ? red[3][tid] : 0.0), NG = rato::row16_sum_dpp(in ? red[4][tid] : 0.0);
-    const double NE = rato::row16_sum_dpp(in ? red[5][tid] : 0.0);
-    const double m = (double)rato::row16_max_dpp(in ? (float)red[2][tid] : -INFINITY);
-    if (tid == 15) {
-      double* bp = ws->blockpart[blockIdx.x];
-      bp[0] = S; bp[1] = C; bp[2] = m; bp[3] = T; bp[4] = NG; bp[5] = NE;
-      // release the partials, take a completion ticket; the last workgroup acquires everyone's partials
-      const unsigned tk = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = (tk == (unsigned)G - 1u);
-    }
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  // every workgroup has read hist3 before taking its ticket: zero the histograms and the counters for the next call
-  for (int i = tid; i < B1 + B2 + B3; i += RS1_T) ws->hist1[i] = 0;   // hist1..3 are contiguous
-  if (tid == 0) {
-    ws->ticket = 0;
-    if (companion) __hip_atomic_store(ws->sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid >= RATO_WAVE) return;
-  double s = 0, c = 0, m = -INFINITY, tl = 0, g = 0, e = 0;
-  if (tid < G) {   // G <= 64: one partial per lane, folded by the fixed shuffle tree (independent of who came last)
-    const double* bp = ws->blockpart[tid];
-    s = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    c = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    m = __hip_atomic_load(bp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tl = __hip_atomic_load(bp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    g = __hip_atomic_load(bp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    e = __hip_atomic_load(bp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  s = rato::wave_sum_dpp(s);
-  c = rato::wave_sum_dpp(c);
-  tl = rato::wave_sum_dpp(tl);
-  g = rato::wave_sum_dpp(g);
-  e = rato::wave_sum_dpp(e);
-  m = (double)rato::wave_max_dpp((float)m);      // maxima of fp32 values: exact in float
-  if (tid != 0) return;
-  out[0] = var_is_max ? m : (double)t;
-  out[1] = (double)t + (tl / (double)M) / alpha;
-  out[2] = c / (double)M;
-  out[3] = s / (double)M;
-  out[4] = m;
-  out[5] = c;
-  out[6] = tl;
-  out[7] = (double)k;
-  out[8] = g;
-  out[9] = e;
-  out[10] = (double)t;
+  __shared__ double red[6 * (RS1_T / RATO_WAVE)];
+  rs_coop_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, G, ws, out, (int)blockIdx.x, companion, h, red);   // rato_select.h
 }
 
 // one workgroup: zero the whole workspace, then tag it
@@ -878,7 +412,6 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     return RATO_EINVAL;
   if (workspace_bytes < sizeof(Workspace)) return RATO_EINVAL;
   if (part && (!sums_out || nblocks <= 0 || ncols <= 0)) return RATO_EINVAL;
-  if (part && companion) return RATO_EINVAL;   // the partial sums are complete at the END of the producer: not beside it
   // ascending 0-based rank of sort(Z)[M - floor(alpha*M) - 1]  (drone_main_plot.py:649-651)
   long xth = (long)floor(alpha * (double)M);
   long kk = M - xth - 1;
@@ -912,7 +445,6 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
-  if (companion) return RATO_EINVAL;   // the launch-per-pass form waits for nothing: M <= 1,048,576 only
   if (part) {
     hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sp_blocks), dim3(SP_COLS * SP_ROWS), 0, st, part, (int)nblocks,
                        (int)ncols, scale, sums_out);
@@ -968,15 +500,4 @@ extern "C" int rato_sums_and_risk_stats(const float* part, int32_t nblocks, int3
   if (!part) return RATO_EINVAL;
   return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, part, nblocks, ncols, scale, sums_out,
                          stream);
-}
-
-// ---- companion launches (round 4) -----------------------------------------------------------------------------------
-extern "C" uint32_t* rato_risk_stats_signal(void* workspace) {
-  return workspace ? static_cast<Workspace*>(workspace)->sig : nullptr;
-}
-
-extern "C" int rato_risk_stats_companion(const float* Z, int64_t M, double alpha, float thr, void* workspace,
-                                         size_t workspace_bytes, double* out, void* stream) {
-  if (M > RS_COOP_MAX) return RATO_EINVAL;
-  return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream, false, true);
 }

@@ -218,7 +218,7 @@ class Model:
         return -g.t().double().cpu().numpy()
 
     # ---- linearization (K4) ------------------------------------------------
-    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True, rows_out=0, signal=None):
+    def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True, rows_out=0, stats_request=None):
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
@@ -249,8 +249,8 @@ class Model:
         final_rhs = reuse("final_rhs", (4,))
         p = self._params(M)
         p.rows_out = int(rows_out)      # 1: g_up receives g itself (base of the cut oracle's delta form, cvar_cuts.py)
-        if signal:                      # companion statistics on another stream (stats.Companion): row-parallel kernel only
-            p.signal = signal
+        if stats_request is not None:   # (workspace, out, alpha): the launch also computes the statistics of its Z
+            stats.request_in_launch(p, *stats_request)
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
             _lib.check(self._lib.rato_car_linearize_philox(
                 C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
@@ -266,23 +266,23 @@ class Model:
         return {"G": G, "g_up": g_up, "Z": Z, "final_du": final_du, "final_rhs": final_rhs, "M": M,
                 "cols_per_thread": cols_per_thread, "tile": tile, "rows_out": int(rows_out)}
 
-    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, companion=None, **kw):
+    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, fused=True, **kw):
         """One single-GPU SAA step: the linearize kernel and the exact fraction satisfied / VaR / CVaR of its Z
-        (driving.py:630-671).  -> (linearize result dict, stats double[N_STATS]).  ``companion`` (a ``stats.Companion``; with
-        ``workspace``, row-parallel kernel, M <= 1,048,576): the statistics run BESIDE the kernel on the companion's
-        stream and start when the last tile's Z has landed (the final rows of the driving problem are sample independent:
-        there is no reduction left behind the kernel at all)."""
+        (driving.py:630-671).  -> (linearize result dict, stats double[N_STATS]).  ``fused`` (default; row-parallel kernel,
+        M <= stats.FUSED_MAX_M): ONE launch -- the statistics are computed by extra workgroups of the linearize launch as
+        soon as the last tile's Z has landed (the final rows of the driving problem are sample independent: nothing else
+        follows the kernel).  Otherwise the kernel and rato_risk_stats behind it."""
         alpha = self.alpha if alpha is None else alpha
         M = int(self._ws.numel())
         cpt, tile = C.c_int32(int(kw.get("cols_per_thread", 0))), C.c_int32(0)
         self._lib.rato_car_linearize_plan(M, self.S, C.byref(cpt), C.byref(tile))
-        if companion is not None and workspace is not None and M <= stats.COMPANION_MAX_M and cpt.value == -1:
-            companion.fork()
-            r = self.linearize_device(us_mat, out=out, signal=stats.signal_ptr(workspace), **kw)
-            with torch.cuda.stream(companion.stream):
-                st = stats.risk_stats_companion_device(r["Z"], alpha, workspace=workspace, out=stats_out)
-            companion.join()
-            return r, st
+        if fused and M <= stats.FUSED_MAX_M and cpt.value == -1:
+            if workspace is None:
+                workspace = stats.new_workspace(M, self.device)
+            if stats_out is None:
+                stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
+            r = self.linearize_device(us_mat, out=out, stats_request=(workspace, stats_out, alpha), **kw)
+            return r, stats_out
         r = self.linearize_device(us_mat, out=out, **kw)
         return r, stats.risk_stats_device(r["Z"], alpha, workspace=workspace, out=stats_out)
 

@@ -236,7 +236,7 @@ class Model:
         return nblk, cpt.value, spl.value, tile.value
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
-                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0, signal=None):
+                         want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0, stats_request=None):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
 
         -> dict of device tensors:
@@ -256,8 +256,8 @@ class Model:
         reduction into the single launch of the risk statistics.
         ``rows_out=1``: the ``g_up`` buffer receives the constraint values g at ``us_mat`` instead of
         g_up = -g + (grad g).u (the base of the cut oracle's delta form, cvar_cuts.py).
-        ``signal`` (``stats.signal_ptr(workspace)``; row-parallel kernel only): the kernel tells a companion statistics
-        launch on another stream when Z / everything has landed (``step_device(companion=...)``).
+        ``stats_request`` = (workspace, out, alpha) (row-parallel kernel only, M <= stats.FUSED_MAX_M): the launch also
+        leaves the ``rato_risk_stats`` record of its Z in ``out`` (extra workgroups of the same launch, ``step_device``).
         """
         dW, mass, Qsym, M = self._inputs(inputs)
         ld, S = mass.numel(), self.S
@@ -300,8 +300,8 @@ class Model:
         if o.get("sums") is not None and (o["sums"].numel() != 6 * S + 6 or o["sums"].dtype != torch.float64):
             o = dict(o, sums=None)
         p = self._params(M, ld, rows_out)
-        if signal:
-            p.signal = signal
+        if stats_request is not None:
+            stats.request_in_launch(p, *stats_request)
         if events is not None:
             events[0].record()
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
@@ -442,38 +442,36 @@ class Model:
         g_up = r["g_up"].permute(2, 0, 1).double().cpu().numpy()
         return g_obs_du, g_up
 
-    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, companion=None, **kw):
-        """One single-GPU SAA step in TWO launches: the linearize kernel, then ONE launch that reduces the sample
-        sums (drone_risk.py:294-296) and computes fraction satisfied / VaR / CVaR of Z (:661, :663-695,
-        drone_main_plot.py:640-652) -- rato_sums_and_risk_stats.  -> (linearize result dict, stats double[N_STATS]).
-        ``companion`` (a ``stats.Companion``; row-parallel kernel, M <= 1,048,576, ``workspace`` given): the second launch
-        statistics run BESIDE the kernel on the companion's stream -- the selection starts when the last tile's Z has
-        landed, long before the Jacobian has been stored -- and only the tiny reduction of the sample sums (complete when
-        the kernel ends) is left behind it."""
+    def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, fused=True, **kw):
+        """One single-GPU SAA step: linearize, the sample sums (drone_risk.py:294-296) and fraction satisfied / VaR / CVaR of
+        Z (:661, :663-695, drone_main_plot.py:640-652).  -> (linearize result dict, stats double[N_STATS]).
+        ``fused`` (default; row-parallel kernel, M <= stats.FUSED_MAX_M): the statistics are computed by extra workgroups
+        of the linearize launch itself as soon as the last tile's Z has landed -- long before the Jacobian has been stored
+        -- and only the tiny reduction of the sample sums (complete when the kernel ends) follows it.  Otherwise: the
+        kernel, then ONE launch for sums + statistics (rato_sums_and_risk_stats)."""
         alpha = self.alpha if alpha is None else alpha
-        M = self._inputs(kw.get("inputs"))[3]
-        if companion is not None and workspace is not None and M <= stats.COMPANION_MAX_M and \
-                self.linearize_plan(M, self._inputs(kw.get("inputs"))[1].numel(), kw.get("cols_per_thread", 0),
-                                    kw.get("samples_per_lane", 0))[1] == -1:
-            companion.fork()
-            r = self.linearize_device(us_mat, out=out, events=events, reduce=False, signal=stats.signal_ptr(workspace), **kw)
-            with torch.cuda.stream(companion.stream):
-                st = stats.risk_stats_companion_device(r["Z"], alpha, workspace=workspace, out=stats_out)
-            stats.sum_partials(r["part"], out=r["sums"])      # complete only when the kernel ends: stream-ordered behind it
-            companion.join()
-            return r, st
+        _, mass, _, M = self._inputs(kw.get("inputs"))
+        if fused and M <= stats.FUSED_MAX_M and \
+                self.linearize_plan(M, mass.numel(), kw.get("cols_per_thread", 0), kw.get("samples_per_lane", 0))[1] == -1:
+            if workspace is None:
+                workspace = stats.new_workspace(M, self.device)
+            if stats_out is None:
+                stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
+            r = self.linearize_device(us_mat, out=out, events=events, reduce=True,
+                                      stats_request=(workspace, stats_out, alpha), **kw)
+            return r, stats_out
         r = self.linearize_device(us_mat, out=out, events=events, reduce=False, **kw)
         _, st = stats.sums_and_risk_stats_device(r["part"], r["Z"], alpha, workspace=workspace, sums_out=r["sums"],
                                                  out=stats_out)
         return r, st
 
     # ---- hipGraph: one SCP-iteration's device work as a single replayable graph -------------
-    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None, companion=False):
+    def capture_step(self, alpha=None, cols_per_thread=0, samples_per_lane=0, factored=None, fused=True):
         """Capture linearize -> sample means -> VaR/CVaR into ONE hipGraph (torch.cuda.CUDAGraph is
         only the capture/replay plumbing; the nodes are this library's kernels).  Returns a
         ``StepGraph``: write the controls into ``.us`` (device tensor, (S, n_u)), call ``.replay()``
         and read ``.out`` (same dict as linearize_device) and ``.stats`` (double[10], rato_saa.h).
-        ``companion``: the statistics as a second BRANCH of the graph, beside the linearize node (``step_device``)."""
+        ``fused``: see ``step_device``."""
         alpha = self.alpha if alpha is None else alpha
         us = torch.zeros((self.S, n_u), dtype=torch.float32, device=self.device)
         out = self.linearize_device(us, cols_per_thread=cols_per_thread, samples_per_lane=samples_per_lane,
@@ -482,14 +480,13 @@ class Model:
         st = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
         kw = dict(cols_per_thread=out["cols_per_thread"], samples_per_lane=out["samples_per_lane"],
                   factored=out["factored"])
-        comp = stats.Companion(self.device) if companion else None
-        self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, companion=comp, **kw)   # warm-up: uncaptured first call
+        self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, fused=fused, **kw)   # warm-up: uncaptured first call
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            res, _ = self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, companion=comp, **kw)
+            res, _ = self.step_device(us, alpha, out=out, workspace=ws, stats_out=st, fused=fused, **kw)
         sg = StepGraph(graph, us, res, st)
-        sg.workspace, sg.companion = ws, comp
+        sg.workspace = ws
         return sg
 
     # ---- L3: sparse QP assembly (drone_risk.py:221-237, 282-423) -----------

@@ -72,44 +72,21 @@ def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=Non
     return out
 
 
-# ---- companion statistics: the selection beside the kernel that produces Z (rato_saa.h, "COMPANION statistics") ----------
-COMPANION_MAX_M = 1048576          # the one-launch forms of the selection
+# ---- statistics in the producer's own launch (rato_saa.h: params.stats_*) -------------------------------------------
+FUSED_MAX_M = 524288               # 64 statistics workgroups x 512 threads x 16 keys
 
 
-def signal_ptr(workspace):
-    """device address of ``workspace``'s signal words: ``linearize_device(..., signal=...)`` makes the row-parallel kernel
-    raise them, ``*_companion_device`` (same workspace) waits for them"""
-    return _lib.load().rato_risk_stats_signal(_lib.ptr(workspace))
-
-
-class Companion:
-    """Stream plumbing of a companion launch: ``fork()`` orders the side stream behind what the current stream has been
-    given so far (call it BEFORE enqueuing the producer), the statistics go onto ``.stream``, ``join()`` makes the current
-    stream wait for them.  Also valid inside a hipGraph capture (fork / join of two captured streams)."""
-
-    def __init__(self, device=None):
-        self.stream = torch.cuda.Stream(device=device)
-
-    def fork(self):
-        self.stream.wait_stream(torch.cuda.current_stream())
-
-    def join(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
-
-
-def risk_stats_companion_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):
-    """``risk_stats_device`` for a Z that is being produced beside this launch (rato_risk_stats_companion)."""
-    lib = _lib.load()
-    Z = _as_device_f32(Z)
-    if workspace is None:
-        raise _lib.RatoError("a companion launch needs the workspace whose signal words the producer was given")
-    if out is None:
-        out = torch.empty(N_STATS, dtype=torch.float64, device=Z.device)
-    _lib.check(lib.rato_risk_stats_companion(_lib.ptr(Z), Z.numel(), float(alpha), float(thr), _lib.ptr(workspace),
-                                             workspace.numel(), _lib.ptr(out),
-                                             _lib.current_stream() if stream is None else stream),
-               "rato_risk_stats_companion")
-    return out
+def request_in_launch(params, workspace, out, alpha, thr=SATISFIED_THRESHOLD):
+    """Fill the ``stats_*`` fields of a ``rato_drone_params`` / ``rato_car_params``: the row-parallel linearize launch
+    given these params then also leaves the ``rato_risk_stats`` record of the Z it produces in ``out`` (device
+    double[N_STATS]) -- computed by extra workgroups at the end of its grid as soon as the last tile's Z has landed,
+    while the Jacobian is still being stored."""
+    if workspace is None or out is None:
+        raise _lib.RatoError("statistics in the launch need an initialised workspace and a device record")
+    params.stats_workspace = workspace.data_ptr()
+    params.stats_out = out.data_ptr()
+    params.stats_alpha = float(alpha)
+    params.stats_thr = float(thr)
 
 
 def risk_stats_recover_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):

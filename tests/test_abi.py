@@ -61,8 +61,8 @@ def test_abi_version_and_size_queries(lib):
 def test_params_struct_layout_matches_header():
     from riskaversetrajopt_amd import _lib
     # 2 int32 + 6 float + 6 + 6 + 6 floats
-    assert ctypes.sizeof(_lib.DroneParams) == 4 * (3 + 6 + 18 + 1) + 8 * (6 + 6 + 6 + 6) + 8   # + the fp64 constants + signal
-    assert ctypes.sizeof(_lib.CarParams) == 4 * (2 + 5 + 8 + 1) + 8 * (4 + 4) + 8   # + the fp64 constants + signal
+    assert ctypes.sizeof(_lib.DroneParams) == 4 * (3 + 6 + 18 + 1) + 8 * (6 + 6 + 6 + 6) + 32   # + the fp64 constants + stats_*
+    assert ctypes.sizeof(_lib.CarParams) == 4 * (2 + 5 + 8 + 1) + 8 * (4 + 4) + 32   # + the fp64 constants + stats_*
 
 
 def test_cut_loop_struct_layouts_match_the_library(lib):

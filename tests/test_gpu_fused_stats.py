@@ -1,0 +1,119 @@
+"""GPU: statistics in the producer's own launch (rato_saa.h: params.stats_*).  A row-parallel linearize launch carries a
+few extra workgroups that wait until every tile's Z has been counted in and then run the exact selection on it -- while
+the Jacobian is still being stored.  Against the same kernel followed by rato_risk_stats: every output of the kernel and
+every exactly defined entry of the record (VaR, counts, max, rank, threshold) bit for bit, the fp64 sums to summation
+order; eager and replayed from a hipGraph; the signal words back at zero after every launch."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EXACT = [0, 2, 4, 5, 7, 8, 9, 10]          # var, frac_satisfied, max, count_satisfied, rank, count_above, count_at, t_star
+SUMS = [1, 3, 6]                           # cvar, mean, tail_sum (fp64 sums: equal to summation order)
+
+
+def _signal_words(ws):
+    import torch
+    # the signal words are the last 8 words of the workspace struct (csrc/rato_select.h: Workspace::sig)
+    return ws[-32:].view(torch.int32).cpu().numpy()
+
+
+def _us(S, n_u, k):
+    t = np.arange(S)[:, None]
+    base = np.hstack([0.6 * np.cos(0.3 * t + 0.1 * k) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    return base[:, :n_u] * (1.0 - 0.03 * k)
+
+
+def _model(system, M, S):
+    from riskaversetrajopt_amd import drone_risk, drone_utils, driving
+    if system == "drone":
+        dW, mass, Q = drone_utils.sample_uncertain_parameters_device(M, S, seed=3)
+        return drone_risk.Model.from_device(S, dW, mass, Q, 'saa', 0.1, M=M), 3
+    dW, x0, ws_, wr = driving.sample_uncertain_parameters_device(M, S, seed=3)
+    return driving.Model.from_device(S, dW, x0, ws_, wr, 'saa', 0.05), 2
+
+
+@pytest.mark.parametrize("system,M,S", [("drone", 300, 20), ("drone", 3000, 20), ("drone", 10000, 50), ("drone", 12289, 20),
+                                        ("drone", 40000, 20), ("drone", 100003, 20), ("drone", 100000, 50),
+                                        ("driving", 3000, 20), ("driving", 10000, 40), ("driving", 125001, 40),
+                                        ("driving", 500000, 10)])
+def test_statistics_in_the_launch_equal_the_separate_launch(system, M, S):
+    import torch
+    from riskaversetrajopt_amd import stats
+    d, n_u = _model(system, M, S)
+    ws_a, ws_b = stats.new_workspace(M, d.device), stats.new_workspace(M, d.device)
+    ra = rb = None
+    for k in range(5):
+        us = _us(S, n_u, k)
+        ra, sa = d.step_device(us, out=ra, workspace=ws_a, fused=False)
+        rb, sb = d.step_device(us, out=rb, workspace=ws_b, fused=True)
+        torch.cuda.synchronize()
+        a, b = sa.cpu().numpy(), sb.cpu().numpy()
+        assert np.array_equal(a[EXACT], b[EXACT]), (k, a, b)
+        np.testing.assert_allclose(b[SUMS], a[SUMS], rtol=1e-12, atol=1e-300)
+        assert torch.equal(ra["Z"], rb["Z"]) and torch.equal(ra["g_up"], rb["g_up"])
+        if system == "drone":
+            assert torch.equal(ra["sums"], rb["sums"])
+            assert torch.equal(d.packed_jacobian(ra), d.packed_jacobian(rb)) if M <= 12289 else True
+        assert not _signal_words(ws_b).any()                      # counter and flag lowered again
+    Zh = np.sort(rb["Z"].double().cpu().numpy())
+    assert b[0] == Zh[M - int(np.floor(d.alpha * M)) - 1] and b[4] == Zh[-1]
+
+
+@pytest.mark.parametrize("system,M,S", [("drone", 10000, 50), ("driving", 10000, 40), ("drone", 60000, 20)])
+def test_statistics_in_the_launch_replayed_from_a_hipgraph(system, M, S):
+    import torch
+    from riskaversetrajopt_amd import stats
+    d, n_u = _model(system, M, S)
+    graphs = {}
+    for fused in (False, True):
+        us = torch.zeros((S, n_u), dtype=torch.float32, device=d.device)
+        ws = stats.new_workspace(M, d.device)
+        st = torch.empty(stats.N_STATS, dtype=torch.float64, device=d.device)
+        r, _ = d.step_device(us, workspace=ws, stats_out=st, fused=fused)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            d.step_device(us, out=r, workspace=ws, stats_out=st, fused=fused)
+        graphs[fused] = (g, us, st, ws)
+    for k in range(6):
+        u = torch.as_tensor(_us(S, n_u, k), dtype=torch.float32, device=d.device)
+        for fused in (False, True):
+            g, us, st, ws = graphs[fused]
+            us.copy_(u)
+            g.replay()
+        torch.cuda.synchronize()
+        a, b = graphs[False][2].cpu().numpy(), graphs[True][2].cpu().numpy()
+        assert np.array_equal(a[EXACT], b[EXACT]), (k, a, b)
+        np.testing.assert_allclose(b[SUMS], a[SUMS], rtol=1e-12, atol=1e-300)
+        assert not _signal_words(graphs[True][3]).any()
+    for fused in (False, True):
+        g = graphs[fused][0]
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            g.replay()
+        torch.cuda.synchronize()
+        print(f"{system} M={M} S={S} {'statistics in the launch' if fused else 'kernel + statistics launch'}: "
+              f"{(time.perf_counter() - t0) / 200 * 1e6:.1f} us per replayed step")
+
+
+def test_refused_where_it_cannot_work():
+    import torch
+    from riskaversetrajopt_amd import _lib, stats
+    d, _ = _model("drone", 2000, 20)
+    ws = stats.new_workspace(2000, d.device)
+    out = torch.empty(stats.N_STATS, dtype=torch.float64, device=d.device)
+    with pytest.raises(_lib.RatoError):                              # the column kernel carries no statistics workgroups
+        d.linearize_device(_us(20, 3, 0), cols_per_thread=8, samples_per_lane=1, factored=False,
+                           stats_request=(ws, out, 0.1))
+    with pytest.raises(_lib.RatoError):                              # Z must be requested
+        d.linearize_device(_us(20, 3, 0), want_Z=False, stats_request=(ws, out, 0.1))
+    big, _ = _model("driving", 600000, 4)                            # beyond 64 x 512 x 16 keys
+    with pytest.raises(_lib.RatoError):
+        big.linearize_device(_us(4, 2, 0), stats_request=(stats.new_workspace(600000, big.device), out, 0.05))
+    r, st = big.step_device(_us(4, 2, 0))                            # step_device falls back to the separate launch there
+    assert torch.isfinite(st).all()

@@ -1,5 +1,6 @@
-"""Step time (linearize + sample sums + exact VaR / CVaR) with the statistics behind the kernel (two launches in a row)
-and beside it (companion branch): eager and as a replayed hipGraph.   usage: python tools/companion_time.py"""
+"""Step time (linearize + sample sums + exact VaR / CVaR) with the statistics as a launch behind the kernel and as extra
+workgroups of the kernel's own launch (params.stats_*): eager and as a replayed hipGraph.
+usage: python tools/fused_stats_time.py"""
 import sys
 import time
 
@@ -33,18 +34,17 @@ for system, M, S, kw in (("drone", 100000, 50, dict(factored=False)), ("drone", 
         us = np.tile([0.1, 0.01], (S, 1))
     usd = d._us_device(us)
     ws = stats.new_workspace(M, d.device)
-    comp = stats.Companion(d.device)
     st = torch.empty(stats.N_STATS, dtype=torch.float64, device=d.device)
     r, _ = d.step_device(usd, workspace=ws, stats_out=st, **kw)
     n = 200 if M <= 20000 else 60
     res = {}
-    res["eager, in a row"] = timed(lambda: d.step_device(usd, out=r, workspace=ws, stats_out=st, **kw), n)
-    res["eager, companion"] = timed(lambda: d.step_device(usd, out=r, workspace=ws, stats_out=st, companion=comp, **kw), n)
-    for name, c in (("graph, in a row", None), ("graph, companion", comp)):
+    res["eager, separate launch"] = timed(lambda: d.step_device(usd, out=r, workspace=ws, stats_out=st, fused=False, **kw), n)
+    res["eager, in the launch"] = timed(lambda: d.step_device(usd, out=r, workspace=ws, stats_out=st, fused=True, **kw), n)
+    for name, c in (("graph, separate launch", False), ("graph, in the launch", True)):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            d.step_device(usd, out=r, workspace=ws, stats_out=st, companion=c, **kw)
+            d.step_device(usd, out=r, workspace=ws, stats_out=st, fused=c, **kw)
         res[name] = timed(g.replay, n)
     # the kernel alone
     res["linearize alone (eager)"] = timed(lambda: d.linearize_device(usd, out=r, **(dict(reduce=False, **kw) if system == "drone" else kw)), n)
