@@ -653,6 +653,37 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       xi = xi_n;
       e = e_n;
     }
+    // Z = max_t g_t - tol from the q table (driving.py:630-638), by the rollout wave itself as soon as the rollout is
+    // done -- BEFORE the rows are swept, so that the statistics workgroups of this launch (params.stats_*) can select on
+    // Z while the Jacobian is still being stored (until round 4: the LAST task of the row queue).  Row-split parts: the
+    // part that owned that task writes.
+    if (Z && (S % row_split) == part_id) {
+      float zmax = -INFINITY;
+      for (int t = 0; t < S; ++t) {
+        const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e = EGOP[t + 1];
+        const float dx = e.x - q.x, dy = e.y - q.y;
+        zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
+      }
+      if (!z_signal) {
+        if (valid) Z[m] = zmax - P.tol;
+      } else {
+        // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
+        // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
+        // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
+        // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
+        if (valid)
+          __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (c == (unsigned)n_tiles_total - 1u) {
+            __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
 #if RATO_CDIAG >= 4
     if (threadIdx.x == 0) {
       const unsigned long long now = wall_clock64();
@@ -676,37 +707,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
   };
   int task = next_task();
-  while (task <= S) {
-    if (task == S) {
-      wait_steps(S);
-      if (Z) {
-        float zmax = -INFINITY;
-        for (int t = 0; t < S; ++t) {
-          const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e = EGOP[t + 1];
-          const float dx = e.x - q.x, dy = e.y - q.y;
-          zmax = fmaxf(zmax, -(sqrtf(dx * dx + dy * dy) - P.d_min));
-        }
-        if (!z_signal) {
-          if (valid) Z[m] = zmax - P.tol;
-        } else {
-          // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
-          // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
-          // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
-          // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
-          if (valid)
-            __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) {
-            const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c == (unsigned)n_tiles_total - 1u) {
-              __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-        }
-      }
-    } else {
+  while (task < S) {
+    {
       const int t = task;
       wait_steps(t + 1);
       const cfloat2_t q = QP[t * CROWS_SAMPLES + lane], e1 = EGOP[t + 1];

@@ -839,6 +839,49 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   const size_t tile_floats = rato::packed_tile_stride((size_t)rato::pair_row_offset(S) * RPP * RT);
   float* __restrict__ Gt = G + (size_t)tile * tile_floats + lane;
 
+  auto wait_steps = [&](int need) {  // both horizontal axes rolled out through step need-1
+    while (true) {
+      const int p0 = prog[0], p1 = prog[1];
+      if ((p0 < p1 ? p0 : p1) >= need) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  // Z = max_{j,t} g - tol from the p_{t+1} table (drone_risk.py:656-662), computed by the z-axis wave as soon as both
+  // horizontal axes have been rolled out -- BEFORE the rows are swept, so that the statistics workgroups of this launch
+  // (params.stats_*) can select on Z while the Jacobian is still being stored.  (Until round 4 this was the LAST task of
+  // the row queue.)  Row-split parts: the part that owned that task writes.
+  auto write_Z = [&]() {
+    wait_steps(S);
+    float zmax = -INFINITY;
+    for (int t = 0; t < S; ++t) {
+      const float2_t pp = PP[t * ROWS_SAMPLES + lane];
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
+        zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
+      }
+    }
+    if (!z_signal) {
+      if (valid) Z[m] = zmax - P.tol;
+    } else {
+      // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
+      // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
+      // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
+      // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
+      if (valid)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == (unsigned)n_tiles_total - 1u) {
+          __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  };
   if (wave < 3) {
     const int a = wave;
     // all three axis waves run the same instruction stream: table offsets (in floats from the LDS base) and
@@ -879,6 +922,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 #if RATO_DIAG == 4
     tl2 = wall_clock64();
 #endif
+    if (a == 2 && Z && RATO_DIAG != 1 && (S % row_split) == part_id) write_Z();
     // d x_S / d u_s = A_{S-1} ... A_{s+1} B_s for this wave's axis: rows (P, V), summed over the block's
     // samples; the same sweep accumulates (d x_S / d u) . u for the rhs  (drone_risk.py:271)
     if (RATO_DIAG != 1 && (a % row_split) == part_id) {
@@ -921,49 +965,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     if (lane == 0) v = atomicAdd(head, 1);
     return part_id + row_split * __builtin_amdgcn_readfirstlane(v);
   };
-  auto wait_steps = [&](int need) {  // both horizontal axes rolled out through step need-1
-    while (true) {
-      const int p0 = prog[0], p1 = prog[1];
-      if ((p0 < p1 ? p0 : p1) >= need) break;
-      __builtin_amdgcn_s_sleep(4);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
   int task = (RATO_DIAG == 1) ? S + 1 : next_task();
-  while (task <= S) {
-    if (task == S) {
-      wait_steps(S);
-      if (Z) {
-        float zmax = -INFINITY;
-        for (int t = 0; t < S; ++t) {
-          const float2_t pp = PP[t * ROWS_SAMPLES + lane];
-#pragma unroll
-          for (int j = 0; j < NOBS; ++j) {
-            const float dx = pp.x - P.obs_xy[j][0], dy = pp.y - P.obs_xy[j][1];
-            zmax = fmaxf(zmax, 1.0f - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy));
-          }
-        }
-        if (!z_signal) {
-          if (valid) Z[m] = zmax - P.tol;
-        } else {
-          // Statistics in this launch: the workgroups behind the producer's are waiting for every tile's Z.  Z goes
-          // out as agent-scope atomic stores (written through to the point of coherence of the device -- a release FENCE
-          // here would write back this XCD's whole L2, in the middle of the Jacobian's store stream, once per tile), the
-          // wave waits for them to complete, then counts its tile in; the tile that completes the count raises z_ready.
-          if (valid)
-            __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) {
-            const unsigned c = __hip_atomic_fetch_add(z_signal + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c == (unsigned)n_tiles_total - 1u) {
-              __hip_atomic_store(z_signal + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(z_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-        }
-      }
-    } else {
+  while (task < S) {
+    {
       const int t = task;
       wait_steps(t + 1);
       const float2_t pp = PP[t * ROWS_SAMPLES + lane];

@@ -76,11 +76,11 @@ def test_statistics_in_the_launch_replayed_from_a_hipgraph(system, M, S):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             d.step_device(us, out=r, workspace=ws, stats_out=st, fused=fused)
-        graphs[fused] = (g, us, st, ws)
+        graphs[fused] = (g, us, st, ws, r)          # (r: the captured launches write into these buffers)
     for k in range(6):
         u = torch.as_tensor(_us(S, n_u, k), dtype=torch.float32, device=d.device)
         for fused in (False, True):
-            g, us, st, ws = graphs[fused]
+            g, us, st, ws, _ = graphs[fused]
             us.copy_(u)
             g.replay()
         torch.cuda.synchronize()
