@@ -143,12 +143,15 @@ typedef struct rato_drone_params {
   double x_init64[6];
   double x_final64[6];
   double obs_xy64[RATO_DRONE_NOBS][2];
-  /* Statistics in the SAME launch (round 4).  stats_workspace != NULL (an initialised rato_risk_stats workspace; row-parallel
-     kernel only: cols_per_thread = -1; Z requested; M <= 524,288): the linearize launch carries a few extra workgroups
-     that compute the rato_risk_stats record of the Z it produces -- double stats_out[RATO_N_STATS], tail level stats_alpha,
-     threshold stats_thr -- as soon as the last tile's Z has landed, while the Jacobian is still being stored: the
-     dependent statistics launch behind the kernel disappears.  Same selection, same record (fp64 sums equal to summation
-     order).  Ignored by every other entry point. */
+  /* Statistics with the linearization (round 4).  stats_workspace != NULL (an initialised rato_risk_stats workspace;
+     row-parallel kernel only: cols_per_thread = -1; Z requested; M <= 524,288): the call also leaves the rato_risk_stats
+     record of the Z it produces in stats_out (double[RATO_N_STATS]; tail level stats_alpha, threshold stats_thr).
+     SMALL batches (every workgroup of the launch resident at once: fewer tiles than workgroup slots, e.g. BASELINE C2 /
+     C3) compute it in a few extra workgroups of the SAME launch: Z is written right after the rollout, the statistics
+     workgroups wait until every tile's Z has been counted in and select while the Jacobian is still being stored -- no
+     dependent statistics launch.  Larger batches issue rato_risk_stats behind the kernel from the same call: beside a
+     store-saturated producer the selection's dependent global round trips run several times slower than behind it.
+     Same selection, same record (fp64 sums equal to summation order).  Ignored by every other entry point. */
   void* stats_workspace;
   double* stats_out;
   double stats_alpha;

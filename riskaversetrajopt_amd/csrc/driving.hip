@@ -396,10 +396,11 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
   const int n_prod = tail.ws ? tail.n_prod : (int)gridDim.x;
-  if ((int)blockIdx.x >= n_prod) {
+  if (tail.is_stats((int)blockIdx.x)) {
     rato_sel::stats_tail_run<CROWS_NW * RATO_WAVE>(tail, Z, (long)P.M, car_lds_raw);
     return;
   }
+  const int pbid = (int)blockIdx.x;
   unsigned* const z_signal = tail.ws ? tail.ws->sig : nullptr;
   const size_t M = (size_t)P.M;
   const int S = P.S;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   const int nrows = 2 * S;
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
   if (!LOOP && !PHILOX) {
-    const size_t mr = (size_t)((int)blockIdx.x / split) * CROWS_SAMPLES + lane;
+    const size_t mr = (size_t)(pbid / split) * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   int dg_tiles = 0;
   dg_mark = wall_clock64();
 #endif
-  for (int unit = (int)blockIdx.x; unit < n_units;) {
+  for (int unit = pbid; unit < n_units;) {
   int tile, part_id, row_split;
   if (LOOP && unit < n_whole) {
     tile = unit;
@@ -959,7 +960,9 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
     rato_sel::StatsTail tail = {};
     size_t lds_launch = lds;
     int grid_launch = grid_x;
-    if (p->stats_workspace) {
+    // (in the launch only while the whole grid is resident at once -- no queue; otherwise behind it, below)
+    const bool stats_behind = p->stats_workspace && queue;
+    if (p->stats_workspace && !stats_behind) {
       int Gs = 0;
       const int extra = rato_sel::stats_tail_workgroups<CROWS_NW * RATO_WAVE>(p->M, Gs);
       if (extra < 0) return RATO_EINVAL;   // beyond the one-launch forms of the selection: use rato_risk_stats
@@ -1002,6 +1005,9 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
                            dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail);
     }
     RATO_LAUNCH_CHECK();
+    if (stats_behind)
+      return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace,
+                             rato_risk_stats_workspace_bytes(p->M), p->stats_out, stream);
     return RATO_OK;
   }
   switch (spt) {

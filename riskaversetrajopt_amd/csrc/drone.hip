@@ -720,7 +720,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
   const int n_prod = tail.ws ? tail.n_prod : (int)gridDim.x;
-  if ((int)blockIdx.x >= n_prod) {
+  if (tail.is_stats((int)blockIdx.x)) {
     rato_sel::stats_tail_run<ROWS_NW * RATO_WAVE>(tail, Z, (long)P.M, lds_raw);
     return;
   }
@@ -1297,7 +1297,9 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     rato_sel::StatsTail tail = {};
     size_t lds_launch = lds;
     int grid_launch = grid;
-    if (p->stats_workspace) {
+    // (in the launch only while the whole grid is resident at once -- no queue; otherwise behind it, below)
+    const bool stats_behind = p->stats_workspace && queue;
+    if (p->stats_workspace && !stats_behind) {
       int Gs = 0;
       const int extra = rato_sel::stats_tail_workgroups<ROWS_NW * RATO_WAVE>(p->M, Gs);
       if (extra < 0) return RATO_EINVAL;   // beyond the one-launch forms of the selection: use rato_risk_stats
@@ -1322,6 +1324,9 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     }
 #undef RATO_ROWS_LAUNCH
     RATO_LAUNCH_CHECK();
+    if (stats_behind)
+      return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace,
+                             rato_risk_stats_workspace_bytes(p->M), p->stats_out, stream);
     return RATO_OK;
   }
 #define RATO_CASE(C, L) \

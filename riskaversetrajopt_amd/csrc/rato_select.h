@@ -102,13 +102,16 @@ __device__ bool wait_signal(unsigned* flag) {
   if (threadIdx.x == 0) {
     const unsigned long long t_start = wall_clock64();
     unsigned ok = 1;
-    for (unsigned tries = 0; __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++tries) {
+    // RELAXED polls, ONE acquire at the end: an acquire load at agent scope invalidates this XCD's L2 every time -- 62
+    // workgroups polling that way beside the producers took the C5 shard from 194 to 269 us
+    for (unsigned tries = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++tries) {
       if ((tries & 255u) == 255u && wall_clock64() - t_start > RS_COOP_WAIT_TICKS) {
         ok = 0;
         break;
       }
-      if (tries < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(32);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
   }
   __syncthreads();
@@ -506,6 +509,12 @@ __device__ void rs_coop_body(const float* __restrict__ Z, long M, double alpha, 
 
 // The statistics of the Z a row-parallel linearize launch produces, computed by G (or one) EXTRA workgroups at the end of
 // that launch's grid (blockIdx >= n_prod): what the launcher hands the kernel.  ws == NULL: no statistics ride along.
+// LAST in the grid, never first: with a fixed tile per workgroup the statistics must not hold a slot a producer is still
+// waiting for.  Used for SMALL batches only (every workgroup of the launch resident at once, the memory system far from
+// saturated).  Beside a store-saturated producer the selection's chain of dependent global round trips (histogram
+// atomics, polls, Z re-read) is several times SLOWER than behind it: statistics workgroups resident from the start of a
+// queue-mode launch took the C5 shard from 194 to 250-269 us and the metric configuration from 579 to 582
+// (profiles/r04_j_stats_in_launch.txt) -- for those launches the same call issues rato_risk_stats behind the kernel.
 struct StatsTail {
   Workspace* ws;
   double* out;
@@ -515,6 +524,7 @@ struct StatsTail {
   float thr;
   int G;        // 0: one workgroup (rs_small_body); > 0: that many cooperating workgroups (rs_coop_body)
   int n_prod;   // workgroups of the producer proper
+  __device__ bool is_stats(int b) const { return ws && b >= n_prod; }
 };
 
 // ascending 0-based rank of sort(Z)[M - floor(alpha M) - 1] (drone_main_plot.py:649-651); alpha M == M wraps to the maximum

@@ -211,7 +211,7 @@ def test_C5_shard_size_properties():
 def test_pedestrian_near_contact(gap):
     """The reference's singular edge: force_on_pedestrian divides by |p_ego - p_ped| (driving.py:154) and the separation
     distance differentiates the same norm (driving.py:228).  Pedestrians are placed so that the ego passes within ``gap``
-    of them (4e-3: closest approach < 1e-2 -- the unit normal turns by O(1) within one step and dn/dp ~ 1/r > 100; 1.0: deep
+    of them (4e-3: closest approach < 2e-2 -- the unit normal turns by O(1) within one step and dn/dp ~ 1/r > 100; 1.0: deep
     inside the minimum separation distance, constraint strongly violated).  HIP vs the fp64 oracle on the same numbers: finite everywhere,
     states / distances to the usual tolerances away from the singular step, Jacobian rows to 1/gap times the usual one."""
     from oracle import driving as ocar
@@ -236,7 +236,7 @@ def test_pedestrian_near_contact(gap):
     xs_o = o.us_to_state_trajectories(us)
     delta = np.linalg.norm(xs_o[:, :, 0:2] - xs_o[:, :, 4:6], axis=-1)
     print(f"gap {gap}: closest approach {delta.min():.3e}")
-    assert delta.min() < max(1e-2, 3 * gap)
+    assert delta.min() < max(2e-2, 3 * gap)
     xs = d.us_to_state_trajectories(us)
     assert np.isfinite(xs).all()
     amp = max(1.0, 1.0 / delta.min())
