@@ -140,12 +140,19 @@ class DroneWork:
         else:
             self.kernel = "drone_eval_kernel<philox>" if self.philox else "drone_eval_kernel"
 
-    def hot_kernel(self, events=None, slot=0, reduce=True):
+    def stats_in_launch(self):
+        """small batches: the linearize launch itself carries the statistics of its Z (rato_saa.h: params.stats_*)"""
+        return (self.mode == "linearize" and self.kernel == "drone_linearize_rows_kernel"
+                and bool(self.model._lib.rato_drone_stats_in_launch(self.M, self.S)))
+
+    def hot_kernel(self, events=None, slot=0, reduce=True, stats_request=None):
         """One pass; ``events`` bracket ONLY the dominant kernel's launch.  ``reduce=False``: the partial sums stay
-        unreduced (the single-GPU step folds their reduction into the launch of the risk statistics)."""
+        unreduced (the single-GPU step folds their reduction into the launch of the risk statistics).
+        ``stats_request`` = (workspace, record, alpha): the statistics ride in the linearize launch (small batches)."""
         if self.mode == "linearize":
             return self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
-                                               out=self.outs[slot], events=events, factored=self.fact, reduce=reduce)
+                                               out=self.outs[slot], events=events, factored=self.fact, reduce=reduce,
+                                               stats_request=stats_request)
         if events is not None:
             events[0].record()
         Z, _, _ = self.model.eval_device(self.us)
@@ -243,11 +250,16 @@ class DrivingWork:
         else:
             self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_kernel"
 
-    def hot_kernel(self, events=None, slot=0):
+    def stats_in_launch(self):
+        return (self.mode == "linearize" and self.kernel == "car_linearize_rows_kernel"
+                and bool(self.model._lib.rato_car_stats_in_launch(self.M, self.S)))
+
+    def hot_kernel(self, events=None, slot=0, stats_request=None):
         if events is not None:
             events[0].record()
         if self.mode == "linearize":
-            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.outs[slot])
+            r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.outs[slot],
+                                            stats_request=stats_request)
         else:
             r = {"Z": self.model.eval_device(self.us)[0]}
         if events is not None:
@@ -467,6 +479,8 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     ev_lin = [torch.cuda.Event() for _ in range(2)]       # hot kernel of the slot finished
     ev_free = [torch.cuda.Event() for _ in range(2)]      # statistics of the slot finished (its buffers are free)
     counter = [0]
+    in_launch = (world == 1 and not pipelined and hasattr(work, "stats_in_launch") and work.stats_in_launch()
+                 and not os.environ.get("RATO_BENCH_NO_IN_LAUNCH"))
 
     def step(i=None):
         """One pass of the hot path: dominant kernel -> partial sums -> [one all-gather of the record when N > 1] ->
@@ -476,6 +490,10 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         counter[0] += 1
         if pipelined:
             main_stream.wait_event(ev_free[slot])
+        if in_launch:   # small batches: the linearize launch carries the statistics of its Z (+ the sample sums behind it)
+            r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot,
+                                stats_request=(wss[slot], stats_out[slot], args.alpha))
+            return work.sums(r)
         fold = (world == 1 and isinstance(work, (DroneWork, HopperWork)) and work.mode == "linearize" and not pipelined
                 and not os.environ.get("RATO_BENCH_NO_FOLD"))
         if fold:       # single GPU: linearize, then ONE launch for the sample sums + VaR / CVaR (2 launches per step)
@@ -573,7 +591,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         except Exception as e:                          # a diagnostic must never take the bench line down
             print(f"note: clock probe skipped ({e})", file=sys.stderr)
     final_stats = stats_out[(counter[0] - 1) & 1].cpu().numpy()
-    launch = "hipGraph replay of the whole step" if use_graph else (
+    launch = ("hipGraph replay of the whole step" + (" (the statistics ride in the linearize launch)" if in_launch else "")) if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
         if pipelined else "eager, one stream, no overlap between steps")
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "

@@ -226,6 +226,11 @@ int rato_drone_obstacle_constraints(const rato_drone_params* p, const float* xs,
 /* ---------------------------------------------------------------- driving */
 
 /* Constants of driving_params.py:1-42 / Model.__init__ driving.py:84-120. */
+/* 1 when rato_drone_linearize / rato_car_linearize (row-parallel kernel) with params.stats_* would compute the statistics
+ * in its own launch for this batch (small batches), 0 when it would issue rato_risk_stats behind the kernel. */
+int rato_drone_stats_in_launch(int32_t M, int32_t S);
+int rato_car_stats_in_launch(int32_t M, int32_t S);
+
 typedef struct rato_car_params {
   int32_t M;
   int32_t S;

@@ -156,6 +156,8 @@ SIGNATURES = {
                                            C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
+    "rato_drone_stats_in_launch": (C.c_int, [C.c_int32, C.c_int32]),
+    "rato_car_stats_in_launch": (C.c_int, [C.c_int32, C.c_int32]),
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
 }

@@ -1036,3 +1036,15 @@ extern "C" int rato_car_linearize_philox(const rato_car_params* p, const float* 
   return car_linearize_impl(p, us, nullptr, seed, sqrtf(sampler_dt), x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z,
                             final_du, final_rhs, -1, stream);
 }
+
+// Would rato_car_linearize (row-parallel kernel) with params.stats_* compute the statistics IN its launch?  (see
+// rato_drone_stats_in_launch)  1 yes, 0 no.
+extern "C" int rato_car_stats_in_launch(int32_t M, int32_t S) {
+  if (M <= 0 || S < 2 || car_rows_lds_bytes(S) > CAR_ROWS_LDS_MAX) return 0;
+  int per_cu = (int)(CAR_ROWS_LDS_MAX / car_rows_lds_bytes(S));
+  if (per_cu > 32 / CROWS_NW) per_cu = 32 / CROWS_NW;
+  if (per_cu < 1) per_cu = 1;
+  const int n_tiles = (M + CROWS_SAMPLES - 1) / CROWS_SAMPLES;
+  int G = 0;
+  return n_tiles <= g_car_queue_pool.cus() * per_cu && rato_sel::stats_tail_workgroups<CROWS_NW * RATO_WAVE>(M, G) > 0;
+}

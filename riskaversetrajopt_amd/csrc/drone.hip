@@ -1360,3 +1360,16 @@ extern "C" int rato_drone_linearize_philox(const rato_drone_params* p, const flo
   return drone_linearize_impl(p, us, nullptr, seed, sqrtf(sampler_dt), mass, Qsym, G, W, A22, g_up, Z, part, -1, 0,
                               stream);
 }
+
+// Would rato_drone_linearize (row-parallel kernel) with params.stats_* compute the statistics IN its launch?  (Small
+// batches: fewer tiles than resident workgroup slots, i.e. no tile queue; the facades then ask for them there and fold the
+// statistics of larger batches into their partial-sum launch instead.)  1 yes, 0 no.
+extern "C" int rato_drone_stats_in_launch(int32_t M, int32_t S) {
+  if (M <= 0 || S < 2 || rows_lds_bytes(S) > ROWS_LDS_MAX) return 0;
+  int per_cu = (int)(ROWS_LDS_MAX / rows_lds_bytes(S));
+  if (per_cu > 32 / ROWS_NW) per_cu = 32 / ROWS_NW;
+  if (per_cu < 1) per_cu = 1;
+  const int n_tiles = (M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
+  int G = 0;
+  return n_tiles <= device_cus() * per_cu && rato_sel::stats_tail_workgroups<ROWS_NW * RATO_WAVE>(M, G) > 0;
+}

@@ -269,14 +269,14 @@ class Model:
     def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, fused=True, **kw):
         """One single-GPU SAA step: the linearize kernel and the exact fraction satisfied / VaR / CVaR of its Z
         (driving.py:630-671).  -> (linearize result dict, stats double[N_STATS]).  ``fused`` (default; row-parallel kernel,
-        M <= stats.FUSED_MAX_M): ONE launch -- the statistics are computed by extra workgroups of the linearize launch as
+        small batches: rato_car_stats_in_launch): ONE launch -- the statistics are computed by extra workgroups of the linearize launch as
         soon as the last tile's Z has landed (the final rows of the driving problem are sample independent: nothing else
         follows the kernel).  Otherwise the kernel and rato_risk_stats behind it."""
         alpha = self.alpha if alpha is None else alpha
         M = int(self._ws.numel())
         cpt, tile = C.c_int32(int(kw.get("cols_per_thread", 0))), C.c_int32(0)
         self._lib.rato_car_linearize_plan(M, self.S, C.byref(cpt), C.byref(tile))
-        if fused and M <= stats.FUSED_MAX_M and cpt.value == -1:
+        if fused and cpt.value == -1 and self._lib.rato_car_stats_in_launch(M, self.S):
             if workspace is None:
                 workspace = stats.new_workspace(M, self.device)
             if stats_out is None:

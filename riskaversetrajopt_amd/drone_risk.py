@@ -445,13 +445,14 @@ class Model:
     def step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, events=None, fused=True, **kw):
         """One single-GPU SAA step: linearize, the sample sums (drone_risk.py:294-296) and fraction satisfied / VaR / CVaR of
         Z (:661, :663-695, drone_main_plot.py:640-652).  -> (linearize result dict, stats double[N_STATS]).
-        ``fused`` (default; row-parallel kernel, M <= stats.FUSED_MAX_M): the statistics are computed by extra workgroups
-        of the linearize launch itself as soon as the last tile's Z has landed -- long before the Jacobian has been stored
-        -- and only the tiny reduction of the sample sums (complete when the kernel ends) follows it.  Otherwise: the
-        kernel, then ONE launch for sums + statistics (rato_sums_and_risk_stats)."""
+        ``fused`` (default; row-parallel kernel, batches small enough for the whole launch to be resident at once:
+        rato_drone_stats_in_launch): the statistics are computed by extra workgroups of the linearize launch itself as soon
+        as the last tile's Z has landed -- before the Jacobian has been stored -- and only the tiny reduction of the sample
+        sums (complete when the kernel ends) follows it.  Otherwise: the kernel, then ONE launch for sums + statistics
+        (rato_sums_and_risk_stats) -- beside a store-saturated kernel the selection would run slower than behind it."""
         alpha = self.alpha if alpha is None else alpha
         _, mass, _, M = self._inputs(kw.get("inputs"))
-        if fused and M <= stats.FUSED_MAX_M and \
+        if fused and self._lib.rato_drone_stats_in_launch(M, self.S) and \
                 self.linearize_plan(M, mass.numel(), kw.get("cols_per_thread", 0), kw.get("samples_per_lane", 0))[1] == -1:
             if workspace is None:
                 workspace = stats.new_workspace(M, self.device)

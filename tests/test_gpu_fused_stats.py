@@ -112,8 +112,11 @@ def test_refused_where_it_cannot_work():
                            stats_request=(ws, out, 0.1))
     with pytest.raises(_lib.RatoError):                              # Z must be requested
         d.linearize_device(_us(20, 3, 0), want_Z=False, stats_request=(ws, out, 0.1))
-    big, _ = _model("driving", 600000, 4)                            # beyond 64 x 512 x 16 keys
-    with pytest.raises(_lib.RatoError):
-        big.linearize_device(_us(4, 2, 0), stats_request=(stats.new_workspace(600000, big.device), out, 0.05))
-    r, st = big.step_device(_us(4, 2, 0))                            # step_device falls back to the separate launch there
-    assert torch.isfinite(st).all()
+    # a batch beyond one round of workgroup slots: the same call issues rato_risk_stats behind the kernel instead
+    big, _ = _model("driving", 200000, 10)
+    assert not big._lib.rato_car_stats_in_launch(200000, 10) and d._lib.rato_drone_stats_in_launch(2000, 20)
+    ws2, out2 = stats.new_workspace(200000, big.device), torch.empty(stats.N_STATS, dtype=torch.float64, device=big.device)
+    r = big.linearize_device(_us(10, 2, 0), stats_request=(ws2, out2, 0.05))
+    ref = stats.risk_stats_device(r["Z"], 0.05)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, ref)
