@@ -561,6 +561,15 @@ size_t rato_cut_result_bytes(void);
  * kept from the previous subproblem, their tail-row sums under the new linearization point, reduced into sums_b_host. */
 int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep, int32_t n_keep, void* stream);
 
+/* The "define" half of a reduced SCP iteration of the drone (system 0) as one call: us [S][3] doubles (host) -> us_dev
+ * (through the pinned us_host), rato_drone_linearize_generators at them without tables (A22 [S][3][ld]: kernel scratch;
+ * Z [z_floats >= M]; part [ceil(M/256)][6S+6]), the sample sums reduced straight into sums_host (pinned, 6S+6 doubles),
+ * the non-finite count of Z and part (bad_dev / bad_host pinned, or both NULL), rato_cut_begin(us, keep, n_keep), ONE
+ * synchronisation.  RATO_ENONFINITE when the count is not zero.  Follow with rato_cut_solve(kept_in_flight = 1). */
+int rato_cut_define_drone(rato_cut_solver* s, const double* us, float* us_host, float* us_dev, float* A22, float* Z,
+                          int64_t z_floats, float* part, double* sums_host, uint32_t* bad_dev, uint32_t* bad_host,
+                          const int32_t* keep, int32_t n_keep, void* stream);
+
 /* The loop.  final_du (n_c x nU, row-major), final_rhs (n_c): the equality rows;  u_lin: the linearization point (the
  * one given to rato_cut_begin);  with_cvar 0: the reference's relaxed first iterations (no CVaR rows: one master solve);
  * tol: a cut is added while CVaR - c_s slack - rhs0 > tol, at most max_cuts; a last cut with violation in

@@ -89,6 +89,7 @@ SIGNATURES = {
     "rato_cut_config_bytes": (C.c_size_t, []),
     "rato_cut_result_bytes": (C.c_size_t, []),
     "rato_cut_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
+    "rato_cut_define_drone": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 5 + [C.c_int32, c_stream]),
     "rato_cut_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
                                  C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
                                  C.POINTER(CutResult), c_stream]),

@@ -167,6 +167,42 @@ extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int
   return rato_sum_partials_f64(c.part_b, s->nblk, n_keep * s->nc, 1.0, c.sums_b_host, stream);
 }
 
+// The "define" half of a reduced SCP iteration of the DRONE as one call (table-free oracle: no linearization table is
+// kept): the controls to the device, the generators-only linearization at them (what is left of it here: the sample
+// sums of the final rows and Z), the reduction of those sums straight into PINNED host memory, the count of
+// non-finite outputs, rato_cut_begin (u_k in fp64 + the kept cuts against it) and ONE synchronisation.  Round 3 issued
+// these from Python: ~0.15 ms of interpreter time per SCP iteration around 0.1 ms of device work.
+//   us [S][3] doubles (host);  us_host (pinned) / us_dev: [S][3] floats;  A22 [S][3][ld] floats (the kernel's scratch);
+//   Z [ld];  part [ceil(M/256)][6S+6] floats;  sums_host (pinned): 6S+6 doubles (sums, not means);
+//   bad_dev / bad_host (pinned): one uint32 each, or both NULL (no non-finite check).
+extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float* us_host, float* us_dev, float* A22,
+                                     float* Z, int64_t z_floats, float* part, double* sums_host, uint32_t* bad_dev,
+                                     uint32_t* bad_host, const int32_t* keep, int32_t n_keep, void* stream) {
+  if (!s || s->c.system != 0 || !us || !us_host || !us_dev || !A22 || !Z || !part || !sums_host || (!bad_dev != !bad_host) ||
+      z_floats < s->c.M)
+    return RATO_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nU = s->nU, S = s->c.S, ncols = 6 * S + 6;
+  for (int i = 0; i < nU; ++i) us_host[i] = (float)us[i];
+  hipError_t e = hipMemcpyAsync(us_dev, us_host, sizeof(float) * (size_t)nU, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  int rc = rato_drone_linearize_generators(&s->drone, us_dev, s->c.s0, s->c.s1, s->c.s2, A22, nullptr, nullptr, Z, part,
+                                           stream);
+  if (rc != RATO_OK) return rc;
+  if ((rc = rato_sum_partials(part, s->nblk, ncols, 1.0, sums_host, stream)) != RATO_OK) return rc;
+  if (bad_dev) {
+    if ((rc = rato_count_nonfinite(Z, z_floats, bad_dev, stream)) != RATO_OK) return rc;
+    if ((rc = rato_count_nonfinite_acc(part, (int64_t)s->nblk * ncols, bad_dev, stream)) != RATO_OK) return rc;
+    e = hipMemcpyAsync(bad_host, bad_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  if ((rc = rato_cut_begin(s, us, keep, n_keep, stream)) != RATO_OK) return rc;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  if (bad_host && *bad_host) return RATO_ENONFINITE;
+  return RATO_OK;
+}
+
 extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const double* final_rhs, int32_t n_c,
                               const double* u_lin, int32_t with_cvar, double tol, int32_t max_cuts,
                               double final_cut_above, int32_t check_finite, int32_t* keep, int32_t* keep_idle_count,

@@ -381,6 +381,8 @@ class CvarCutSolver:
         The master QP is tiny (3S+1 variables): a BLAS pool with one thread per host core (256 on the MI355X
         boxes) makes every call slower AND starves the thread that feeds the GPU (measured: 2.9 ms instead of
         0.65 ms per oracle call), so the loop runs under a 4-thread limit."""
+        if kwargs.get("u_lin") is not None and not kwargs.get("verbose") and self.native_loop_applies():
+            return self._solve(*args, **kwargs)   # the native loop: no BLAS call is made on this side
         ctl = _threadpool_controller()
         if ctl is None:                           # pragma: no cover
             return self._solve(*args, **kwargs)

@@ -630,6 +630,15 @@ class Model:
             rollout = bool(implicit and generators_only and delta and dW is not None)
         if rollout and not (implicit and delta and dW is not None):
             raise ValueError("the rollout form of the oracle needs implicit=True, delta=True and a materialised dW")
+        world = getattr(self, "_world", 1)
+        if rollout and world == 1 and not verbose:
+            # the benchmarked configuration: define (rato_cut_define_drone) and solve (rato_cut_solve) are one native call each
+            cs = self._reduced_cut_solver(int(self._inputs(None)[3]), mass.numel())
+            cs.implicit = None
+            cs.rollout = ("drone", self._params(cs.M, mass.numel()), dW, mass, Qsym)
+            cs.check_finite = False
+            if cs.native_loop_applies():
+                return self._solve_reduced_native(cs, us_mat_p, scp_iter, tol)
         if generators_only:
             # (the table-free oracle reads neither W nor g: only Z and the sample sums are produced then)
             bufs = getattr(self, "_gen_buffers", None)
@@ -645,15 +654,7 @@ class Model:
                                       rows_out=rows_out, factored=factored)
             self._lin_buffers = r
         M, S = r["M"], self.S
-        world = getattr(self, "_world", 1)
-        cs = getattr(self, "_cut_solver", None)
-        if cs is None:
-            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=S, M=M, ld=mass.numel(),
-                                         R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
-                                         slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max,
-                                         group=getattr(self, "_group", None), world=world, mode=self.method,
-                                         rhs0=-1e-3 / self.MULTIPLIER)
-            self._cut_solver = cs
+        cs = self._reduced_cut_solver(M, mass.numel())
         cs.implicit = cs.rollout = None
         if implicit:
             cs.implicit = (self._params(M, mass.numel()), mass, r["_A22"], r.get("a22_axes", 2))
@@ -688,6 +689,55 @@ class Model:
                         u_lin=(np.asarray(us_mat_p, dtype=np.float64) if delta else None),
                         with_cvar=(scp_iter >= 2), tol=tol, verbose=verbose)
         info["final_du"], info["final_rhs"] = final_du, final_rhs        # (the equality rows: certificate.certify)
+        return info["us"], info["t_risk"], info
+
+    def _reduced_cut_solver(self, M, ld):
+        cs = getattr(self, "_cut_solver", None)
+        if cs is None:
+            cs = cvar_cuts.CvarCutSolver(self._lib, self.device, n_u=n_u, S=self.S, M=M, ld=ld,
+                                         R=n_obs, alpha=self.alpha, dt=self.dt, Rcost=P.R,
+                                         slack_penalty=self.SLACK_PENALTY, u_min=self.u_min, u_max=self.u_max,
+                                         group=getattr(self, "_group", None), world=getattr(self, "_world", 1),
+                                         mode=self.method, rhs0=-1e-3 / self.MULTIPLIER)
+            self._cut_solver = cs
+        return cs
+
+    def _solve_reduced_native(self, cs, us_mat_p, scp_iter, tol):
+        """``solve_reduced`` for the benchmarked configuration (table-free oracle, one GPU) as TWO library calls:
+        rato_cut_define_drone (controls up, generators-only linearization, sample sums into pinned memory, non-finite
+        count, u_k and the kept cuts for the oracle, one synchronisation) and rato_cut_solve (the cutting-plane loop)."""
+        S, M, ld = self.S, cs.M, self._mass.numel()
+        b = getattr(self, "_native_define", None)
+        if b is None or b["key"] != (S, M, ld):
+            e = lambda *sh, dt=torch.float32: torch.empty(sh, dtype=dt, device=self.device)
+            b = {"key": (S, M, ld), "us_host": torch.zeros((S, n_u), dtype=torch.float32).pin_memory(), "us_dev": e(S, n_u),
+                 "A22": e(S, 3, ld), "Z": e(ld), "part": e((M + 255) // 256, 6 * S + 6),
+                 "sums_host": torch.zeros(6 * S + 6, dtype=torch.float64).pin_memory(),
+                 "bad_dev": e(1, dt=torch.int32), "bad_host": torch.zeros(1, dtype=torch.int32).pin_memory()}
+            b["sums_np"] = b["sums_host"].numpy()
+            self._native_define = b
+        us64 = np.ascontiguousarray(us_mat_p, dtype=np.float64)
+        if us64.shape != (S, n_u):
+            raise ValueError(f"us_mat must be ({S},{n_u}), got {us64.shape}")
+        h = cs._native_solver()
+        out = cs._keep_arrays()
+        K = len(cs.keep) if (scp_iter >= 2 and cs.recycle and S >= 2) else 0
+        chk = bool(self.check_finite)
+        rc = self._lib.rato_cut_define_drone(
+            h, us64.ctypes.data, b["us_host"].data_ptr(), b["us_dev"].data_ptr(), b["A22"].data_ptr(), b["Z"].data_ptr(), M,
+            b["part"].data_ptr(), b["sums_host"].data_ptr(), b["bad_dev"].data_ptr() if chk else None,
+            b["bad_host"].data_ptr() if chk else None, out["keep"].ctypes.data, K, _lib.current_stream())
+        if rc == _lib.RATO_ENONFINITE:
+            raise _lib.RatoNonFiniteError("drone linearize (generators): non-finite outputs (RATO_ENONFINITE)")
+        _lib.check(rc, "rato_cut_define_drone")
+        cs.u_lin = us64.reshape(-1).copy()
+        cs._relin_pending = K if K else None
+        cs.check_finite = chk
+        sums = b["sums_np"]
+        final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / M)
+        final_rhs = sums[6 * S:] / M
+        info = cs._solve(None, None, 64, None, final_du, final_rhs, u_lin=us64, with_cvar=(scp_iter >= 2), tol=tol)
+        info["final_du"], info["final_rhs"] = final_du, final_rhs
         return info["us"], info["t_risk"], info
 
     def certify_reduced(self, info):
