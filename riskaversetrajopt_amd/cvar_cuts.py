@@ -401,7 +401,7 @@ class CvarCutSolver:
     def _native_solver(self):
         """the rato_cut_solver for the current samples (rebuilt when they, or the parameters, change)"""
         kind, p, *samples = self.rollout
-        key = (kind, bytes(p)) + tuple(a.data_ptr() for a in samples)
+        key = (kind, bytes(p), bool(self.recycle), self.keep_recent, self.keep_idle, self.keep_max) + tuple(a.data_ptr() for a in samples)
         if self._native is not None and self._native[0] == key:
             return self._native[1]
         self._native_destroy()

@@ -297,8 +297,9 @@ def test_recycled_cuts_are_valid_and_do_not_change_the_iterates():
     us1, _, info1 = d.solve_reduced(start, 5)
     cs = d._cut_solver
     assert cs.recycle and len(cs.keep) >= 1
-    r = d._gen_buffers                                   # the (generators-only) linearization of the kept cuts
-    assert r["G"] is None and r["rows_out"] == 1 and cs.u_lin is not None      # delta form: the buffer holds g
+    # (the table-free oracle keeps no linearization at all: nothing but the samples and u_k stands behind the kept cuts)
+    r = {"G": None, "_W": None, "tile": 64, "_g_up": None}
+    assert cs.rollout is not None and cs.u_lin is not None
     rows, rhs = cs.relinearize_kept_cuts(r["G"], r["_W"], r["tile"], r["_g_up"])
     assert rows.shape == (len(cs.keep), 3 * S) and np.all(rows.reshape(-1, S, 3)[:, :, 2] == 0)
     rng = np.random.RandomState(1)
