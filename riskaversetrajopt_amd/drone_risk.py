@@ -723,17 +723,18 @@ class Model:
         out = cs._keep_arrays()
         K = len(cs.keep) if (scp_iter >= 2 and cs.recycle and S >= 2) else 0
         chk = bool(self.check_finite)
+        # (no device-side scan here: every quantity this path consumes goes through the sample sums -- a NaN / Inf anywhere
+        #  in a rollout reaches its final state and poisons them -- and the oracle checks its own m values)
         rc = self._lib.rato_cut_define_drone(
             h, us64.ctypes.data, b["us_host"].data_ptr(), b["us_dev"].data_ptr(), b["A22"].data_ptr(), b["Z"].data_ptr(), M,
-            b["part"].data_ptr(), b["sums_host"].data_ptr(), b["bad_dev"].data_ptr() if chk else None,
-            b["bad_host"].data_ptr() if chk else None, out["keep"].ctypes.data, K, _lib.current_stream())
-        if rc == _lib.RATO_ENONFINITE:
-            raise _lib.RatoNonFiniteError("drone linearize (generators): non-finite outputs (RATO_ENONFINITE)")
+            b["part"].data_ptr(), b["sums_host"].data_ptr(), None, None, out["keep"].ctypes.data, K, _lib.current_stream())
         _lib.check(rc, "rato_cut_define_drone")
         cs.u_lin = us64.reshape(-1).copy()
         cs._relin_pending = K if K else None
         cs.check_finite = chk
         sums = b["sums_np"]
+        if chk and not np.isfinite(sums).all():
+            raise _lib.RatoNonFiniteError("drone linearize (generators): non-finite sample sums (RATO_ENONFINITE)")
         final_du = self.expand_final_du(sums[:6 * S].reshape(S, 6), 1.0 / M)
         final_rhs = sums[6 * S:] / M
         info = cs._solve(None, None, 64, None, final_du, final_rhs, u_lin=us64, with_cvar=(scp_iter >= 2), tol=tol)
