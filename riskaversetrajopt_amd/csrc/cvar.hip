@@ -476,6 +476,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
   const double inv_m = 1.0 / (double)mass[m];
   const double a21 = -kp * dt * inv_m, dtm = dt * inv_m, cn = sqrt(dt) * P.beta64 * inv_m;
+  // The kernel is bound by fp64 instruction ISSUE (round 4: two lanes per sample made it slower), so the step is written
+  // for the fewest operations: per axis, with c1 = dt kd / m, c2 = dt drag / m,
+  //   a22 = (1 - c1) - 2 c2 |v|,       v' = ((1 - c1) - c2 |v|) v + (dt/m) u - (kp dt/m) p + cn xi,       p' = p + dt v
+  // (the reference's  v + dt ((u - (kp p + kd v)) / m - drag |v| v / m)  multiplied out: 12 operations instead of 19),
+  // and an obstacle row as  1 - [dx (q00 (dx + 2 dp_x) + qs (dy + dp_y)) + dy (q11 (dy + 2 dp_y) + qs dp_x)]
+  // (= g + grad g . dp: 11 operations instead of 16).  One running maximum per obstacle, merged at the end.
+  const double one_c1 = 1.0 - dt * kd * inv_m, c2 = dt * drag * inv_m, c22 = 2.0 * c2;
   double q00[3], qs[3], q11[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -485,10 +492,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   }
   double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
   double dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};
-  double best = -INFINITY;
-  int best_idx = 0;
-  // The kernel is bound by load latency (1.5 waves per SIMD at M = 1e5): the noise of 8 steps is requested as one batch,
-  // and the NEXT batch is already in flight while a batch is consumed (two register buffers, the loop unrolled by two).
+  double best[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int best_t[3] = {0, 0, 0};
+  // The loads are batched: the noise of 8 steps is requested as one batch, and the NEXT batch is already in flight while
+  // a batch is consumed (two register buffers, the loop unrolled by two).
   constexpr int TB = 8;
   auto load = [&](float (&xi)[TB][2], int t0) {
 #pragma unroll
@@ -505,27 +512,28 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
       if (t < S) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const double a22 = 1.0 - dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m;   // at the state BEFORE the step
-          const double ndp = dp[a] + dt * dv[a];
-          dv[a] = a21 * dp[a] + a22 * dv[a] + dtm * xs[t * 3 + a];
+          const double av = fabs(v[a]);                           // at the state BEFORE the step
+          const double a22 = fma(-c22, av, one_c1);
+          const double ndp = fma(dt, dv[a], dp[a]);
+          dv[a] = fma(a21, dp[a], fma(a22, dv[a], dtm * xs[t * 3 + a]));
           dp[a] = ndp;
-          const double u = uk[t * 3 + a];
-          const double acc = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
-          const double pn = p[a] + dt * v[a];
-          v[a] = v[a] + dt * acc + cn * (double)xi[i][a];
+          const double sv = fma(-c2, av, one_c1);
+          const double tv = fma(a21, p[a], fma(dtm, uk[t * 3 + a], cn * (double)xi[i][a]));
+          const double pn = fma(dt, v[a], p[a]);
+          v[a] = fma(sv, v[a], tv);
           p[a] = pn;
         }
+        const double px2 = fma(2.0, dp[0], p[0]), py2 = fma(2.0, dp[1], p[1]), sy = p[1] + dp[1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const double dx = p[0] - P.obs_xy64[j][0], dy = p[1] - P.obs_xy64[j][1];
-          const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
-          const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
-          const double val = gj + wx * dp[0] + wy * dp[1];
-          const int r = j * S + t;
-          if (val > best || (val == best && r < best_idx)) {   // smallest row index among equal values
-            best = val;
-            best_idx = r;
-          }
+          const double ox = P.obs_xy64[j][0], oy = P.obs_xy64[j][1];
+          const double dx = p[0] - ox, dy = p[1] - oy;
+          const double ix = fma(qs[j], sy - oy, q00[j] * (px2 - ox));
+          const double iy = fma(qs[j], dp[0], q11[j] * (py2 - oy));
+          const double val = fma(-dy, iy, fma(-dx, ix, 1.0));
+          const bool up = val > best[j];                          // ascending t: the smallest t among equal values
+          best[j] = up ? val : best[j];
+          best_t[j] = up ? t : best_t[j];
         }
       }
     }
@@ -538,8 +546,17 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
     load(xa, t0 + 2 * TB);
     steps(xb, t0 + TB);
   }
-  m_out[m] = (float)best;
-  arg_out[m] = best_idx;
+  // merge the three maxima: the larger value, the smaller row index r = j S + t among equal values
+  double bv = best[0];
+  int bi = best_t[0];
+#pragma unroll
+  for (int j = 1; j < 3; ++j)
+    if (best[j] > bv) {
+      bv = best[j];
+      bi = j * S + best_t[j];
+    }
+  m_out[m] = (float)bv;
+  arg_out[m] = bi;
 }
 
 // The cut of the rollout form: the tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
