@@ -173,13 +173,14 @@ extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int
 // non-finite outputs, rato_cut_begin (u_k in fp64 + the kept cuts against it) and ONE synchronisation.  Round 3 issued
 // these from Python: ~0.15 ms of interpreter time per SCP iteration around 0.1 ms of device work.
 //   us [S][3] doubles (host);  us_host (pinned) / us_dev: [S][3] floats;  A22 [S][3][ld] floats (the kernel's scratch);
-//   Z [ld];  part [ceil(M/256)][6S+6] floats;  sums_host (pinned): 6S+6 doubles (sums, not means);
+//   Z [ld] or NULL (nothing downstream of this call reads it: without it no obstacle row is formed at all);
+//   part [ceil(M/256)][6S+6] floats;  sums_host (pinned): 6S+6 doubles (sums, not means);
 //   bad_dev / bad_host (pinned): one uint32 each, or both NULL (no non-finite check).
 extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float* us_host, float* us_dev, float* A22,
                                      float* Z, int64_t z_floats, float* part, double* sums_host, uint32_t* bad_dev,
                                      uint32_t* bad_host, const int32_t* keep, int32_t n_keep, void* stream) {
-  if (!s || s->c.system != 0 || !us || !us_host || !us_dev || !A22 || !Z || !part || !sums_host || (!bad_dev != !bad_host) ||
-      z_floats < s->c.M)
+  if (!s || s->c.system != 0 || !us || !us_host || !us_dev || !A22 || !part || !sums_host || (!bad_dev != !bad_host) ||
+      (bad_dev && !Z) || (Z && z_floats < s->c.M))
     return RATO_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nU = s->nU, S = s->c.S, ncols = 6 * S + 6;

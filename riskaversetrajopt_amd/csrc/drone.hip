@@ -163,6 +163,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
 // rato_drone_tail_rows_implicit).  One lane per sample, no LDS tables: a forward pass (rollout + the linear
 // response dx(u_bar) for g_up) that is HBM-read bound like the eval kernel, then the backward final-state
 // adjoint over the a22 the lane has just written.  60 B per sample-step instead of 245 B (factored) / 613 B (products).
+// TABLES: W and g_up are written (the table forms of the cut oracle); WANT_Z: Z is.  A reduced SCP iteration whose oracle
+// re-runs the rollout (the benchmarked configuration) needs neither -- only the sample sums of the final rows -- and then
+// neither the tangent of the linearized dynamics nor any obstacle row is formed: <false, false> is a third of the work.
+template <bool TABLES, bool WANT_Z>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ A22,
@@ -224,12 +228,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       if (valid) A22[((size_t)t * 3 + a) * ld + m] = e22;
     }
     // d x_{t+1} = A_t d x_t + B u_t  (x, y): the forward form of the adjoint row sweep; d p(t+1) = (Phi u_bar)[t]
+    if (TABLES) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const double ndp = dp[a] + dt * dv[a];
-      const double ndv = a21 * dp[a] + a22[a] * dv[a] + dtm * (double)us[t * 3 + a];
-      dp[a] = ndp;
-      dv[a] = ndv;
+      for (int a = 0; a < 2; ++a) {
+        const double ndp = dp[a] + dt * dv[a];
+        const double ndv = a21 * dp[a] + a22[a] * dv[a] + dtm * (double)us[t * 3 + a];
+        dp[a] = ndp;
+        dv[a] = ndv;
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // one Euler-Maruyama step of one axis (drone_risk.py:122-131,148-153)
@@ -238,18 +244,20 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       v[a] = v[a] + dt * acc + cn * (double)xi[a];
       p[a] = pn;
     }
+    if (TABLES || WANT_Z) {
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
       const double dx = p[0] - P.obs_xy64[j][0], dy = p[1] - P.obs_xy64[j][1];
       const double gj = 1.0 - (q00[j] * dx * dx + qs[j] * dx * dy + q11[j] * dy * dy);
       const double wx = -(2.0 * q00[j] * dx + qs[j] * dy), wy = -(qs[j] * dx + 2.0 * q11[j] * dy);
       zmax = fmax(zmax, gj);
-      if (valid && W) {   // (W == NULL: a caller whose cut oracle re-runs the rollout needs only the sample sums)
+      if (TABLES && valid) {   // (!TABLES: a caller whose cut oracle re-runs the rollout needs only the sample sums)
         W[(((size_t)j * S + t) * 2 + 0) * ld + m] = (float)wx;
         W[(((size_t)j * S + t) * 2 + 1) * ld + m] = (float)wy;
         // -g + (grad g) . u   (drone_risk.py:278), or -- rows_out = 1 -- the constraint value g itself
         g_up[((size_t)j * S + t) * ld + m] = (float)(P.rows_out ? gj : (-gj + wx * dp[0] + wy * dp[1]));
       }
+    }
     }
     }
     }   // step t of the batch
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       forward_steps(xb, t0 + TB);
     }
   }
-  if (Z && valid) Z[m] = (float)(zmax - P.tol64);
+  if (WANT_Z && Z && valid) Z[m] = (float)(zmax - P.tol64);
   // final-state Jacobian d x_S / d u_s (rows P, V of each axis), summed over the block's samples, and the rhs
   // (drone_risk.py:271): adjoint from S over the a22 (recomputed from the fp32 table this lane wrote: the consumers of
   // the table see the same numbers)
@@ -1172,8 +1180,15 @@ extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
   const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(double);
   if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 340
-  hipLaunchKernelGGL(drone_linearize_generators_kernel, grid, block, lds, rato::as_stream(stream), *p, us, dW, mass,
-                     Qsym, A22, W, g_up, Z, part);
+  if (W)
+    hipLaunchKernelGGL((drone_linearize_generators_kernel<true, true>), grid, block, lds, rato::as_stream(stream), *p, us,
+                       dW, mass, Qsym, A22, W, g_up, Z, part);
+  else if (Z)
+    hipLaunchKernelGGL((drone_linearize_generators_kernel<false, true>), grid, block, lds, rato::as_stream(stream), *p, us,
+                       dW, mass, Qsym, A22, W, g_up, Z, part);
+  else
+    hipLaunchKernelGGL((drone_linearize_generators_kernel<false, false>), grid, block, lds, rato::as_stream(stream), *p, us,
+                       dW, mass, Qsym, A22, W, g_up, Z, part);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }

@@ -726,7 +726,7 @@ class Model:
         # (no device-side scan here: every quantity this path consumes goes through the sample sums -- a NaN / Inf anywhere
         #  in a rollout reaches its final state and poisons them -- and the oracle checks its own m values)
         rc = self._lib.rato_cut_define_drone(
-            h, us64.ctypes.data, b["us_host"].data_ptr(), b["us_dev"].data_ptr(), b["A22"].data_ptr(), b["Z"].data_ptr(), M,
+            h, us64.ctypes.data, b["us_host"].data_ptr(), b["us_dev"].data_ptr(), b["A22"].data_ptr(), None, 0,
             b["part"].data_ptr(), b["sums_host"].data_ptr(), None, None, out["keep"].ctypes.data, K, _lib.current_stream())
         _lib.check(rc, "rato_cut_define_drone")
         cs.u_lin = us64.reshape(-1).copy()
