@@ -364,7 +364,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_linearize_kernel(
 // The forward/column kernel above re-rolls the pedestrian once per column group and carries
 // 8 registers per control step; it stays as the fallback when the LDS tables do not fit.
 #ifndef RATO_CDIAG
-#define RATO_CDIAG 0             // diagnostic builds: 1 no Jacobian stores; 4 phase times of every workgroup into g_up; 5 both
+#define RATO_CDIAG 0             // diagnostic builds: 1 no Jacobian stores; 4 phase times of every workgroup into g_up; 5 both;
+#endif                           // 6 the timeline of every workgroup (tools/car_timeline.py)
+#define RATO_CDIAG_PHASES (RATO_CDIAG == 4 || RATO_CDIAG == 5)
+#ifndef RATO_CRAMP
+#define RATO_CRAMP 1             // A/B: 0 = the launch ramp of round 3 (first tile's noise requested after the ego tables, pedestrian
+#endif                           // state requested at the rollout, progress published every step, rollout wave at default priority)
+#ifndef RATO_CROLL_PUBLISH
+#define RATO_CROLL_PUBLISH (RATO_CRAMP ? 4 : 1)   // the rollout wave publishes its progress every this many steps
 #endif
 #ifndef RATO_CROWS_NW
 #define RATO_CROWS_NW 8          // waves per workgroup (A/B builds: tools/ab.sh ... -DRATO_CROWS_NW=16)
@@ -429,8 +436,9 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   constexpr int MAXR = 16;
   const int nrows = 2 * S;
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
-  if (!LOOP && !PHILOX) {
-    const size_t mr = (size_t)(pbid / split) * CROWS_SAMPLES + lane;
+  bool first_unit = true;   // (scalar) the first unit's noise is requested here, in front of the ego tables
+  if ((!LOOP || RATO_CRAMP) && !PHILOX) {
+    const size_t mr = (size_t)((LOOP && pbid < n_whole) ? pbid : (LOOP ? n_whole + (pbid - n_whole) / split : pbid / split)) * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
@@ -502,12 +510,19 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // LOOP with split > 1: the queue hands the first n_whole tiles out whole and the LAST ones as `split` row-interleaved
   // parts each (shorter last units shorten the drain of the launch, as in the drone kernel).
   const int n_units = LOOP ? n_whole + (n_tiles_total - n_whole) * split : n_tiles_total * split;
-#if RATO_CDIAG >= 4   // diagnostic builds 4 / 5 (tools/car_phases.py): where does a tile's time go?  100 MHz ticks, thread 0 / wave 0
+#if RATO_CDIAG_PHASES   // diagnostic builds 4 / 5 (tools/car_phases.py): where does a tile's time go?  100 MHz ticks, thread 0 / wave 0
   unsigned long long dg_t0 = wall_clock64(), dg_prologue = 0, dg_stage = 0, dg_roll = 0, dg_rows = 0, dg_next = 0, dg_mark = 0;
   int dg_tiles = 0;
   dg_mark = wall_clock64();
 #endif
+#if RATO_CDIAG == 6   // per tile: start, rows-after-the-rollout start, end (100 MHz ticks, low 24 bits), flushed into g_up at the end
+  __shared__ unsigned dg_tl[64];
+  int dg_n = 0;
+#endif
   for (int unit = pbid; unit < n_units;) {
+#if RATO_CDIAG == 6
+  if (threadIdx.x == 0 && dg_n < 20) dg_tl[1 + 3 * dg_n] = (unsigned)wall_clock64();
+#endif
   int tile, part_id, row_split;
   if (LOOP && unit < n_whole) {
     tile = unit;
@@ -524,6 +539,13 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   const size_t m = valid ? m_raw : M - 1;
   const float w_s = w_speed[m], w_r = w_rep[m];
   const float ks = P.dt * w_s;
+  // the pedestrian's initial state, requested by the rollout wave HERE so that it arrives under the staging of the noise
+  // tile (requested at the rollout it cost a round trip to memory per tile, behind the workgroup's own row stores)
+  float ped0[4] = {0.f, 0.f, 0.f, 0.f};
+  if (RATO_CRAMP && wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ped0[i] = x0_ped[(size_t)i * M + m];
+  }
 
   // ---- phase 0: queue state and the noise tile (the ego tables were built by this workgroup before the loop: the
   // separate one-workgroup ego prologue launch, 10-30 us in front of every linearize call, is gone)
@@ -545,13 +567,14 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         QPf[(t * CROWS_SAMPLES + lane) * 2 + 1] = x1 * noise_scale;
       }
     }
-    if (LOOP && !PHILOX) {
+    if (LOOP && !PHILOX && !(RATO_CRAMP && first_unit)) {
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = wave + i * CROWS_NW;
         tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
       }
     }
+    first_unit = false;
     if (!PHILOX) {
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     }
   }
   __syncthreads();
-#if RATO_CDIAG >= 4
+#if RATO_CDIAG_PHASES
   if (threadIdx.x == 0) {
     const unsigned long long now = wall_clock64();
     dg_stage += now - dg_mark;
@@ -630,7 +653,13 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     c.w_s = w_s;
     c.w_r = w_r;
     c.cn = sqrtf(P.dt) * P.beta;
-    float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+    float px, py, vx, vy;
+    if (RATO_CRAMP) {
+      px = ped0[0]; py = ped0[1]; vx = ped0[2]; vy = ped0[3];
+      __builtin_amdgcn_s_setprio(3);   // the rollout is the critical path of a tile: its wave wins issue against the sweeps
+    } else {
+      px = x0_ped[0 * M + m]; py = x0_ped[1 * M + m]; vx = x0_ped[2 * M + m]; vy = x0_ped[3 * M + m];
+    }
     cfloat2_t xi = QP[lane], e = EGOP[0];
     for (int t = 0; t < S; ++t) {
       const int slot = t * CROWS_SAMPLES + lane;
@@ -649,11 +678,14 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
       q.x = px;
       q.y = py;
       QP[slot] = q;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) *prog = t + 1;
+      if (RATO_CROLL_PUBLISH == 1 || ((t + 1) % RATO_CROLL_PUBLISH) == 0 || t + 1 == S) {   // (scalar condition)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // waits for the table stores: not on every step
+        if (lane == 0) *prog = t + 1;
+      }
       xi = xi_n;
       e = e_n;
     }
+    if (RATO_CRAMP) __builtin_amdgcn_s_setprio(0);
     // Z = max_t g_t - tol from the q table (driving.py:630-638), by the rollout wave itself as soon as the rollout is
     // done -- BEFORE the rows are swept, so that the statistics workgroups of this launch (params.stats_*) can select on
     // Z while the Jacobian is still being stored (until round 4: the LAST task of the row queue).  Row-split parts: the
@@ -685,12 +717,15 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         }
       }
     }
-#if RATO_CDIAG >= 4
+#if RATO_CDIAG_PHASES
     if (threadIdx.x == 0) {
       const unsigned long long now = wall_clock64();
       dg_roll += now - dg_mark;
       dg_mark = now;
     }
+#endif
+#if RATO_CDIAG == 6
+    if (threadIdx.x == 0 && dg_n < 20) dg_tl[2 + 3 * dg_n] = (unsigned)wall_clock64();
 #endif
   }
 
@@ -757,7 +792,11 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   // ---- next tile
   if (!LOOP) break;
   __syncthreads();   // every wave has finished this tile's rows: the sample tables are dead, head[] may be rewritten
-#if RATO_CDIAG >= 4
+#if RATO_CDIAG == 6
+  if (threadIdx.x == 0 && dg_n < 20) dg_tl[3 + 3 * dg_n] = (unsigned)wall_clock64();
+  ++dg_n;
+#endif
+#if RATO_CDIAG_PHASES
   if (threadIdx.x == 0) {
     const unsigned long long now = wall_clock64();
     dg_rows += now - dg_mark;
@@ -768,7 +807,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     head[2] = n_prod + (int)__hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   unit = head[2];
-#if RATO_CDIAG >= 4
+#if RATO_CDIAG_PHASES
   if (threadIdx.x == 0) {
     const unsigned long long now = wall_clock64();
     dg_next += now - dg_mark;
@@ -776,12 +815,19 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   }
 #endif
   }  // unit loop
-#if RATO_CDIAG >= 4
+#if RATO_CDIAG_PHASES
   if (threadIdx.x == 0 && (size_t)(blockIdx.x + 1) * 8 <= (size_t)S * M) {
     float* o = g_up + (size_t)blockIdx.x * 8;
     o[0] = (float)dg_tiles; o[1] = (float)dg_stage; o[2] = (float)dg_roll; o[3] = (float)dg_rows; o[4] = (float)dg_next;
     o[5] = (float)(wall_clock64() - dg_t0); o[6] = (float)dg_prologue; o[7] = 0.f;
   }
+#endif
+#if RATO_CDIAG == 6
+  __syncthreads();
+  if (threadIdx.x == 0) dg_tl[0] = (unsigned)dg_n;
+  __syncthreads();
+  if (threadIdx.x < 64 && (size_t)(blockIdx.x + 1) * 64 <= (size_t)S * M)
+    g_up[(size_t)blockIdx.x * 64 + threadIdx.x] = (float)(dg_tl[threadIdx.x] & 0xffffffu);
 #endif
   if (LOOP && threadIdx.x == 0) {   // the workgroup that leaves last zeroes the queue for the next launch
     const unsigned gone = __hip_atomic_fetch_add(tile_queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
