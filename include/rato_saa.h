@@ -564,8 +564,10 @@ int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep,
 /* The "define" half of a reduced SCP iteration of the drone (system 0) as one call: us [S][3] doubles (host) -> us_dev
  * (through the pinned us_host), rato_drone_linearize_generators at them without tables (A22 [S][3][ld]: kernel scratch;
  * Z [z_floats >= M] or NULL; part [ceil(M/256)][6S+6]), the sample sums reduced straight into sums_host (pinned, 6S+6 doubles),
- * the non-finite count of Z and part (bad_dev / bad_host pinned, or both NULL), rato_cut_begin(us, keep, n_keep), ONE
- * synchronisation.  RATO_ENONFINITE when the count is not zero.  Follow with rato_cut_solve(kept_in_flight = 1). */
+ * the non-finite count of Z and part (bad_dev / bad_host pinned, or both NULL), rato_cut_begin(us, keep, n_keep).  WAITS
+ * for the sample sums and the count only (an event behind them): the kept cuts' sums may still be in flight when it
+ * returns -- follow with rato_cut_solve(kept_in_flight = 1), which builds the master first and then synchronises the stream
+ * (or synchronise it yourself before reading sums_b_host).  RATO_ENONFINITE when the count is not zero. */
 int rato_cut_define_drone(rato_cut_solver* s, const double* us, float* us_host, float* us_dev, float* A22, float* Z,
                           int64_t z_floats, float* part, double* sums_host, uint32_t* bad_dev, uint32_t* bad_host,
                           const int32_t* keep, int32_t n_keep, void* stream);

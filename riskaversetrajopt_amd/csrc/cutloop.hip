@@ -89,7 +89,11 @@ struct rato_cut_solver {
   rato_car_params car;
   int nU = 0, n = 0, nc = 0, nres = 0, nblk = 0;
   std::vector<double> p_diag, q;
+  hipEvent_t sums_ready = nullptr;   // rato_cut_define_drone: recorded behind the linearization's sample sums (lazily created)
   const void* params() const { return c.system == 0 ? (const void*)&drone : (const void*)&car; }
+  ~rato_cut_solver() {
+    if (sums_ready) (void)hipEventDestroy(sums_ready);
+  }
 };
 
 extern "C" int rato_cut_solver_create(rato_cut_solver** out, const rato_cut_config* cfg) {
@@ -142,6 +146,67 @@ int tail_rows_launch(rato_cut_solver* s, const float* m_base, const int32_t* arg
                                                     res_base, s->nres, slots, K, c.alphaM, part, stream);
 }
 
+// u_k, the controls and the kept slots reach the device IN THE ARGUMENTS of one small launch: an asynchronous copy of a
+// kilobyte costs ~25 us of host time on this stack (the define issued three), a launch ~5.
+constexpr int STAGE_MAX = 192, STAGE_SLOTS = 64;
+struct StageArgs {
+  double uk[STAGE_MAX];
+  float us[STAGE_MAX];
+  int32_t slots[STAGE_SLOTS];
+};
+__global__ void cut_stage_kernel(const StageArgs a, int n_uk, int n_us, int n_slots, double* __restrict__ uk_dev,
+                                 float* __restrict__ us_dev, int32_t* __restrict__ slots_dev) {
+  const int i = threadIdx.x;
+  if (i < n_uk) uk_dev[i] = a.uk[i];
+  if (i < n_us) us_dev[i] = a.us[i];
+  if (i < n_slots) slots_dev[i] = a.slots[i];
+}
+
+// u_lin -> uk_dev (fp64), us (optional) -> us_dev (fp32), keep -> slots_dev: one launch when they fit its arguments
+int stage_inputs(rato_cut_solver* s, const double* u_lin, const float* us_f32, float* us_dev, const int32_t* keep, int n_keep,
+                 hipStream_t st) {
+  const rato_cut_config& c = s->c;
+  const int nU = s->nU;
+  if (nU <= STAGE_MAX && n_keep <= STAGE_SLOTS) {
+    StageArgs a;
+    memcpy(a.uk, u_lin, sizeof(double) * (size_t)nU);
+    if (us_f32) memcpy(a.us, us_f32, sizeof(float) * (size_t)nU);
+    for (int k = 0; k < n_keep; ++k) a.slots[k] = keep[k];
+    hipLaunchKernelGGL(cut_stage_kernel, dim3(1), dim3(STAGE_MAX), 0, st, a, nU, us_f32 ? nU : 0, n_keep, c.uk_dev, us_dev,
+                       c.slots_dev);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? RATO_OK : RATO_EHIP - (int)e;
+  }
+  memcpy(c.uk_host, u_lin, sizeof(double) * (size_t)nU);
+  hipError_t e = hipMemcpyAsync(c.uk_dev, c.uk_host, sizeof(double) * (size_t)nU, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  if (us_f32) {   // (us_f32 is the caller's pinned buffer)
+    e = hipMemcpyAsync(us_dev, us_f32, sizeof(float) * (size_t)nU, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  if (n_keep > 0) {
+    for (int k = 0; k < n_keep; ++k) c.slots_host[k] = keep[k];
+    e = hipMemcpyAsync(c.slots_dev, c.slots_host, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  return RATO_OK;
+}
+
+// the kept cuts' tail-row sums under the linearization point staged last, reduced into pinned host memory
+int kept_cuts_launch(rato_cut_solver* s, int n_keep, void* stream) {
+  const rato_cut_config& c = s->c;
+  if (n_keep == 0 || c.S < 2) return RATO_OK;
+  int rc = tail_rows_launch(s, c.ring_m, c.ring_arg, c.ring_res, c.slots_dev, n_keep, c.part_b, stream);
+  if (rc != RATO_OK) return rc;
+  return rato_sum_partials_f64(c.part_b, s->nblk, n_keep * s->nc, 1.0, c.sums_b_host, stream);
+}
+
+bool keep_ok(const rato_cut_solver* s, const int32_t* keep, int n_keep) {
+  for (int k = 0; k < n_keep; ++k)
+    if (keep[k] < 0 || keep[k] >= s->c.cap - 1) return false;
+  return true;
+}
+
 }  // namespace
 
 // Stream-ordered prologue of a subproblem: u_k -> device (fp64), and -- when cuts were kept from the previous
@@ -150,21 +215,12 @@ int tail_rows_launch(rato_cut_solver* s, const float* m_base, const int32_t* arg
 // this work too (one device round trip per "define" instead of two).
 extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep, int32_t n_keep, void* stream) {
   if (!s || !u_lin || n_keep < 0 || n_keep > s->c.keep_max || (n_keep > 0 && !keep)) return RATO_EINVAL;
-  const rato_cut_config& c = s->c;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  memcpy(c.uk_host, u_lin, sizeof(double) * (size_t)s->nU);
-  hipError_t e = hipMemcpyAsync(c.uk_dev, c.uk_host, sizeof(double) * (size_t)s->nU, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
-  if (n_keep == 0 || c.S < 2) return RATO_OK;
-  for (int k = 0; k < n_keep; ++k) {
-    if (keep[k] < 0 || keep[k] >= c.cap - 1) return RATO_EINVAL;
-    c.slots_host[k] = keep[k];
-  }
-  e = hipMemcpyAsync(c.slots_dev, c.slots_host, sizeof(int32_t) * (size_t)n_keep, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
-  int rc = tail_rows_launch(s, c.ring_m, c.ring_arg, c.ring_res, c.slots_dev, n_keep, c.part_b, stream);
+  const bool with_cuts = n_keep > 0 && s->c.S >= 2;
+  if (with_cuts && !keep_ok(s, keep, n_keep)) return RATO_EINVAL;
+  const int rc = stage_inputs(s, u_lin, nullptr, nullptr, keep, with_cuts ? n_keep : 0, st);
   if (rc != RATO_OK) return rc;
-  return rato_sum_partials_f64(c.part_b, s->nblk, n_keep * s->nc, 1.0, c.sums_b_host, stream);
+  return kept_cuts_launch(s, with_cuts ? n_keep : 0, stream);
 }
 
 // The "define" half of a reduced SCP iteration of the DRONE as one call (table-free oracle: no linearization table is
@@ -184,10 +240,14 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
     return RATO_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nU = s->nU, S = s->c.S, ncols = 6 * S + 6;
+  if (n_keep < 0 || n_keep > s->c.keep_max || (n_keep > 0 && !keep)) return RATO_EINVAL;
+  const bool with_cuts = n_keep > 0 && S >= 2;
+  if (with_cuts && !keep_ok(s, keep, n_keep)) return RATO_EINVAL;
   for (int i = 0; i < nU; ++i) us_host[i] = (float)us[i];
-  hipError_t e = hipMemcpyAsync(us_dev, us_host, sizeof(float) * (size_t)nU, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
-  int rc = rato_drone_linearize_generators(&s->drone, us_dev, s->c.s0, s->c.s1, s->c.s2, A22, nullptr, nullptr, Z, part,
+  hipError_t e = hipSuccess;
+  int rc = stage_inputs(s, us, us_host, us_dev, keep, with_cuts ? n_keep : 0, st);   // us, u_k (fp64) and the kept slots: one launch
+  if (rc != RATO_OK) return rc;
+  rc = rato_drone_linearize_generators(&s->drone, us_dev, s->c.s0, s->c.s1, s->c.s2, A22, nullptr, nullptr, Z, part,
                                            stream);
   if (rc != RATO_OK) return rc;
   if ((rc = rato_sum_partials(part, s->nblk, ncols, 1.0, sums_host, stream)) != RATO_OK) return rc;
@@ -197,8 +257,16 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
     e = hipMemcpyAsync(bad_host, bad_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return RATO_EHIP - (int)e;
   }
-  if ((rc = rato_cut_begin(s, us, keep, n_keep, stream)) != RATO_OK) return rc;
-  e = hipStreamSynchronize(st);
+  // The host continues (sample sums -> equality rows -> the master's factorisation) as soon as the SUMS are back; the kept
+  // cuts' re-linearization behind them is waited for by rato_cut_solve(kept_in_flight = 1), after it has built the master.
+  if (!s->sums_ready) {
+    e = hipEventCreateWithFlags(&s->sums_ready, hipEventDisableTiming);
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  e = hipEventRecord(s->sums_ready, st);
+  if (e != hipSuccess) return RATO_EHIP - (int)e;
+  if ((rc = kept_cuts_launch(s, with_cuts ? n_keep : 0, stream)) != RATO_OK) return rc;
+  e = hipEventSynchronize(s->sums_ready);
   if (e != hipSuccess) return RATO_EHIP - (int)e;
   if (bad_host && *bad_host) return RATO_ENONFINITE;
   return RATO_OK;

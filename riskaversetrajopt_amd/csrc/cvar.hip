@@ -693,6 +693,209 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
+// K > 1 (the cuts kept from the previous subproblem, re-linearized at the new u_k): ONE pass per block of 256 samples for
+// all the cuts.  The rollout at u_k is the same for every cut and their tails are nearly the same samples, so the UNION of
+// the tails is compacted (in sample order) and walked in chunks of 64: wave 0 re-runs the rollout once per chunk (e22 of
+// both axes into LDS; at every cut's own t* the position the row is evaluated at), then the waves take a cut each and sweep its
+// adjoint over the chunk.  Launched per cut (gridDim.y = K, the kernel above) the K x ceil(M/256) one-wave workgroups
+// took 104 us for 9 cuts at M = 1e5 -- five latency-bound rounds; this form costs one forward pass + ceil(K / 8) sweeps.
+constexpr int TRU_NW = 8, TRU_KMAX = 16;
+__host__ __device__ inline size_t tail_union_lds_bytes(int S, int K) {
+  const size_t nc = 2 * (size_t)(S - 1) + 1;
+  return sizeof(double) * ((size_t)K * nc + (size_t)K * 2 * RATO_WAVE) + sizeof(float) * (size_t)S * 2 * RATO_WAVE +
+         (sizeof(float) + sizeof(int)) * (size_t)K * RATO_WAVE + sizeof(unsigned) * (size_t)S;
+}
+__global__ __launch_bounds__(TRU_NW* RATO_WAVE) void drone_tail_rows_rollout_union_kernel(
+    rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
+    const float* __restrict__ Qsym, const float* __restrict__ m_base, const int* __restrict__ arg_base,
+    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, int k0, int K, int K_total,
+    double alphaM, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tru_lds[];
+  constexpr int NT = TRU_NW * RATO_WAVE;
+  const int S = P.S;
+  const long M = P.M, ld = P.ld;
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  double* acc = reinterpret_cast<double*>(tru_lds);                        // [K][nc] column sums of the block, per cut
+  double* GW = acc + (size_t)K * nc;                                       // [K][2][64] p_{t*+1} of (cut, lane)
+  float* E = reinterpret_cast<float*>(GW + (size_t)K * 2 * RATO_WAVE);     // [S][2][64] e22 of the current chunk
+  float* WT = E + (size_t)S * 2 * RATO_WAVE;                               // [K][64] tail weight of (cut, lane)
+  int* TR = reinterpret_cast<int*>(WT + (size_t)K * RATO_WAVE);            // [K][64] arg-max row: t | r << 20
+  unsigned* TMASK = reinterpret_cast<unsigned*>(TR + (size_t)K * RATO_WAVE);   // [S] the cuts with a lane whose t* is this step
+  __shared__ int s_src[RATO_BLOCK];
+  __shared__ int s_cnt[RATO_BLOCK / RATO_WAVE];
+  __shared__ float s_ts[TRU_KMAX], s_lam[TRU_KMAX];
+  __shared__ long s_slot[TRU_KMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long block_base = (long)blockIdx.x * RATO_BLOCK;
+  if (tid < K) {
+    const long slot = slots[k0 + tid];
+    float ts, lam;
+    tail_rule(stats_base + slot * stats_stride, alphaM, ts, lam);
+    s_ts[tid] = ts;
+    s_lam[tid] = lam;
+    s_slot[tid] = slot;
+  }
+  for (int i = tid; i < K * nc; i += NT) acc[i] = 0.0;
+  __syncthreads();
+  // ---- the union of the K tails, compacted in sample order
+  bool act = false;
+  if (tid < RATO_BLOCK && block_base + tid < M) {
+    for (int kk = 0; kk < K; ++kk)
+      act = act || (tail_weight(m_base[s_slot[kk] * M + block_base + tid], s_ts[kk], s_lam[kk]) != 0.0f);
+  }
+  const unsigned long long bal = __ballot(act);
+  if (wave < RATO_BLOCK / RATO_WAVE && lane == 0) s_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int base = 0, n_un = 0;
+#pragma unroll
+  for (int i = 0; i < RATO_BLOCK / RATO_WAVE; ++i) {
+    const int c = s_cnt[i];
+    if (i < wave) base += c;
+    n_un += c;
+  }
+  if (act) s_src[base + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+  const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
+  for (int c0 = 0; c0 < n_un; c0 += RATO_WAVE) {   // chunks of 64 union samples
+    for (int i = tid; i < S; i += NT) TMASK[i] = 0u;
+    __syncthreads();   // (s_src complete; the previous chunk's tables are dead)
+    for (int idx = tid; idx < K * RATO_WAVE; idx += NT) {
+      const int kk = idx >> 6, l = idx & 63;
+      float w = 0.0f;
+      int tr = 0;
+      if (c0 + l < n_un) {
+        const long m = block_base + s_src[c0 + l];
+        w = tail_weight(m_base[s_slot[kk] * M + m], s_ts[kk], s_lam[kk]);
+        const int a = arg_base[s_slot[kk] * M + m];
+        const int r = a / S, t = a - r * S;
+        tr = t | (r << 20);
+        if (w != 0.0f) atomicOr(&TMASK[t], 1u << kk);
+      }
+      WT[idx] = w;
+      TR[idx] = tr;
+    }
+    __syncthreads();
+    const bool on = c0 + lane < n_un;
+    const long m = on ? block_base + s_src[c0 + lane] : block_base;
+    const double inv_m = 1.0 / (double)mass[m];
+    const double a21 = -kp * dt * inv_m, dtm = dt * inv_m;
+    if (wave == 0) {
+      // ---- forward: the rollout of the chunk at u_k, once for all cuts
+      const double cn = sqrt(dt) * P.beta64 * inv_m;
+      int t_hi = 0;   // wave-uniform: the largest t* of any (cut, lane) of the chunk
+      {
+        int tm = 0;
+        for (int kk = 0; kk < K; ++kk)
+          if (WT[kk * RATO_WAVE + lane] != 0.0f) tm = max(tm, TR[kk * RATO_WAVE + lane] & 0xfffff);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
+        t_hi = __builtin_amdgcn_readfirstlane(tm);
+      }
+      double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
+      constexpr int TB = 8;   // noise in batches of 8 steps, the next batch in flight while one is consumed
+      auto load = [&](float (&xi)[TB][2], int tb) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = (tb + i <= t_hi) ? tb + i : t_hi;
+          xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
+          xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
+        }
+      };
+      auto steps = [&](const float (&xi)[TB][2], int tb) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int t = tb + i;
+          if (t <= t_hi) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
+              E[(t * 2 + a) * RATO_WAVE + lane] = e22;
+              const double u = uk[t * 3 + a];
+              const double ac = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
+              const double pn = p[a] + dt * v[a];
+              v[a] = v[a] + dt * ac + cn * (double)xi[i][a];
+              p[a] = pn;
+            }
+            unsigned mask = __builtin_amdgcn_readfirstlane(TMASK[t]);
+            while (mask) {   // the cuts with an arg-max row at this step: the position p_{t+1} the row is evaluated at
+              const int kk = __builtin_ctz(mask);
+              mask &= mask - 1u;
+              if (on && WT[kk * RATO_WAVE + lane] != 0.0f && (TR[kk * RATO_WAVE + lane] & 0xfffff) == t) {
+                GW[(kk * 2 + 0) * RATO_WAVE + lane] = p[0];
+                GW[(kk * 2 + 1) * RATO_WAVE + lane] = p[1];
+              }
+            }
+          }
+        }
+      };
+      float xa[TB][2], xb[TB][2];
+      load(xa, 0);
+      for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
+        load(xb, tb + TB);
+        steps(xa, tb);
+        load(xa, tb + 2 * TB);
+        steps(xb, tb + TB);
+      }
+    }
+    __syncthreads();
+    // ---- adjoint sweeps: one cut per wave.  mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
+    for (int kk = wave; kk < K; kk += TRU_NW) {
+      const float wf = WT[kk * RATO_WAVE + lane];
+      const bool in_tail = on && wf != 0.0f;
+      const int ts = in_tail ? (TR[kk * RATO_WAVE + lane] & 0xfffff) : 0;
+      const double w = in_tail ? (double)wf : 0.0;
+      double gval = 0.0, w0 = 0.0, w1 = 0.0;
+      if (in_tail) {   // g and grad_p g of the arg-max row at p_{t*+1}
+        const int rs = TR[kk * RATO_WAVE + lane] >> 20;
+        const double q00 = (double)Qsym[(size_t)(rs * 3 + 0) * ld + m], qss = (double)Qsym[(size_t)(rs * 3 + 1) * ld + m],
+                     q11 = (double)Qsym[(size_t)(rs * 3 + 2) * ld + m];
+        const double ox = rs == 0 ? P.obs_xy64[0][0] : (rs == 1 ? P.obs_xy64[1][0] : P.obs_xy64[2][0]);
+        const double oy = rs == 0 ? P.obs_xy64[0][1] : (rs == 1 ? P.obs_xy64[1][1] : P.obs_xy64[2][1]);
+        const double dx = GW[(kk * 2 + 0) * RATO_WAVE + lane] - ox, dy = GW[(kk * 2 + 1) * RATO_WAVE + lane] - oy;
+        gval = 1.0 - (q00 * dx * dx + qss * dx * dy + q11 * dy * dy);
+        w0 = w * -(2.0 * q00 * dx + qss * dy) * dtm;
+        w1 = w * -(qss * dx + 2.0 * q11 * dy) * dtm;
+      }
+      int t_hi = 0;
+      {
+        int tm = ts;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
+        t_hi = __builtin_amdgcn_readfirstlane(tm);
+      }
+      double* __restrict__ ak = acc + (size_t)kk * nc;
+      double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
+      for (int k = t_hi; k >= 1; --k) {   // wave-uniform
+        const bool in = in_tail && k <= ts;
+        if (in && k == ts) {
+          m0x = 1.0; m1x = 0.0; m0y = 1.0; m1y = 0.0;
+        }
+        double cx = 0.0, cy = 0.0;
+        if (in) {
+          const double ax = 1.0 - (double)E[(k * 2 + 0) * RATO_WAVE + lane], ay = 1.0 - (double)E[(k * 2 + 1) * RATO_WAVE + lane];
+          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * ax;
+          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * ay;
+          m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
+          cx = w0 * m1x;
+          cy = w1 * m1y;
+        }
+        const double s0 = rato::wave_sum_dpp(cx);
+        const double s1 = rato::wave_sum_dpp(cy);
+        if (lane == 0) {
+          ak[(k - 1) * 2 + 0] += s0;
+          ak[(k - 1) * 2 + 1] += s1;
+        }
+      }
+      const double sg = rato::wave_sum_dpp(w * gval);
+      if (lane == 0) ak[nw] += sg;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * nc; i += NT) {
+    const int kk = i / nc, j = i - kk * nc;
+    part[((size_t)blockIdx.x * K_total + (k0 + kk)) * nc + j] = acc[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Table-free form of the DRIVING oracle (R = 1: g_t = -(|e_{t+1} - q_{t+1}| - d_min), e = ego position, q = pedestrian
 // position; driving.py:145-236, :260-313).  Everything about the ego is sample independent (its state carries no noise:
@@ -1190,6 +1393,27 @@ extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const do
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     });
     if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
+  // several cuts (the kept cuts of a subproblem): the union form, up to TRU_KMAX cuts per launch (A/B: RATO_TAIL_UNION=0)
+  static const int union_env = [] { const char* e = getenv("RATO_TAIL_UNION"); return e ? atoi(e) : 1; }();
+  if (K > 1 && union_env) {
+    const size_t lds_u = tail_union_lds_bytes(p->S, K < TRU_KMAX ? K : TRU_KMAX);
+    if (lds_u + 4096 <= 160 * 1024) {
+      static rato::DynamicLdsLimit lds_limit_u;
+      const hipError_t e = lds_limit_u.ensure(lds_u, [](size_t bytes) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(drone_tail_rows_rollout_union_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      });
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
+      for (int k0 = 0; k0 < K; k0 += TRU_KMAX) {
+        const int kn = (K - k0) < TRU_KMAX ? (K - k0) : TRU_KMAX;
+        hipLaunchKernelGGL(drone_tail_rows_rollout_union_kernel, dim3((unsigned)rato::nblocks_for(p->M)),
+                           dim3(TRU_NW * RATO_WAVE), tail_union_lds_bytes(p->S, kn), rato::as_stream(stream), *p, uk, dW,
+                           mass, Qsym, m_base, arg_base, stats_base, (long)stats_stride, slots, k0, kn, K, alphaM, part);
+        RATO_LAUNCH_CHECK();
+      }
+      return RATO_OK;
+    }
   }
   dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_tail_rows_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, mass, Qsym,

@@ -53,7 +53,9 @@ def main():
                 "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
                 "oracle_median_s": float(np.median(out["oracle_s"])), "cuts_median": float(np.median(out["cuts"])),
                 "cuts_max": int(out["cuts"].max()), "cumulative_s": float(out["cumulative_s"][-1]),
-                "wall_s": time.perf_counter() - t_all, "L2_error_last": float(out["L2_error"][-1])}
+                "wall_s": time.perf_counter() - t_all, "L2_error_last": float(out["L2_error"][-1]),
+                "define_total_s": float(np.sum(out["define_s"])), "oracle_total_s": float(np.sum(out["oracle_s"])),
+                "master_total_s": float(np.sum(out["solve_s"]) - np.sum(out["oracle_s"])), "cuts_total": int(out["cuts"].sum())}
         st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)          # this rank's shard
         line["in_sample"] = {k: st[k] for k in ("var", "cvar", "frac_satisfied")}
         if rank == 0:

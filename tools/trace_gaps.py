@@ -34,3 +34,13 @@ print(f"{len(rows)} kernels, span {span / 1e6:.3f} ms, busy {sum(dur.values()) /
 print(f"{'kernel':58s} {'calls':>6s} {'mean us':>9s} {'gap before us':>14s} {'total ms':>9s} {'gaps ms':>8s}")
 for k in sorted(dur, key=lambda k: -dur[k]):
     print(f"{k[:58]:58s} {cnt[k]:6d} {dur[k] / cnt[k] / 1e3:9.2f} {gap[k] / cnt[k] / 1e3:14.2f} {dur[k] / 1e6:9.3f} {gap[k] / 1e6:8.3f}")
+n_dump = int(os.environ.get("TRACE_DUMP", "0"))
+if n_dump:   # the raw sequence at the END of the trace (the last SCP iterations): start (us), duration, idle gap before, kernel
+    tail = rows[-n_dump:]
+    t0 = tail[0][0]
+    prev = None
+    print(f"--- last {n_dump} kernels: start us | duration us | gap before us | kernel")
+    for s, e, name in tail:
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:50]
+        print(f"{(s - t0) / 1e3:10.1f} {(e - s) / 1e3:8.1f} {((s - prev) / 1e3 if prev else 0):8.1f}  {short}")
+        prev = e
