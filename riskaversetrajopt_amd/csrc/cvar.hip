@@ -578,6 +578,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
   const long slot = slots ? slots[kk] : 0;
   const float* __restrict__ mvals = m_base + slot * M;
   const int* __restrict__ arg = arg_base + slot * M;
+#ifdef RATO_TDIAG   // diagnostic build (tools/tail_phases.py): shader-clock ticks of the phases of every block, wave 0, into `part`
+  long long dg[6];
+  const unsigned long long dg_wall0 = wall_clock64();
+  dg[0] = clock64();
+#endif
   float tstar, lambda;
   tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -596,101 +601,135 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
   TailLists lists;
   const int n_tail = compact_tail(w0f, t0, r0, (long)blockIdx.x * RATO_BLOCK, M, unused, &lists);
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) acc[i] = 0.0;
+  __shared__ double s_pt[2][RATO_WAVE];   // p_{t*+1} of the chunk's samples, one axis per wave
   __syncthreads();
-  if (wave == 0) {
-    const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
-    for (int c0 = 0; c0 < n_tail; c0 += RATO_WAVE) {   // chunks of 64 tail samples, in sample order
-      const bool on = c0 + lane < n_tail;
-      const long m = on ? (long)blockIdx.x * RATO_BLOCK + lists.src[c0 + lane] : 0;
-      const double w = on ? (double)lists.w[c0 + lane] : 0.0;
-      const int tr = on ? lists.tr[c0 + lane] : 0;
-      const int ts = tr & 0xfffff, rs = tr >> 20;
-      const double inv_m = 1.0 / (double)mass[m];
-      const double a21 = -kp * dt * inv_m, dtm = dt * inv_m, cn = sqrt(dt) * P.beta64 * inv_m;
-      const double q00 = (double)Qsym[(size_t)(rs * 3 + 0) * ld + m], qss = (double)Qsym[(size_t)(rs * 3 + 1) * ld + m],
-                   q11 = (double)Qsym[(size_t)(rs * 3 + 2) * ld + m];
-      double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
-      double wx = 0.0, wy = 0.0, gval = 0.0;
-      int t_hi = 0;   // wave-uniform: the forward pass only has to reach the largest t* of the chunk
-      {
-        int tm = on ? ts : 0;
+#ifdef RATO_TDIAG
+  dg[1] = clock64();
+  dg[2] = dg[3] = dg[4] = dg[1];
+#endif
+  // The two horizontal axes are independent chains (forward and adjoint) that meet only in the arg-max row's gradient:
+  // wave a runs axis a.  One wave running both was bound by the latency of its own chain (a block has one wave of work).
+  const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
+  const int a = wave;   // (waves 2, 3 only keep the barriers company)
+  const bool cols_in_regs = S - 1 <= RATO_WAVE;
+  double colsum = 0.0;   // lane j: column j of axis a, summed over the chunks (chunk order = sample order)
+  for (int c0 = 0; c0 < n_tail; c0 += RATO_WAVE) {   // chunks of 64 tail samples, in sample order
+    const bool on = c0 + lane < n_tail;
+    const long m = on ? (long)blockIdx.x * RATO_BLOCK + lists.src[c0 + lane] : 0;
+    const double w = on ? (double)lists.w[c0 + lane] : 0.0;
+    const int tr = on ? lists.tr[c0 + lane] : 0;
+    const int ts = tr & 0xfffff, rs = tr >> 20;
+    int t_hi = 0;   // wave-uniform: the forward pass only has to reach the largest t* of the chunk
+    {
+      int tm = on ? ts : 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
-        t_hi = __builtin_amdgcn_readfirstlane(tm);
-      }
+      for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
+      t_hi = __builtin_amdgcn_readfirstlane(tm);
+    }
+    double inv_m = 0.0, a21 = 0.0, dtm = 0.0;
+    if (a < 2) {
+      inv_m = 1.0 / (double)mass[m];
+      a21 = -kp * dt * inv_m;
+      dtm = dt * inv_m;
+      const double cn = sqrt(dt) * P.beta64 * inv_m;
+      double p = P.x_init64[a], v = P.x_init64[3 + a];
       constexpr int TB = 8;   // noise in batches of 8 steps, the next batch in flight while one is consumed
-      auto load = [&](float (&xi)[TB][2], int tb) {
+      auto load = [&](float (&xi)[TB], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = (tb + i <= t_hi) ? tb + i : t_hi;
-          xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
-          xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
+          xi[i] = dW[((size_t)t * 3 + a) * ld + m];
         }
       };
-      auto steps = [&](const float (&xi)[TB][2], int tb) {
+      auto steps = [&](const float (&xi)[TB], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
           const int t = tb + i;
           if (t <= t_hi) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-              const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
-              E[(t * 2 + a) * RATO_WAVE + lane] = e22;
-              const double u = uk[t * 3 + a];
-              const double ac = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
-              const double pn = p[a] + dt * v[a];
-              v[a] = v[a] + dt * ac + cn * (double)xi[i][a];
-              p[a] = pn;
-            }
-            if (on && t == ts) {   // the arg-max row of this sample: g and grad_p g at p_{t*+1}
-              const double dx = p[0] - P.obs_xy64[rs][0], dy = p[1] - P.obs_xy64[rs][1];
-              gval = 1.0 - (q00 * dx * dx + qss * dx * dy + q11 * dy * dy);
-              wx = -(2.0 * q00 * dx + qss * dy);
-              wy = -(qss * dx + 2.0 * q11 * dy);
-            }
+            const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v)) * inv_m);
+            E[(t * 2 + a) * RATO_WAVE + lane] = e22;
+            const double u = uk[t * 3 + a];
+            const double ac = (u - (kp * p + kd * v)) * inv_m - drag * fabs(v) * v * inv_m;
+            const double pn = p + dt * v;
+            v = v + dt * ac + cn * (double)xi[i];
+            p = pn;
+            if (on && t == ts) s_pt[a][lane] = p;   // the arg-max row of this sample is evaluated at p_{t*+1}
           }
         }
       };
-      {
-        float xa[TB][2], xb[TB][2];
-        load(xa, 0);
-        for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
-          load(xb, tb + TB);
-          steps(xa, tb);
-          load(xa, tb + 2 * TB);
-          steps(xb, tb + TB);
-        }
+      float xa[TB], xb[TB];
+      load(xa, 0);
+      for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
+        load(xb, tb + TB);
+        steps(xa, tb);
+        load(xa, tb + 2 * TB);
+        steps(xb, tb + TB);
       }
-      // adjoint sweep: mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
-      const double w0 = w * wx * dtm, w1 = w * wy * dtm;
-      double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
+    }
+#ifdef RATO_TDIAG
+    dg[2] = clock64();
+#endif
+    __syncthreads();   // both axes' positions are in s_pt
+#ifdef RATO_TDIAG
+    dg[3] = clock64();
+#endif
+    if (a < 2) {
+      // g and grad_p g of the arg-max row at p_{t*+1}; adjoint sweep of this wave's axis:
+      // mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
+      double wa = 0.0, gval = 0.0;
+      if (on) {
+        const double q00 = (double)Qsym[(size_t)(rs * 3 + 0) * ld + m], qss = (double)Qsym[(size_t)(rs * 3 + 1) * ld + m],
+                     q11 = (double)Qsym[(size_t)(rs * 3 + 2) * ld + m];
+        const double dx = s_pt[0][lane] - P.obs_xy64[rs][0], dy = s_pt[1][lane] - P.obs_xy64[rs][1];
+        gval = 1.0 - (q00 * dx * dx + qss * dx * dy + q11 * dy * dy);
+        const double wx = -(2.0 * q00 * dx + qss * dy), wy = -(qss * dx + 2.0 * q11 * dy);
+        wa = w * (a == 0 ? wx : wy) * dtm;
+      }
+      double m0 = 0.0, m1 = 0.0;
+      float e_k = (t_hi >= 1) ? E[(t_hi * 2 + a) * RATO_WAVE + lane] : 0.0f;   // (read one step ahead of its use)
       for (int k = t_hi; k >= 1; --k) {   // wave-uniform
+        const float e_next = (k > 1) ? E[((k - 1) * 2 + a) * RATO_WAVE + lane] : 0.0f;
         const bool in = on && k <= ts;
         if (in && k == ts) {
-          m0x = 1.0; m1x = 0.0; m0y = 1.0; m1y = 0.0;
+          m0 = 1.0; m1 = 0.0;
         }
-        double cx = 0.0, cy = 0.0;
+        double c = 0.0;
         if (in) {
-          const double ax = 1.0 - (double)E[(k * 2 + 0) * RATO_WAVE + lane], ay = 1.0 - (double)E[(k * 2 + 1) * RATO_WAVE + lane];
-          const double n0x = m0x + m1x * a21, n1x = m0x * dt + m1x * ax;
-          const double n0y = m0y + m1y * a21, n1y = m0y * dt + m1y * ay;
-          m0x = n0x; m1x = n1x; m0y = n0y; m1y = n1y;
-          cx = w0 * m1x;
-          cy = w1 * m1y;
+          const double aa = 1.0 - (double)e_k;
+          const double n0 = m0 + m1 * a21, n1 = m0 * dt + m1 * aa;
+          m0 = n0; m1 = n1;
+          c = wa * m1;
         }
-        const double s0 = rato::wave_sum_dpp(cx);
-        const double s1 = rato::wave_sum_dpp(cy);
-        if (lane == 0) {
-          acc[(k - 1) * 2 + 0] += s0;
-          acc[(k - 1) * 2 + 1] += s1;
-        }
+        e_k = e_next;
+        const double s0 = rato::wave_sum_dpp(c);
+        // column k-1 of this axis: kept in lane k-1's register while the horizon fits a wave (no LDS read-modify-write
+        // in the chain), in LDS otherwise
+        if (cols_in_regs) colsum += (lane == k - 1) ? s0 : 0.0;
+        else if (lane == 0) acc[(k - 1) * 2 + a] += s0;
       }
-      const double sg = rato::wave_sum_dpp(w * gval);
-      if (lane == 0) acc[nw] += sg;
+      if (a == 0) {
+        const double sg = rato::wave_sum_dpp(w * gval);
+        if (lane == 0) acc[nw] += sg;
+      }
     }
+#ifdef RATO_TDIAG
+    dg[4] = clock64();
+#endif
+    __syncthreads();   // s_pt and the tables are free for the next chunk
   }
+  if (cols_in_regs && a < 2 && lane < S - 1) acc[lane * 2 + a] = colsum;
   __syncthreads();
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
+#ifdef RATO_TDIAG
+  dg[5] = clock64();
+  if (threadIdx.x == 0) {
+    double* o = part + ((size_t)blockIdx.x * K + kk) * nc;
+    for (int i = 0; i < 5; ++i) o[i] = (double)(dg[i + 1] - dg[i]);
+    o[5] = (double)n_tail;
+    o[6] = (double)wall_clock64();
+    o[7] = (double)(wall_clock64() - dg_wall0);   // the block's lifetime in 10 ns ticks: shader clock = sum of the phases / this
+  }
+#endif
 }
 
 // K > 1 (the cuts kept from the previous subproblem, re-linearized at the new u_k): ONE pass per block of 256 samples for
@@ -863,6 +902,8 @@ __global__ __launch_bounds__(TRU_NW* RATO_WAVE) void drone_tail_rows_rollout_uni
         t_hi = __builtin_amdgcn_readfirstlane(tm);
       }
       double* __restrict__ ak = acc + (size_t)kk * nc;
+      const bool cols_in_regs = S - 1 <= RATO_WAVE;   // lane j keeps column j of both axes: no LDS update inside the chain
+      double colx = 0.0, coly = 0.0;
       double m0x = 0.0, m1x = 0.0, m0y = 0.0, m1y = 0.0;
       for (int k = t_hi; k >= 1; --k) {   // wave-uniform
         const bool in = in_tail && k <= ts;
@@ -880,10 +921,17 @@ __global__ __launch_bounds__(TRU_NW* RATO_WAVE) void drone_tail_rows_rollout_uni
         }
         const double s0 = rato::wave_sum_dpp(cx);
         const double s1 = rato::wave_sum_dpp(cy);
-        if (lane == 0) {
+        if (cols_in_regs) {
+          colx += (lane == k - 1) ? s0 : 0.0;
+          coly += (lane == k - 1) ? s1 : 0.0;
+        } else if (lane == 0) {
           ak[(k - 1) * 2 + 0] += s0;
           ak[(k - 1) * 2 + 1] += s1;
         }
+      }
+      if (cols_in_regs && lane < S - 1) {
+        ak[lane * 2 + 0] += colx;
+        ak[lane * 2 + 1] += coly;
       }
       const double sg = rato::wave_sum_dpp(w * gval);
       if (lane == 0) ak[nw] += sg;
