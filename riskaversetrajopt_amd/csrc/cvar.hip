@@ -559,54 +559,22 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   arg_out[m] = bi;
 }
 
-// The cut of the rollout form: the tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
-// rollout in fp64 up to their own t*, leaving e22 = 1 - a22 of both axes in LDS ([S][2][64] floats: exact to 1e-10 of
-// a22), pick up W and g of their arg-max row on the way, and then run the adjoint sweep from t* down, exactly as
-// drone_tail_rows_implicit_kernel does from its table.  Output layout of tail_rows_batch_kernel (offset sum = sum w g).
-__global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
-    rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
-    const float* __restrict__ Qsym, const float* __restrict__ m_base, const int* __restrict__ arg_base,
-    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
-    double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char trr_lds[];
+// The tail phase of ONE cut for one block of 256 samples: thread i brings its sample's tail weight and arg-max row (step t0,
+// row group r0); on return (behind a barrier) acc [2 (S - 1) + 1] holds the block's column sums.  E: [S][2][64] floats.
+__device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, const double* __restrict__ uk,
+                                                 const float* __restrict__ dW, const float* __restrict__ mass,
+                                                 const float* __restrict__ Qsym, float w0f, int t0, int r0,
+                                                 double* __restrict__ acc, float* __restrict__ E) {
   const int S = P.S;
   const long M = P.M, ld = P.ld;
   const int nw = 2 * (S - 1), nc = nw + 1;
-  double* acc = reinterpret_cast<double*>(trr_lds);                   // [nc] column sums of the block
-  float* E = reinterpret_cast<float*>(acc + nc);                      // [S][2][64] e22 of the current chunk
-  const int K = gridDim.y, kk = blockIdx.y;
-  const long slot = slots ? slots[kk] : 0;
-  const float* __restrict__ mvals = m_base + slot * M;
-  const int* __restrict__ arg = arg_base + slot * M;
-#ifdef RATO_TDIAG   // diagnostic build (tools/tail_phases.py): shader-clock ticks of the phases of every block, wave 0, into `part`
-  long long dg[6];
-  const unsigned long long dg_wall0 = wall_clock64();
-  dg[0] = clock64();
-#endif
-  float tstar, lambda;
-  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float w0f = 0.0f;
-  int t0 = 0, r0 = 0;
-  {
-    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
-    if (m0 < M) {
-      w0f = tail_weight(mvals[m0], tstar, lambda);
-      const int a = arg[m0];
-      r0 = a / S;
-      t0 = a - r0 * S;
-    }
-  }
   TailLane unused;
   TailLists lists;
   const int n_tail = compact_tail(w0f, t0, r0, (long)blockIdx.x * RATO_BLOCK, M, unused, &lists);
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) acc[i] = 0.0;
   __shared__ double s_pt[2][RATO_WAVE];   // p_{t*+1} of the chunk's samples, one axis per wave
   __syncthreads();
-#ifdef RATO_TDIAG
-  dg[1] = clock64();
-  dg[2] = dg[3] = dg[4] = dg[1];
-#endif
   // The two horizontal axes are independent chains (forward and adjoint) that meet only in the arg-max row's gradient:
   // wave a runs axis a.  One wave running both was bound by the latency of its own chain (a block has one wave of work).
   const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
@@ -666,13 +634,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
         steps(xb, tb + TB);
       }
     }
-#ifdef RATO_TDIAG
-    dg[2] = clock64();
-#endif
     __syncthreads();   // both axes' positions are in s_pt
-#ifdef RATO_TDIAG
-    dg[3] = clock64();
-#endif
     if (a < 2) {
       // g and grad_p g of the arg-max row at p_{t*+1}; adjoint sweep of this wave's axis:
       // mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
@@ -712,24 +674,47 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
         if (lane == 0) acc[nw] += sg;
       }
     }
-#ifdef RATO_TDIAG
-    dg[4] = clock64();
-#endif
     __syncthreads();   // s_pt and the tables are free for the next chunk
   }
   if (cols_in_regs && a < 2 && lane < S - 1) acc[lane * 2 + a] = colsum;
   __syncthreads();
-  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
-#ifdef RATO_TDIAG
-  dg[5] = clock64();
-  if (threadIdx.x == 0) {
-    double* o = part + ((size_t)blockIdx.x * K + kk) * nc;
-    for (int i = 0; i < 5; ++i) o[i] = (double)(dg[i + 1] - dg[i]);
-    o[5] = (double)n_tail;
-    o[6] = (double)wall_clock64();
-    o[7] = (double)(wall_clock64() - dg_wall0);   // the block's lifetime in 10 ns ticks: shader clock = sum of the phases / this
+}
+
+// The cut of the rollout form: the tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
+// rollout in fp64 up to their own t*, leaving e22 = 1 - a22 of both axes in LDS ([S][2][64] floats: exact to 1e-10 of
+// a22), pick up W and g of their arg-max row on the way, and then run the adjoint sweep from t* down, exactly as
+// drone_tail_rows_implicit_kernel does from its table.  Output layout of tail_rows_batch_kernel (offset sum = sum w g).
+__global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
+    rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
+    const float* __restrict__ Qsym, const float* __restrict__ m_base, const int* __restrict__ arg_base,
+    const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
+    double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char trr_lds[];
+  const int S = P.S;
+  const long M = P.M, ld = P.ld;
+  const int nw = 2 * (S - 1), nc = nw + 1;
+  double* acc = reinterpret_cast<double*>(trr_lds);                   // [nc] column sums of the block
+  float* E = reinterpret_cast<float*>(acc + nc);                      // [S][2][64] e22 of the current chunk
+  const int K = gridDim.y, kk = blockIdx.y;
+  const long slot = slots ? slots[kk] : 0;
+  const float* __restrict__ mvals = m_base + slot * M;
+  const int* __restrict__ arg = arg_base + slot * M;
+  float tstar, lambda;
+  tail_rule(stats_base + slot * stats_stride, alphaM, tstar, lambda);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w0f = 0.0f;
+  int t0 = 0, r0 = 0;
+  {
+    const long m0 = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;
+    if (m0 < M) {
+      w0f = tail_weight(mvals[m0], tstar, lambda);
+      const int a = arg[m0];
+      r0 = a / S;
+      t0 = a - r0 * S;
+    }
   }
-#endif
+  drone_tail_block(P, uk, dW, mass, Qsym, w0f, t0, r0, acc, E);
+  for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
 // K > 1 (the cuts kept from the previous subproblem, re-linearized at the new u_k): ONE pass per block of 256 samples for
