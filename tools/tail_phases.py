@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where does drone_tail_rows_rollout_kernel (one cut) spend its time?  Needs a -DRATO_TDIAG build of the library
-(RATO_SAA_LIB=/path/to/lib.so): wave 0 of every block leaves the shader-clock ticks of its phases in `part`.
+"""What does a launch of drone_tail_rows_rollout_kernel (one cut) cost, with and without work, and do the kernels of an oracle
+round trip cost more between each other than between copies of themselves?  (The per-phase shader-clock ticks and the
+clock-at-cadence measurement quoted in profiles/EXPERIMENTS.md came from a -DRATO_TDIAG build of commit 4fe294d.)
     python tools/tail_phases.py [M] [S]"""
 import os
 import sys
@@ -29,35 +30,6 @@ part = torch.zeros((cs.nblk, cs.nc), dtype=torch.float64, device=d.device)
 for _ in range(3):
     cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slots), 1, part, st)
 torch.cuda.synchronize()
-p = part.cpu().numpy()[:, :7]
-names = ["statistics record, m / arg loads, compaction", "forward (rollout to t*)", "barrier", "row gradient + adjoint sweep", "barrier + write-out"]
-tot = p[:, :5].sum(axis=1)
-print(f"M {M} S {S}: {cs.nblk} blocks, tail samples per block mean {p[:, 5].mean():.1f} max {p[:, 5].max():.0f}")
-for i, n in enumerate(names):
-    print(f"  {n:48s} mean {p[:, i].mean():8.0f} ticks  ({100 * p[:, i].mean() / tot.mean():4.1f} %)")
-print(f"  block total mean {tot.mean():.0f} ticks, max {tot.max():.0f};  blocks end over {(p[:, 6].max() - p[:, 6].min()) * 1e-2:.1f} us (100 MHz clock)")
-
-
-def sclk_mhz():
-    q = part.cpu().numpy()
-    return float(np.median(q[:, :5].sum(axis=1) / np.maximum(q[:, 7], 1.0)) * 100.0)
-
-
-if os.environ.get("RATO_SAA_LIB"):     # (diagnostic build) the shader clock the kernel sees, back to back and at the SCP's cadence
-    import time
-    for _ in range(300):
-        cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slots), 1, part, st)
-    torch.cuda.synchronize()
-    print(f"shader clock seen by the kernel: {sclk_mhz():.0f} MHz after 300 launches back to back")
-    for pause_us in (10, 30, 100, 1000):
-        for _ in range(400):
-            cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slots), 1, part, st)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            while (time.perf_counter() - t0) * 1e6 < pause_us:
-                pass
-        print(f"                                 {sclk_mhz():.0f} MHz with a synchronisation and {pause_us} us of host time between launches")
-    sys.exit(0)
 
 
 def per_launch_us(n=200):
