@@ -261,7 +261,7 @@ constexpr int RS1_T = 1024;
 __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                   int var_is_max, float thr, double* __restrict__ out,
                                                   const float* __restrict__ part, int nblocks, int ncols,
-                                                  double scale, double* __restrict__ sums_out, unsigned* sig) {
+                                                  double scale, double* __restrict__ sums_out) {
   if (blockIdx.x > 0) {   // the sample-mean second stage rides along (independent workgroups)
     sum_partials_block(blockIdx.x - 1, part, nblocks, ncols, scale, sums_out);
     return;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
   __shared__ unsigned h[B1];
   __shared__ double red[5 * (RS1_T / RATO_WAVE)];
   __shared__ float redmax[RS1_T / RATO_WAVE];
-  rs_small_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, out, sig, h, red, redmax);   // rato_select.h
+  rs_small_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, out, nullptr, h, red, redmax);   // rato_select.h (no producer to wait for)
 }
 
 // ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
@@ -285,14 +285,14 @@ constexpr long RS_COOP_MAX = (long)RS_COOP_MAX_WG * RS1_T * RS_COOP_KEYS;   // 1
 __global__ __launch_bounds__(RS1_T) void rs_coop(const float* __restrict__ Z, long M, double alpha, unsigned k,
                                                  int var_is_max, float thr, int G, Workspace* __restrict__ ws,
                                                  double* __restrict__ out, const float* __restrict__ part, int nblocks,
-                                                 int ncols, double scale, double* __restrict__ sums_out, int companion) {
+                                                 int ncols, double scale, double* __restrict__ sums_out) {
   if ((int)blockIdx.x >= G) {   // the sample-mean second stage rides along (independent workgroups, no barriers)
     sum_partials_block(blockIdx.x - G, part, nblocks, ncols, scale, sums_out);
     return;
   }
   __shared__ unsigned h[B1];
   __shared__ double red[6 * (RS1_T / RATO_WAVE)];
-  rs_coop_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, G, ws, out, (int)blockIdx.x, companion, h, red);   // rato_select.h
+  rs_coop_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, G, ws, out, (int)blockIdx.x, 0, h, red);   // rato_select.h (stand-alone)
 }
 
 // one workgroup: zero the whole workspace, then tag it
@@ -406,7 +406,7 @@ extern "C" size_t rato_risk_stats_workspace_bytes(int64_t M) {
 namespace {
 int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* workspace, size_t workspace_bytes,
                     double* out, const float* part, int32_t nblocks, int32_t ncols, double scale, double* sums_out,
-                    void* stream, bool recover = false, bool companion = false) {
+                    void* stream, bool recover = false) {
   RATO_CLEAR_ERROR();
   if (!Z || !out || !workspace || M <= 0 || M >= (int64_t)0xffffffffLL || !(alpha > 0.0) || !(alpha <= 1.0))
     return RATO_EINVAL;
@@ -430,7 +430,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
   static const int force_coop = [] { const char* e = getenv("RATO_RS_PATH"); return (e && e[0] == 'c') ? 1 : 0; }();
   if (M <= RS_SMALL_MAX && !force_multi && !force_coop) {   // ONE launch, one workgroup (+ the partial-sum workgroups), keys in LDS
     hipLaunchKernelGGL(rs_small, dim3(1 + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr, out,
-                       part, (int)nblocks, (int)ncols, scale, sums_out, companion ? ws->sig : (unsigned*)nullptr);
+                       part, (int)nblocks, (int)ncols, scale, sums_out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }
@@ -441,7 +441,7 @@ int risk_stats_impl(const float* Z, int64_t M, double alpha, float thr, void* wo
     long G = (M + RS1_T * kpt - 1) / (RS1_T * kpt);
     if (G > RS_COOP_MAX_WG) G = RS_COOP_MAX_WG;
     hipLaunchKernelGGL(rs_coop, dim3((unsigned)G + sp_blocks), dim3(RS1_T), 0, st, Z, (long)M, alpha, k, var_is_max, thr,
-                       (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out, companion ? 1 : 0);
+                       (int)G, ws, out, part, (int)nblocks, (int)ncols, scale, sums_out);
     RATO_LAUNCH_CHECK();
     return RATO_OK;
   }

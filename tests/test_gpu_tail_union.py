@@ -14,7 +14,7 @@ def _us(S, k):
 
 
 @pytest.mark.parametrize("M,S,K,alpha", [(10007, 20, 5, 0.1), (100000, 50, 9, 0.1), (3000, 12, 2, 0.3), (60000, 30, 21, 0.05),
-                                          (700, 20, 3, 1.0)])
+                                          (700, 20, 3, 1.0), (500, 80, 3, 0.1), (300, 66, 2, 0.2), (300, 65, 2, 0.2)])
 def test_union_form_equals_one_launch_per_cut(M, S, K, alpha):
     import torch
     from riskaversetrajopt_amd import _lib, drone_risk, drone_utils, stats
