@@ -660,6 +660,11 @@ def scp_block(work, args):
             "iteration_median_s": float(np.median(out["define_s"] + out["solve_s"])),
             "cumulative_s": float(out["cumulative_s"][-1]), "wall_s": wall,
             "cuts_median": float(np.median(out["cuts"])), "cuts_max": int(out["cuts"].max()),
+            "cuts_total": int(out["cuts"].sum()),
+            # where the cumulative time goes: the subproblems' definitions (linearization + sums + kept cuts), the oracle
+            # round trips of the cutting-plane loops (device work + launch / synchronisation latency), the host master QPs
+            "split_s": {"define": float(np.sum(out["define_s"])), "oracle_round_trips": float(np.sum(out["oracle_s"])),
+                        "master": float(np.sum(out["solve_s"]) - np.sum(out["oracle_s"]))},
             "L2_error_last": float(out["L2_error"][-1]),
             "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
 
