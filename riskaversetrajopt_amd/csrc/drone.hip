@@ -166,6 +166,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
 // TABLES: W and g_up are written (the table forms of the cut oracle); WANT_Z: Z is.  A reduced SCP iteration whose oracle
 // re-runs the rollout (the benchmarked configuration) needs neither -- only the sample sums of the final rows -- and then
 // neither the tangent of the linearized dynamics nor any obstacle row is formed: <false, false> is a third of the work.
+#ifndef RATO_GEN_LDS_REDUCE
+#define RATO_GEN_LDS_REDUCE 1   // A/B: 0 = six fp64 DPP trees per backward step
+#endif
 template <bool TABLES, bool WANT_Z>
 __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     rato_drone_params P, const float* __restrict__ us, const float* __restrict__ dW,
@@ -278,6 +281,26 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   // the table see the same numbers)
   extern __shared__ double gen_red[];   // [waves][S + 1][6]: per-wave sums, combined once after the sweep
   constexpr int NWV = RATO_BLOCK / RATO_WAVE;
+#if RATO_GEN_LDS_REDUCE
+  // The six sums over the wave's samples that every backward step needs used to be six fp64 DPP trees per step (76 DPP
+  // moves + 36 adds of the ~160 instructions of a step: the kernel is bound by instruction issue at M ~ 1e5).  Now the
+  // lanes park their six numbers of FOUR steps in a tile of LDS ([24 columns][64 lanes], rows padded to 65) and 48 lanes
+  // sum half a column each, serially: ~18 instructions per step instead of 112.  Fixed order: lanes 0..31, then 32..63.
+  double* const Tw = gen_red + (size_t)NWV * (S + 1) * 6 + (size_t)wave * (24 * 65);
+  auto flush_group = [&](int s_first) {   // the columns of steps s_first, s_first - 1, s_first - 2, s_first - 3
+    const int col = lane % 24, half = lane / 24;
+    const int j = col / 6, e = col - j * 6;
+    const int s2c = s_first - j;
+    double psum = 0.0;
+    if (lane < 48 && s2c >= 0) {
+      const double* src = Tw + col * 65 + half * 32;
+#pragma unroll 8
+      for (int l = 0; l < 32; ++l) psum += src[l];
+    }
+    const double other = __shfl_down(psum, 24, RATO_WAVE);
+    if (lane < 24 && s2c >= 0) gen_red[(wave * (S + 1) + s2c) * 6 + e] = psum + other;
+  };
+#endif
   double mP0[3], mP1[3], mV0[3], mV1[3], dP[3], dV[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -305,6 +328,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       dP[a] += eP[a] * ua;
       dV[a] += eV[a] * ua;
     }
+#if RATO_GEN_LDS_REDUCE
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Tw[((i & 3) * 6 + a) * 65 + lane] = valid ? eP[a] : 0.0;
+      Tw[((i & 3) * 6 + 3 + a) * 65 + lane] = valid ? eV[a] : 0.0;
+    }
+#else
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double sp = rato::wave_sum_dpp(valid ? eP[a] : 0.0);
@@ -314,6 +344,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
         gen_red[(wave * (S + 1) + s2) * 6 + 3 + a] = sv;
       }
     }
+#endif
     if (s2 > 0) {  // mu_s = mu_{s+1} A_s
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -324,6 +355,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       }
     }
     }
+#if RATO_GEN_LDS_REDUCE
+    if ((i & 3) == 3 && sb - (i - 3) >= 0) flush_group(sb - (i - 3));   // (wave-uniform)
+#endif
     }   // step s2 of the batch
   };
   {
@@ -1178,8 +1212,21 @@ extern "C" int rato_drone_linearize_generators(const rato_drone_params* p, const
   // W and g_up may BOTH be NULL: only A22 (the lane's own scratch for the backward pass), Z and the sample sums
   if (!params_ok(p) || !params64_ok(p) || !us || !dW || !mass || !Qsym || !A22 || (!W != !g_up) || !part) return RATO_EINVAL;
   dim3 grid(rato::nblocks_for(p->M)), block(RATO_BLOCK);
-  const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * (p->S + 1) * 6 * sizeof(double);
-  if (lds > 64 * 1024) return RATO_EINVAL;   // S <= 340
+  const size_t lds = (size_t)(RATO_BLOCK / RATO_WAVE) * ((size_t)(p->S + 1) * 6 + (RATO_GEN_LDS_REDUCE ? 24 * 65 : 0)) * sizeof(double);
+  if (lds > 160 * 1024) return RATO_EINVAL;   // S <= 570
+  static rato::DynamicLdsLimit gen_lds_limit;
+  {
+    const hipError_t e = gen_lds_limit.ensure(lds, [](size_t bytes) {
+      const void* kernels[3] = {reinterpret_cast<const void*>(drone_linearize_generators_kernel<true, true>),
+                                reinterpret_cast<const void*>(drone_linearize_generators_kernel<false, true>),
+                                reinterpret_cast<const void*>(drone_linearize_generators_kernel<false, false>)};
+      hipError_t err = hipSuccess;
+      for (int i = 0; i < 3 && err == hipSuccess; ++i)
+        err = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      return err;
+    });
+    if (e != hipSuccess) return RATO_EHIP - (int)e;
+  }
   if (W)
     hipLaunchKernelGGL((drone_linearize_generators_kernel<true, true>), grid, block, lds, rato::as_stream(stream), *p, us,
                        dW, mass, Qsym, A22, W, g_up, Z, part);
