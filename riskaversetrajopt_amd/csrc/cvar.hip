@@ -600,6 +600,7 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
       a21 = -kp * dt * inv_m;
       dtm = dt * inv_m;
       const double cn = sqrt(dt) * P.beta64 * inv_m;
+      const double c1 = dt * kd * inv_m, one_c1 = 1.0 - c1, c2 = dt * drag * inv_m, c22 = 2.0 * c2;
       double p = P.x_init64[a], v = P.x_init64[3 + a];
       constexpr int TB = 8;   // noise in batches of 8 steps, the next batch in flight while one is consumed
       auto load = [&](float (&xi)[TB], int tb) {
@@ -614,12 +615,13 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
         for (int i = 0; i < TB; ++i) {
           const int t = tb + i;
           if (t <= t_hi) {
-            const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v)) * inv_m);
-            E[(t * 2 + a) * RATO_WAVE + lane] = e22;
-            const double u = uk[t * 3 + a];
-            const double ac = (u - (kp * p + kd * v)) * inv_m - drag * fabs(v) * v * inv_m;
-            const double pn = p + dt * v;
-            v = v + dt * ac + cn * (double)xi[i];
+            // the step of drone_rowmax_rollout_kernel, operation for operation (same trajectory, bit for bit: the row the
+            // cut is built from is evaluated where the maximum was found); 8 fp64 operations, 3 of them in the chain
+            const double av = fabs(v);
+            E[(t * 2 + a) * RATO_WAVE + lane] = (float)fma(c22, av, c1);      // e22 = dt (kd + 2 drag |v|) / m
+            const double tv = fma(a21, p, fma(dtm, uk[t * 3 + a], cn * (double)xi[i]));
+            const double pn = fma(dt, v, p);
+            v = fma(fma(-c2, av, one_c1), v, tv);
             p = pn;
             if (on && t == ts) s_pt[a][lane] = p;   // the arg-max row of this sample is evaluated at p_{t*+1}
           }
@@ -805,6 +807,7 @@ __global__ __launch_bounds__(TRU_NW* RATO_WAVE) void drone_tail_rows_rollout_uni
     if (wave == 0) {
       // ---- forward: the rollout of the chunk at u_k, once for all cuts
       const double cn = sqrt(dt) * P.beta64 * inv_m;
+      const double c1 = dt * kd * inv_m, one_c1 = 1.0 - c1, c2 = dt * drag * inv_m, c22 = 2.0 * c2;
       int t_hi = 0;   // wave-uniform: the largest t* of any (cut, lane) of the chunk
       {
         int tm = 0;
@@ -831,12 +834,11 @@ __global__ __launch_bounds__(TRU_NW* RATO_WAVE) void drone_tail_rows_rollout_uni
           if (t <= t_hi) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-              const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
-              E[(t * 2 + a) * RATO_WAVE + lane] = e22;
-              const double u = uk[t * 3 + a];
-              const double ac = (u - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
-              const double pn = p[a] + dt * v[a];
-              v[a] = v[a] + dt * ac + cn * (double)xi[i][a];
+              const double av = fabs(v[a]);   // (the step of drone_rowmax_rollout_kernel, operation for operation)
+              E[(t * 2 + a) * RATO_WAVE + lane] = (float)fma(c22, av, c1);
+              const double tv = fma(a21, p[a], fma(dtm, uk[t * 3 + a], cn * (double)xi[i][a]));
+              const double pn = fma(dt, v[a], p[a]);
+              v[a] = fma(fma(-c2, av, one_c1), v[a], tv);
               p[a] = pn;
             }
             unsigned mask = __builtin_amdgcn_readfirstlane(TMASK[t]);

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   const double inv_m = 1.0 / (double)mass[m];
   const double a21 = -kp * dt * inv_m, dtm = dt * inv_m;
   const double cn = sqrt(dt) * P.beta64 * inv_m;   // sqrt(dt) * (beta/m): drone_risk.py:136,151
+  const double c1 = dt * kd * inv_m, one_c1 = 1.0 - c1, c2 = dt * drag * inv_m, c22 = 2.0 * c2;
   double q00[NOBS], qs[NOBS], q11[NOBS];
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       // A_t[1,1] = 1 - e22 at the state BEFORE the step.  The table stores e22 = dt (k_d + 2 c_d |v|) / m ~ 1e-3, not a22
       // itself: rounded to fp32 it is exact to 1e-10 of a22, where a22 ~ 1 would carry 6e-8 -- and a row of Phi is a
       // product of up to S of them.  The consumers rebuild a22 = 1 - e22 in fp64 from the SAME fp32 number.
-      const float e22 = (float)(dt * (kd + 2.0 * drag * fabs(v[a])) * inv_m);
+      const float e22 = (float)fma(c22, fabs(v[a]), c1);   // dt (kd + 2 drag |v|) / m
       a22[a] = 1.0 - (double)e22;
       if (valid) A22[((size_t)t * 3 + a) * ld + m] = e22;
     }
@@ -241,10 +242,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {   // one Euler-Maruyama step of one axis (drone_risk.py:122-131,148-153)
-      const double acc = ((double)us[t * 3 + a] - (kp * p[a] + kd * v[a])) * inv_m - drag * fabs(v[a]) * v[a] * inv_m;
-      const double pn = p[a] + dt * v[a];
-      v[a] = v[a] + dt * acc + cn * (double)xi[a];
+    for (int a = 0; a < 3; ++a) {   // one Euler-Maruyama step of one axis (drone_risk.py:122-131,148-153), multiplied out
+      // as in the cut oracle's rollout kernels (cvar.hip): v' = ((1 - c1) - c2 |v|) v + (dt/m) u - (kp dt/m) p + cn xi
+      const double av = fabs(v[a]);
+      const double tv = fma(a21, p[a], fma(dtm, (double)us[t * 3 + a], cn * (double)xi[a]));
+      const double pn = fma(dt, v[a], p[a]);
+      v[a] = fma(fma(-c2, av, one_c1), v[a], tv);
       p[a] = pn;
     }
     if (TABLES || WANT_Z) {
