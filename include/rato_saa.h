@@ -90,7 +90,7 @@ extern "C" {
  * params.stats_* -- the statistics of Z in extra workgroups of the row-parallel linearize launch itself)
  * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 9
+#define RATO_ABI_VERSION 10
 int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
@@ -636,6 +636,20 @@ int rato_car_eval_philox(const rato_car_params* p, const float* us, uint64_t see
 int rato_car_linearize_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,
                               const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch,
                               float* G, float* g_up, float* Z, float* final_du, float* final_rhs, void* stream);
+
+/* The row-parallel driving kernel reads a tile's noise -- 2S rows of 64 samples -- while the tiles of other workgroups are
+ * being stored; as 2S rows of 256 B that lie M floats apart these reads cost the launch 6-11 % (5 % more bytes; reads and
+ * writes share the HBM bus), as ONE contiguous block per tile a third less.  A batch that is linearized
+ * again and again (every SCP iteration) is therefore re-tiled ONCE:
+ *   rato_car_tiled_noise_floats(M, S)           floats of the tiled copy: ceil(M / 64) * 2S * 64
+ *   rato_car_tile_noise(dW, M, S, dW_tiled)     dW [S][2][M] -> dW_tiled [ceil(M/64)][2S][64] (lanes beyond M: 0)
+ *   rato_car_linearize_tiled(...)               rato_car_linearize(cols_per_thread = -1) reading dW_tiled: the same
+ *                                               outputs, bit for bit */
+size_t rato_car_tiled_noise_floats(int64_t M, int32_t S);
+int rato_car_tile_noise(const float* dW, int64_t M, int32_t S, float* dW_tiled, void* stream);
+int rato_car_linearize_tiled(const rato_car_params* p, const float* us, const float* dW_tiled, const float* x0_ped,
+                             const float* w_speed, const float* w_rep, float* ego_scratch, float* G, float* g_up, float* Z,
+                             float* final_du, float* final_rhs, void* stream);
 
 /* hopper.py:70-74: a = 0.025 sqrt(2/30) U(0,1), theta = pi U(0,1), tau = 2 pi U(0,1), each [30][M]. */
 int rato_hopper_sample(int64_t M, uint64_t seed, float* a, float* theta, float* tau, void* stream);

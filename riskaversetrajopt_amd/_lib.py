@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 9              # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 10             # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -148,6 +148,9 @@ SIGNATURES = {
                         [C.POINTER(C.c_float), C.POINTER(C.c_float)] + [c_float_p] * 4 + [c_stream]),
     "rato_car_linearize_philox": (C.c_int, [C.POINTER(CarParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 9
                                   + [c_stream]),
+    "rato_car_tiled_noise_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "rato_car_tile_noise": (C.c_int, [c_float_p, C.c_int64, C.c_int32, c_float_p, c_stream]),
+    "rato_car_linearize_tiled": (C.c_int, [C.POINTER(CarParams)] + [c_float_p] * 11 + [c_stream]),
     "rato_car_eval_philox": (C.c_int, [C.POINTER(CarParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 7 +
                              [c_stream]),
     "rato_hopper_sample": (C.c_int, [C.c_int64, C.c_uint64, c_float_p, c_float_p, c_float_p, c_stream]),

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
     float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole,
-    const rato_sel::StatsTail tail) {
+    const rato_sel::StatsTail tail, int noise_tiled) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
@@ -438,12 +438,16 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
   bool first_unit = true;   // (scalar) the first unit's noise is requested here, in front of the ego tables
   if ((!LOOP || RATO_CRAMP) && !PHILOX) {
-    const size_t mr = (size_t)((LOOP && pbid < n_whole) ? pbid : (LOOP ? n_whole + (pbid - n_whole) / split : pbid / split)) * CROWS_SAMPLES + lane;
+    const size_t tile0 = (size_t)((LOOP && pbid < n_whole) ? pbid : (LOOP ? n_whole + (pbid - n_whole) / split : pbid / split));
+    const size_t mr = tile0 * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
       const int r = wave + i * CROWS_NW;
-      tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + mm];
+      const int rr = (r < nrows) ? r : 0;
+      // noise_tiled: dW is [tile][2S][64] (rato_car_tile_noise) -- a tile's 2S rows are ONE contiguous block instead of
+      // 2S rows of 256 B that lie M floats apart (reads beside the store stream: DESIGN.md 4.2)
+      tmp0[i] = noise_tiled ? dW[(tile0 * nrows + rr) * CROWS_SAMPLES + lane] : dW[(size_t)rr * M + mm];
     }
   }
   for (int t = threadIdx.x; t < S; t += NT) {
@@ -571,7 +575,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = wave + i * CROWS_NW;
-        tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
+        const int rr = (r < nrows) ? r : 0;
+        tmp0[i] = noise_tiled ? dW[((size_t)tile * nrows + rr) * CROWS_SAMPLES + lane] : dW[(size_t)rr * M + m];
       }
     }
     first_unit = false;
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = r0 + i * CROWS_NW;
-        tmp[i] = (r < nrows) ? dW[(size_t)r * M + m] : 0.0f;
+        tmp[i] = (r < nrows) ? (noise_tiled ? dW[((size_t)tile * nrows + r) * CROWS_SAMPLES + lane] : dW[(size_t)r * M + m]) : 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -937,7 +942,7 @@ namespace {
 int car_linearize_impl(const rato_car_params* p, const float* us, const float* dW, uint64_t seed, float noise_scale,
                        const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch, float* G,
                        float* g_up, float* Z, float* final_du, float* final_rhs, int32_t cols_per_thread,
-                       void* stream) {
+                       void* stream, int noise_tiled = 0) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !x0_ped || !w_speed || !w_rep || !ego_scratch || !G || !g_up)
     return RATO_EINVAL;
@@ -945,6 +950,7 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
   int32_t spt = cols_per_thread, tile = 0;
   if (rato_car_linearize_plan(p->M, p->S, &spt, &tile) < 0) return RATO_EINVAL;
   if (!dW && spt != -1) return RATO_EINVAL;
+  if (noise_tiled && (spt != -1 || !dW)) return RATO_EINVAL;   // the tiled noise layout: row-parallel kernel only
   if (p->stats_workspace && (spt != -1 || !Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0)))
     return RATO_EINVAL;   // statistics in the same launch: row-parallel kernel, Z requested
   // the ego prologue (trajectory + per-step tangents Epos, Eu) serves the forward/column kernel; the row-parallel
@@ -1038,17 +1044,17 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
       if (dW)
         hipLaunchKernelGGL((car_linearize_rows_kernel<true, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, noise_tiled);
       else
         hipLaunchKernelGGL((car_linearize_rows_kernel<true, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, noise_tiled);
     } else {
       if (dW)
         hipLaunchKernelGGL((car_linearize_rows_kernel<false, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, noise_tiled);
       else
         hipLaunchKernelGGL((car_linearize_rows_kernel<false, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, noise_tiled);
     }
     RATO_LAUNCH_CHECK();
     if (stats_behind)
@@ -1085,6 +1091,41 @@ extern "C" int rato_car_linearize_philox(const rato_car_params* p, const float* 
 
 // Would rato_car_linearize (row-parallel kernel) with params.stats_* compute the statistics IN its launch?  (see
 // rato_drone_stats_in_launch)  1 yes, 0 no.
+namespace {
+__global__ __launch_bounds__(RATO_BLOCK) void car_tile_noise_kernel(const float* __restrict__ dW, long M, int nrows,
+                                                                   float* __restrict__ out) {
+  const long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;        // over [tile][row][lane]
+  const long n_tiles = (M + CROWS_SAMPLES - 1) / CROWS_SAMPLES;
+  if (i >= n_tiles * nrows * CROWS_SAMPLES) return;
+  const int lane = (int)(i % CROWS_SAMPLES);
+  const long tr = i / CROWS_SAMPLES;
+  const int r = (int)(tr % nrows);
+  const long m = (tr / nrows) * CROWS_SAMPLES + lane;
+  out[i] = (m < M) ? dW[(size_t)r * M + m] : 0.0f;
+}
+}  // namespace
+
+extern "C" size_t rato_car_tiled_noise_floats(int64_t M, int32_t S) {
+  return (M > 0 && S > 0) ? (size_t)((M + CROWS_SAMPLES - 1) / CROWS_SAMPLES) * (size_t)(2 * S) * CROWS_SAMPLES : 0;
+}
+
+extern "C" int rato_car_tile_noise(const float* dW, int64_t M, int32_t S, float* dW_tiled, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!dW || !dW_tiled || M <= 0 || S <= 0) return RATO_EINVAL;
+  const size_t n = rato_car_tiled_noise_floats(M, S);
+  hipLaunchKernelGGL(car_tile_noise_kernel, dim3((unsigned)((n + RATO_BLOCK - 1) / RATO_BLOCK)), dim3(RATO_BLOCK), 0,
+                     rato::as_stream(stream), dW, (long)M, 2 * S, dW_tiled);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_car_linearize_tiled(const rato_car_params* p, const float* us, const float* dW_tiled,
+                                        const float* x0_ped, const float* w_speed, const float* w_rep, float* ego_scratch,
+                                        float* G, float* g_up, float* Z, float* final_du, float* final_rhs, void* stream) {
+  return car_linearize_impl(p, us, dW_tiled, 0, 0.0f, x0_ped, w_speed, w_rep, ego_scratch, G, g_up, Z, final_du, final_rhs,
+                            -1, stream, 1);
+}
+
 extern "C" int rato_car_stats_in_launch(int32_t M, int32_t S) {
   if (M <= 0 || S < 2 || car_rows_lds_bytes(S) > CAR_ROWS_LDS_MAX) return 0;
   int per_cu = (int)(CAR_ROWS_LDS_MAX / car_rows_lds_bytes(S));

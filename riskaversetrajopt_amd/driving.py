@@ -218,6 +218,20 @@ class Model:
         return -g.t().double().cpu().numpy()
 
     # ---- linearization (K4) ------------------------------------------------
+    TILED_NOISE = True        # (class-level switch for A/B runs and the equality test)
+
+    def _tiled_noise(self, dW, M):
+        """the [tile][2S][64] copy of ``dW`` the row-parallel kernel reads: made once per noise array, kept with it"""
+        c = getattr(self, "_dW_tiled_cache", None)
+        if c is None or c[0] != dW.data_ptr() or c[1] != dW._version or c[2].device != dW.device:
+            n = int(self._lib.rato_car_tiled_noise_floats(M, self.S))
+            t = torch.empty(n, dtype=torch.float32, device=dW.device)
+            _lib.check(self._lib.rato_car_tile_noise(_lib.ptr(dW), M, self.S, _lib.ptr(t), _lib.current_stream()),
+                       "rato_car_tile_noise")
+            c = (dW.data_ptr(), dW._version, t)
+            self._dW_tiled_cache = c
+        return c[2]
+
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True, rows_out=0, stats_request=None):
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
         (device, fp32; final_* are sample-independent, i.e. already the mean)."""
@@ -256,6 +270,13 @@ class Model:
                 C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
                 _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
                 _lib.ptr(final_rhs), _lib.current_stream()), "rato_car_linearize_philox")
+        elif cols_per_thread == -1 and self.TILED_NOISE:
+            # the row-parallel kernel reads the batch's noise re-tiled ONCE ([tile][2S][64]: a tile's noise is one block
+            # instead of 2S rows M floats apart -- reads beside the store stream); same outputs bit for bit
+            _lib.check(self._lib.rato_car_linearize_tiled(
+                C.byref(p), _lib.ptr(us), _lib.ptr(self._tiled_noise(dW, M)), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
+                _lib.ptr(final_rhs), _lib.current_stream()), "rato_car_linearize_tiled")
         else:
             _lib.check(self._lib.rato_car_linearize(
                 C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),

@@ -287,3 +287,32 @@ def test_ragged_last_tile_at_the_C5_shard_size():
     again = d.linearize_device(us)                     # (lanes >= M of the last tile are not written: compare the samples)
     assert bool((untile(again["G"], M) == Gp).all()) and bool((again["Z"] == r["Z"]).all())
     assert bool((again["g_up"] == r["g_up"]).all())
+
+
+@pytest.mark.parametrize("M,S", [(300, 20), (10000, 40), (125001, 40), (70000, 90)])
+def test_tiled_noise_gives_the_same_linearization_bit_for_bit(M, S):
+    """rato_car_linearize_tiled (the noise re-tiled once per batch: one contiguous block per tile of 64 samples) against
+    rato_car_linearize on the [S][2][M] array: every output identical (static grid, split tiles, tile queue, long horizon)."""
+    import torch
+    from riskaversetrajopt_amd import driving
+    dW, x0, ws_, wr = driving.sample_uncertain_parameters_device(M, S, seed=4)
+    d = driving.Model.from_device(S, dW, x0, ws_, wr, 'saa', 0.05)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * (20.0 / S)
+    assert driving.Model.TILED_NOISE
+    a = d.linearize_device(us)
+    try:
+        driving.Model.TILED_NOISE = False
+        b = d.linearize_device(us)
+    finally:
+        driving.Model.TILED_NOISE = True
+    torch.cuda.synchronize()
+    assert a["cols_per_thread"] == b["cols_per_thread"] == -1
+    for k in ("g_up", "Z", "final_du", "final_rhs"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(driving.untile(a["G"], M), driving.untile(b["G"], M))
+    # the tiled copy follows the noise array: a new batch in the same Model is re-tiled
+    dW2 = dW * 1.5
+    d2 = driving.Model.from_device(S, dW2, x0, ws_, wr, 'saa', 0.05)
+    c = d2.linearize_device(us)
+    assert not torch.equal(c["Z"], a["Z"])
