@@ -623,6 +623,20 @@ int rato_drone_linearize_philox(const rato_drone_params* p, const float* us, uin
                                 const float* mass, const float* Qsym, float* G, float* W, float* A22, float* g_up,
                                 float* Z, float* part, void* stream);
 
+/* The row-parallel kernels read a tile's noise while the tiles of other workgroups are being stored, and reads beside a
+ * saturated store stream cost more than their bytes (the noise regenerated in the kernel: -7 % at the metric
+ * configuration).  A batch that is linearized again and again is re-tiled ONCE, so that a tile's 3S rows are one
+ * contiguous block instead of 3S rows of 256 B that lie ld floats apart:
+ *   rato_drone_tiled_noise_floats(M, S)              floats of the tiled copy: ceil(M / 64) * 3S * 64
+ *   rato_drone_tile_noise(dW, M, ld, S, dW_tiled)    dW [S][3][ld] -> dW_tiled [ceil(M/64)][3S][64] (lanes beyond M: 0)
+ *   rato_drone_linearize_tiled(...)                  rato_drone_linearize(cols_per_thread = -1) reading dW_tiled: the
+ *                                                    same outputs, bit for bit (see also rato_car_linearize_tiled) */
+size_t rato_drone_tiled_noise_floats(int64_t M, int32_t S);
+int rato_drone_tile_noise(const float* dW, int64_t M, int64_t ld, int32_t S, float* dW_tiled, void* stream);
+int rato_drone_linearize_tiled(const rato_drone_params* p, const float* us, const float* dW_tiled, const float* mass,
+                               const float* Qsym, float* G, float* W, float* A22, float* g_up, float* Z, float* part,
+                               void* stream);
+
 /* driving.py:84-120: dW [S][2][M], x0_ped [4][M] = x0_mean + x0_std * N(0,1) (HOST float[4] each), w_speed, w_rep [M]
  * ~ U(nom -+ del).  dW may be NULL; the three parameter arrays may all be NULL. */
 int rato_car_sample(int64_t M, int32_t S, float sampler_dt, uint64_t seed, float w_speed_nom, float w_speed_del,

@@ -142,6 +142,9 @@ SIGNATURES = {
                                     C.POINTER(C.c_float), C.c_float, c_float_p, c_float_p, c_float_p, c_stream]),
     "rato_drone_linearize_philox": (C.c_int, [C.POINTER(DroneParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 8
                                     + [c_stream]),
+    "rato_drone_tiled_noise_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "rato_drone_tile_noise": (C.c_int, [c_float_p, C.c_int64, C.c_int64, C.c_int32, c_float_p, c_stream]),
+    "rato_drone_linearize_tiled": (C.c_int, [C.POINTER(DroneParams)] + [c_float_p] * 10 + [c_stream]),
     "rato_drone_eval_philox": (C.c_int, [C.POINTER(DroneParams), c_float_p, C.c_uint64, C.c_float] + [c_float_p] * 5 +
                                [c_stream]),
     "rato_car_sample": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64] + [C.c_float] * 4 +

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     uint64_t seed, float noise_scale, const float* __restrict__ us, const float* __restrict__ dW,
     const float* __restrict__ mass, const float* __restrict__ Qsym, float* __restrict__ G,
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
-    float* __restrict__ part, const rato_sel::StatsTail tail) {
+    float* __restrict__ part, const rato_sel::StatsTail tail, int noise_tiled) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
@@ -842,7 +842,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 #if RATO_DIAG == 5   // diagnostic: no noise reads at all (a cheap hash instead): what do the reads cost beside the stores?
         tmp[i] = 0.01f * (float)((int)((r * 2654435761u + (unsigned)m * 40503u) >> 20) - 2048) * (1.0f / 2048.0f);
 #else
-        tmp[i] = (r < nrows) ? dW[(size_t)r * ld + m] : 0.0f;
+        // noise_tiled: dW is [tile][3S][64] (rato_drone_tile_noise) -- the tile's 3S rows are one contiguous block instead
+        // of 3S rows of 256 B that lie ld floats apart (reads beside the store stream cost more than their bytes)
+        tmp[i] = (r < nrows) ? (noise_tiled ? dW[((size_t)tile * nrows + r) * ROWS_SAMPLES + lane] : dW[(size_t)r * ld + m]) : 0.0f;
 #endif
       }
 #pragma unroll
@@ -1256,12 +1258,14 @@ namespace {
 // dW == NULL: the noise is regenerated from (seed, noise_scale) -- the row-parallel kernel only
 int drone_linearize_impl(const rato_drone_params* p, const float* us, const float* dW, uint64_t seed, float noise_scale,
                          const float* mass, const float* Qsym, float* G, float* W, float* A22, float* g_up, float* Z,
-                         float* part, int32_t cols_per_thread, int32_t samples_per_lane, void* stream) {
+                         float* part, int32_t cols_per_thread, int32_t samples_per_lane, void* stream,
+                         int noise_tiled = 0) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !mass || !Qsym || !G || !g_up || !part) return RATO_EINVAL;
   int32_t cpt = cols_per_thread, spl = samples_per_lane;
   if (!plan(p->M, p->S, p->ld, &cpt, &spl)) return RATO_EINVAL;
   if (!dW && cpt != -1) return RATO_EINVAL;
+  if (noise_tiled && (cpt != -1 || !dW)) return RATO_EINVAL;   // the tiled noise layout: row-parallel kernel only
   if (W && cpt != -1) return RATO_EINVAL;  // the factored output exists for the row-parallel kernel only
   if (p->stats_workspace && (cpt != -1 || !Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0)))
     return RATO_EINVAL;   // statistics in the same launch: row-parallel kernel, Z requested
@@ -1381,7 +1385,7 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
 #define RATO_ROWS_LAUNCH(F, PH)                                                                                     \
   hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid_launch), dim3(ROWS_NW * RATO_WAVE), lds_launch, st, \
                      *p, n_whole, split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, \
-                     Z, part, tail)
+                     Z, part, tail, noise_tiled)
     if (W) {
       if (dW) RATO_ROWS_LAUNCH(true, false); else RATO_ROWS_LAUNCH(true, true);
     } else {
@@ -1424,6 +1428,41 @@ extern "C" int rato_drone_linearize_philox(const rato_drone_params* p, const flo
   if (!(sampler_dt > 0.0f)) return RATO_EINVAL;
   return drone_linearize_impl(p, us, nullptr, seed, sqrtf(sampler_dt), mass, Qsym, G, W, A22, g_up, Z, part, -1, 0,
                               stream);
+}
+
+namespace {
+__global__ __launch_bounds__(RATO_BLOCK) void drone_tile_noise_kernel(const float* __restrict__ dW, long M, long ld, int nrows,
+                                                                     float* __restrict__ out) {
+  const long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;        // over [tile][row][lane]
+  const long n_tiles = (M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
+  if (i >= n_tiles * nrows * ROWS_SAMPLES) return;
+  const int lane = (int)(i % ROWS_SAMPLES);
+  const long tr = i / ROWS_SAMPLES;
+  const int r = (int)(tr % nrows);
+  const long m = (tr / nrows) * ROWS_SAMPLES + lane;
+  out[i] = (m < M) ? dW[(size_t)r * ld + m] : 0.0f;
+}
+}  // namespace
+
+extern "C" size_t rato_drone_tiled_noise_floats(int64_t M, int32_t S) {
+  return (M > 0 && S > 0) ? (size_t)((M + ROWS_SAMPLES - 1) / ROWS_SAMPLES) * (size_t)(3 * S) * ROWS_SAMPLES : 0;
+}
+
+extern "C" int rato_drone_tile_noise(const float* dW, int64_t M, int64_t ld, int32_t S, float* dW_tiled, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!dW || !dW_tiled || M <= 0 || ld < M || S <= 0) return RATO_EINVAL;
+  const size_t n = rato_drone_tiled_noise_floats(M, S);
+  hipLaunchKernelGGL(drone_tile_noise_kernel, dim3((unsigned)((n + RATO_BLOCK - 1) / RATO_BLOCK)), dim3(RATO_BLOCK), 0,
+                     rato::as_stream(stream), dW, (long)M, (long)ld, 3 * S, dW_tiled);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+
+extern "C" int rato_drone_linearize_tiled(const rato_drone_params* p, const float* us, const float* dW_tiled,
+                                          const float* mass, const float* Qsym, float* G, float* W, float* A22,
+                                          float* g_up, float* Z, float* part, void* stream) {
+  if (!dW_tiled) return RATO_EINVAL;
+  return drone_linearize_impl(p, us, dW_tiled, 0, 0.0f, mass, Qsym, G, W, A22, g_up, Z, part, -1, 0, stream, 1);
 }
 
 // Would rato_drone_linearize (row-parallel kernel) with params.stats_* compute the statistics IN its launch?  (Small

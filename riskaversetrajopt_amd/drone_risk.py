@@ -235,6 +235,20 @@ class Model:
                                  f"samples_per_lane={samples_per_lane}, ld={ld}")
         return nblk, cpt.value, spl.value, tile.value
 
+    TILED_NOISE = True        # (class-level switch for A/B runs and the equality test)
+
+    def _tiled_noise(self, dW, M, ld):
+        """the [tile][3S][64] copy of ``dW`` the row-parallel kernel reads: made once per noise array, kept with it"""
+        c = getattr(self, "_dW_tiled_cache", None)
+        if c is None or c[0] != dW.data_ptr() or c[1] != dW._version or c[2].device != dW.device or c[3] != (M, ld):
+            n = int(self._lib.rato_drone_tiled_noise_floats(M, self.S))
+            t = torch.empty(n, dtype=torch.float32, device=dW.device)
+            _lib.check(self._lib.rato_drone_tile_noise(_lib.ptr(dW), M, ld, self.S, _lib.ptr(t), _lib.current_stream()),
+                       "rato_drone_tile_noise")
+            c = (dW.data_ptr(), dW._version, t, (M, ld))
+            self._dW_tiled_cache = c
+        return c[2]
+
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
                          want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0, stats_request=None):
         """One SAA linearization pass on the device (drone_risk.py:239-296).
@@ -309,6 +323,13 @@ class Model:
                 C.byref(p), _lib.ptr(us), self._noise_seed, self._sampler_dt, _lib.ptr(mass), _lib.ptr(Qsym),
                 _lib.ptr(G), _lib.ptr(Wf), _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part),
                 _lib.current_stream()), "rato_drone_linearize_philox")
+        elif cpt == -1 and self.TILED_NOISE:
+            # the row-parallel kernel reads the batch's noise re-tiled ONCE ([tile][3S][64]: a tile's noise is one block
+            # instead of 3S rows ld floats apart -- reads beside the store stream cost more than their bytes); same outputs
+            _lib.check(self._lib.rato_drone_linearize_tiled(
+                C.byref(p), _lib.ptr(us), _lib.ptr(self._tiled_noise(dW, M, ld)), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
+                _lib.ptr(Wf), _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()),
+                "rato_drone_linearize_tiled")
         else:
             _lib.check(self._lib.rato_drone_linearize(
                 C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G), _lib.ptr(Wf),

@@ -355,3 +355,31 @@ def test_ragged_last_tile_at_the_C2_size():
     assert st["var"] == srt[M - int(np.floor(0.1 * M)) - 1] and st["max"] == srt[-1]
     again = d.linearize_device(us)                     # (lanes >= M of the last tile are not written: compare the samples)
     assert bool((d.packed_jacobian(again) == d.packed_jacobian(r)).all()) and bool((again["Z"][:M] == r["Z"][:M]).all())
+
+
+@pytest.mark.parametrize("M,S,factored", [(300, 20, False), (10007, 50, False), (100000, 50, True), (100000, 50, False), (5000, 126, False)])
+def test_tiled_noise_gives_the_same_linearization_bit_for_bit(M, S, factored):
+    """rato_drone_linearize_tiled (the noise re-tiled once per batch: one contiguous block per tile of 64 samples) against
+    rato_drone_linearize on the [S][3][ld] array: every output identical (static grid, split tiles, tile queue)."""
+    import torch
+    from riskaversetrajopt_amd import drone_risk, drone_utils
+    dW, mass, Q = drone_utils.sample_uncertain_parameters_device(M, S, seed=4)
+    d = drone_risk.Model.from_device(S, dW, mass, Q, 'saa', 0.1, M=M)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    assert drone_risk.Model.TILED_NOISE
+    a = d.linearize_device(us, factored=factored)
+    try:
+        drone_risk.Model.TILED_NOISE = False
+        b = d.linearize_device(us, factored=factored)
+    finally:
+        drone_risk.Model.TILED_NOISE = True
+    torch.cuda.synchronize()
+    for k in ("g_up", "Z", "sums", "part"):
+        assert torch.equal(a[k], b[k]), k
+    if factored:
+        assert torch.equal(a["W"], b["W"])
+    if M <= 10007:
+        assert torch.equal(drone_risk.untile(a["G"], M), drone_risk.untile(b["G"], M))
+    else:
+        assert torch.equal(a["G"][:3], b["G"][:3]) and torch.equal(a["G"][-2:-1], b["G"][-2:-1])
