@@ -628,7 +628,9 @@ int rato_drone_linearize_philox(const rato_drone_params* p, const float* us, uin
  * configuration).  A batch that is linearized again and again is re-tiled ONCE, so that a tile's 3S rows are one
  * contiguous block instead of 3S rows of 256 B that lie ld floats apart:
  *   rato_drone_tiled_noise_floats(M, S)              floats of the tiled copy: ceil(M / 64) * 3S * 64
- *   rato_drone_tile_noise(dW, M, ld, S, dW_tiled)    dW [S][3][ld] -> dW_tiled [ceil(M/64)][3S][64] (lanes beyond M: 0)
+ *   rato_drone_tile_noise(dW, M, ld, S, dW_tiled)    dW [S][3][ld] -> dW_tiled [ceil(M/64)] blocks of 3S * 64 floats, each the
+ *                                                    image the kernel keeps in LDS: [S][64] (xi_x, xi_y) pairs, then [S][64]
+ *                                                    xi_z (lanes beyond M: 0)
  *   rato_drone_linearize_tiled(...)                  rato_drone_linearize(cols_per_thread = -1) reading dW_tiled: the
  *                                                    same outputs, bit for bit (see also rato_car_linearize_tiled) */
 size_t rato_drone_tiled_noise_floats(int64_t M, int32_t S);

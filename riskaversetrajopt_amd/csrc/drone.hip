@@ -834,7 +834,29 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
         AZ[t * ROWS_SAMPLES + lane] = x2 * noise_scale;
       }
     }
-    for (int r0 = wave; !PHILOX && r0 < nrows; r0 += ROWS_NW * MAXR) {
+    if (!PHILOX && noise_tiled) {
+      // the tile's block IS the LDS image (PP: [S][64] (xi_x, xi_y) pairs, then AZ: [S][64] xi_z): a straight copy, 16 bytes
+      // per lane and request, every request of the thread in flight before the first one is stored
+      typedef float rfloat4_t __attribute__((ext_vector_type(4)));
+      const rfloat4_t* __restrict__ src4 = reinterpret_cast<const rfloat4_t*>(dW + (size_t)tile * nrows * ROWS_SAMPLES);
+      rfloat4_t* dst4 = reinterpret_cast<rfloat4_t*>(PPf);
+      const int n4 = nrows * (ROWS_SAMPLES / 4);
+      constexpr int MAX4 = 5, NT = ROWS_NW * RATO_WAVE;   // S = 50: 2400 requests over 512 threads
+      for (int b0 = threadIdx.x; b0 < n4; b0 += NT * MAX4) {
+        rfloat4_t tmp4[MAX4];
+#pragma unroll
+        for (int i = 0; i < MAX4; ++i) {
+          const int idx = b0 + i * NT;
+          tmp4[i] = src4[idx < n4 ? idx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < MAX4; ++i) {
+          const int idx = b0 + i * NT;
+          if (idx < n4) dst4[idx] = tmp4[i];
+        }
+      }
+    }
+    for (int r0 = wave; !PHILOX && !noise_tiled && r0 < nrows; r0 += ROWS_NW * MAXR) {
       float tmp[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -842,9 +864,7 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
 #if RATO_DIAG == 5   // diagnostic: no noise reads at all (a cheap hash instead): what do the reads cost beside the stores?
         tmp[i] = 0.01f * (float)((int)((r * 2654435761u + (unsigned)m * 40503u) >> 20) - 2048) * (1.0f / 2048.0f);
 #else
-        // noise_tiled: dW is [tile][3S][64] (rato_drone_tile_noise) -- the tile's 3S rows are one contiguous block instead
-        // of 3S rows of 256 B that lie ld floats apart (reads beside the store stream cost more than their bytes)
-        tmp[i] = (r < nrows) ? (noise_tiled ? dW[((size_t)tile * nrows + r) * ROWS_SAMPLES + lane] : dW[(size_t)r * ld + m]) : 0.0f;
+        tmp[i] = (r < nrows) ? dW[(size_t)r * ld + m] : 0.0f;
 #endif
       }
 #pragma unroll
@@ -1436,11 +1456,23 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tile_noise_kernel(const floa
   const long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;        // over [tile][row][lane]
   const long n_tiles = (M + ROWS_SAMPLES - 1) / ROWS_SAMPLES;
   if (i >= n_tiles * nrows * ROWS_SAMPLES) return;
-  const int lane = (int)(i % ROWS_SAMPLES);
-  const long tr = i / ROWS_SAMPLES;
-  const int r = (int)(tr % nrows);
-  const long m = (tr / nrows) * ROWS_SAMPLES + lane;
-  out[i] = (m < M) ? dW[(size_t)r * ld + m] : 0.0f;
+  // a tile's block is the image the row kernel keeps in LDS: [S][64] (xi_x, xi_y) pairs, then [S][64] xi_z
+  const int S = nrows / 3;
+  const long tile = i / ((long)nrows * ROWS_SAMPLES);
+  const int o = (int)(i - tile * (long)nrows * ROWS_SAMPLES);
+  int t, lane, a;
+  if (o < S * 2 * ROWS_SAMPLES) {
+    t = o / (2 * ROWS_SAMPLES);
+    lane = (o % (2 * ROWS_SAMPLES)) / 2;
+    a = o & 1;
+  } else {
+    const int o2 = o - S * 2 * ROWS_SAMPLES;
+    t = o2 / ROWS_SAMPLES;
+    lane = o2 % ROWS_SAMPLES;
+    a = 2;
+  }
+  const long m = tile * ROWS_SAMPLES + lane;
+  out[i] = (m < M) ? dW[(size_t)(t * 3 + a) * ld + m] : 0.0f;
 }
 }  // namespace
 
