@@ -658,7 +658,8 @@ int rato_car_linearize_philox(const rato_car_params* p, const float* us, uint64_
  * writes share the HBM bus), as ONE contiguous block per tile a third less.  A batch that is linearized
  * again and again (every SCP iteration) is therefore re-tiled ONCE:
  *   rato_car_tiled_noise_floats(M, S)           floats of the tiled copy: ceil(M / 64) * 2S * 64
- *   rato_car_tile_noise(dW, M, S, dW_tiled)     dW [S][2][M] -> dW_tiled [ceil(M/64)][2S][64] (lanes beyond M: 0)
+ *   rato_car_tile_noise(dW, M, S, dW_tiled)     dW [S][2][M] -> dW_tiled [ceil(M/64)] blocks of 2S * 64 floats, each the image
+ *                                               the kernel keeps in LDS: [S][64] (xi_0, xi_1) pairs (lanes beyond M: 0)
  *   rato_car_linearize_tiled(...)               rato_car_linearize(cols_per_thread = -1) reading dW_tiled: the same
  *                                               outputs, bit for bit */
 size_t rato_car_tiled_noise_floats(int64_t M, int32_t S);

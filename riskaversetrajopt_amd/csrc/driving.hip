@@ -436,18 +436,30 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
   constexpr int MAXR = 16;
   const int nrows = 2 * S;
   float tmp0[MAXR];   // batch 0 of the noise rows (S = 40: all 80 rows)
+  constexpr int MAX4 = 4;             // the tiled form: 16-byte requests per thread and batch (S <= 64: one batch)
+  cfloat4_t pre4[MAX4];
+  const int n4 = nrows * (CROWS_SAMPLES / 4);
   bool first_unit = true;   // (scalar) the first unit's noise is requested here, in front of the ego tables
   if ((!LOOP || RATO_CRAMP) && !PHILOX) {
     const size_t tile0 = (size_t)((LOOP && pbid < n_whole) ? pbid : (LOOP ? n_whole + (pbid - n_whole) / split : pbid / split));
     const size_t mr = tile0 * CROWS_SAMPLES + lane;
     const size_t mm = mr < M ? mr : M - 1;
+    if (noise_tiled) {
+      // noise_tiled: dW is [tile] blocks of 2S x 64 floats (rato_car_tile_noise), each the image this kernel keeps in LDS
+      // ([S][64] (xi_0, xi_1) pairs): ONE contiguous block per tile instead of 2S rows of 256 B that lie M floats apart
+      // (reads beside the store stream: DESIGN.md 4.2), staged as a straight 16-byte-per-lane copy
+      const cfloat4_t* __restrict__ src4 = reinterpret_cast<const cfloat4_t*>(dW + tile0 * nrows * CROWS_SAMPLES);
+#pragma unroll
+      for (int i = 0; i < MAX4; ++i) {
+        const int idx = (int)threadIdx.x + i * NT;
+        pre4[i] = src4[idx < n4 ? idx : 0];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
       const int r = wave + i * CROWS_NW;
-      const int rr = (r < nrows) ? r : 0;
-      // noise_tiled: dW is [tile][2S][64] (rato_car_tile_noise) -- a tile's 2S rows are ONE contiguous block instead of
-      // 2S rows of 256 B that lie M floats apart (reads beside the store stream: DESIGN.md 4.2)
-      tmp0[i] = noise_tiled ? dW[(tile0 * nrows + rr) * CROWS_SAMPLES + lane] : dW[(size_t)rr * M + mm];
+      tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + mm];
+    }
     }
   }
   for (int t = threadIdx.x; t < S; t += NT) {
@@ -571,28 +583,56 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         QPf[(t * CROWS_SAMPLES + lane) * 2 + 1] = x1 * noise_scale;
       }
     }
-    if (LOOP && !PHILOX && !(RATO_CRAMP && first_unit)) {
+    if (!PHILOX && noise_tiled) {
+      const cfloat4_t* __restrict__ src4 = reinterpret_cast<const cfloat4_t*>(dW + (size_t)tile * nrows * CROWS_SAMPLES);
+      cfloat4_t* dst4 = reinterpret_cast<cfloat4_t*>(QPf);
+      if (!((!LOOP || RATO_CRAMP) && first_unit)) {
+#pragma unroll
+        for (int i = 0; i < MAX4; ++i) {
+          const int idx = (int)threadIdx.x + i * NT;
+          pre4[i] = src4[idx < n4 ? idx : 0];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAX4; ++i) {
+        const int idx = (int)threadIdx.x + i * NT;
+        if (idx < n4) dst4[idx] = pre4[i];
+      }
+      for (int b0 = (int)threadIdx.x + MAX4 * NT; b0 < n4; b0 += MAX4 * NT) {   // long horizons: further batches
+        cfloat4_t t4[MAX4];
+#pragma unroll
+        for (int i = 0; i < MAX4; ++i) {
+          const int idx = b0 + i * NT;
+          t4[i] = src4[idx < n4 ? idx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < MAX4; ++i) {
+          const int idx = b0 + i * NT;
+          if (idx < n4) dst4[idx] = t4[i];
+        }
+      }
+    }
+    if (LOOP && !PHILOX && !noise_tiled && !(RATO_CRAMP && first_unit)) {
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = wave + i * CROWS_NW;
-        const int rr = (r < nrows) ? r : 0;
-        tmp0[i] = noise_tiled ? dW[((size_t)tile * nrows + rr) * CROWS_SAMPLES + lane] : dW[(size_t)rr * M + m];
+        tmp0[i] = dW[(size_t)((r < nrows) ? r : 0) * M + m];
       }
     }
     first_unit = false;
-    if (!PHILOX) {
+    if (!PHILOX && !noise_tiled) {
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = wave + i * CROWS_NW;
         if (r < nrows) QPf[((r >> 1) * CROWS_SAMPLES + lane) * 2 + (r & 1)] = tmp0[i];
       }
     }
-    for (int r0 = wave + CROWS_NW * MAXR; !PHILOX && r0 < nrows; r0 += CROWS_NW * MAXR) {   // long horizons: further batches
+    for (int r0 = wave + CROWS_NW * MAXR; !PHILOX && !noise_tiled && r0 < nrows; r0 += CROWS_NW * MAXR) {   // long horizons: further batches
       float tmp[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int r = r0 + i * CROWS_NW;
-        tmp[i] = (r < nrows) ? (noise_tiled ? dW[((size_t)tile * nrows + r) * CROWS_SAMPLES + lane] : dW[(size_t)r * M + m]) : 0.0f;
+        tmp[i] = (r < nrows) ? dW[(size_t)r * M + m] : 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
@@ -1097,11 +1137,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_tile_noise_kernel(const float*
   const long i = (long)blockIdx.x * RATO_BLOCK + threadIdx.x;        // over [tile][row][lane]
   const long n_tiles = (M + CROWS_SAMPLES - 1) / CROWS_SAMPLES;
   if (i >= n_tiles * nrows * CROWS_SAMPLES) return;
-  const int lane = (int)(i % CROWS_SAMPLES);
-  const long tr = i / CROWS_SAMPLES;
-  const int r = (int)(tr % nrows);
-  const long m = (tr / nrows) * CROWS_SAMPLES + lane;
-  out[i] = (m < M) ? dW[(size_t)r * M + m] : 0.0f;
+  // a tile's block is the image the row kernel keeps in LDS: [S][64] (xi_0, xi_1) pairs
+  const long tile = i / ((long)nrows * CROWS_SAMPLES);
+  const int o = (int)(i - tile * (long)nrows * CROWS_SAMPLES);
+  const int t = o / (2 * CROWS_SAMPLES), lane = (o % (2 * CROWS_SAMPLES)) / 2, a = o & 1;
+  const long m = tile * CROWS_SAMPLES + lane;
+  out[i] = (m < M) ? dW[(size_t)(t * 2 + a) * M + m] : 0.0f;
 }
 }  // namespace
 
