@@ -802,6 +802,9 @@ def main():
                                    f"M={M} samples/GPU x S={S} steps, alpha={args.alpha}"
                                    + (f", Jacobian written as {jacobian}" if jacobian else ""),
                        "baseline_config": args.config,
+                       "inputs": "resident in HBM before the timed region; the row-parallel drone / driving kernels read the "
+                                 "batch's noise from a copy re-tiled once per batch (rato_*_tile_noise: one contiguous block per "
+                                 "tile of 64 samples, the same numbers)",
                        "M_per_gpu": M, "S": S, "M_total": world * M,
                        "value_is_for": ("the SURVEY 8(d) contract: every structural nonzero of the Jacobian written "
                                         "(3S(S-1) numbers per sample)" if jacobian in ("products", "regenerated") else
