@@ -398,7 +398,7 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     const float* __restrict__ x0_ped, const float* __restrict__ w_speed, const float* __restrict__ w_rep,
     float* __restrict__ final_du, float* __restrict__ final_rhs, float* __restrict__ G, float* __restrict__ g_up,
     float* __restrict__ Z, int n_tiles_total, unsigned* __restrict__ tile_queue, int split, int n_whole,
-    const rato_sel::StatsTail tail, int noise_tiled) {
+    const rato_sel::StatsTail tail, int flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char car_lds_raw[];
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
@@ -408,6 +408,8 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     return;
   }
   const int pbid = (int)blockIdx.x;
+  const bool noise_tiled = (flags & 1) != 0;   // dW is the re-tiled copy (rato_car_tile_noise)
+  const bool nt_stores = (flags & 2) != 0;     // the Jacobian goes out as streaming (non-temporal) stores (see drone.hip)
   unsigned* const z_signal = tail.ws ? tail.ws->sig : nullptr;
   const size_t M = (size_t)P.M;
   const int S = P.S;
@@ -825,8 +827,13 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
         if (valid) {
 #endif
           float* __restrict__ o = Grow + (k - 1) * (2 * RT);
-          o[lane] = E2.x;
-          o[RT + lane] = E2.y;
+          if (nt_stores) {   // streaming: the Jacobian is never read back here; the memory-side cache keeps the batch's inputs
+            rato::store_streaming<0>(o + lane, E2.x);
+            rato::store_streaming<RT * 4>(o + lane, E2.y);
+          } else {
+            o[lane] = E2.x;
+            o[RT + lane] = E2.y;
+          }
         }
       }
       const float acc = acc2.x + acc2.y;
@@ -1069,6 +1076,12 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       if (lds_launch < rato_sel::rs_body_lds_bytes<CROWS_NW * RATO_WAVE>()) lds_launch = rato_sel::rs_body_lds_bytes<CROWS_NW * RATO_WAVE>();
     }
     dim3 grid(grid_launch), block(CROWS_NW * RATO_WAVE);
+    // streaming stores for the Jacobian when the output is far beyond the memory-side cache and the inputs fit (drone.hip):
+    // C5 shard (800 MB out, 40 MB in) -11.7 %; M = 1e6 (6.4 GB out, 320 MB in) ordinary stores (+2 % with streaming ones)
+    static const int nt_env = [] { const char* e = getenv("RATO_NT_STORES"); return e ? atoi(e) : 1; }();
+    const double out_bytes = (double)p->M * (double)rato::pair_row_offset(p->S) * 2.0 * 4.0;
+    const double in_bytes = (double)p->M * p->S * 2.0 * 4.0;
+    const bool nt_stores = nt_env == 2 || (nt_env == 1 && out_bytes >= 256e6 && in_bytes <= 128e6);
     if (queue) {
       // the last `tail_tiles` tiles of the queue as `tail_split` parts each (RATO_CAR_TAIL_SPLIT / RATO_CAR_TAIL_TILES).
       // OFF by default: unlike the drone's products output it does not pay here -- C5 shard (M = 125,000, 1954 tiles
@@ -1084,17 +1097,17 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
       const int n_whole = tail_split > 1 ? n_tiles - tail_tiles : n_tiles;
       if (dW)
         hipLaunchKernelGGL((car_linearize_rows_kernel<true, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, noise_tiled);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0));
       else
         hipLaunchKernelGGL((car_linearize_rows_kernel<true, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, noise_tiled);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, tail_split, n_whole, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0));
     } else {
       if (dW)
         hipLaunchKernelGGL((car_linearize_rows_kernel<false, false>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, noise_tiled);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0));
       else
         hipLaunchKernelGGL((car_linearize_rows_kernel<false, true>), grid, block, lds_launch, st, *p, seed, noise_scale, us,
-                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, noise_tiled);
+                           dW, x0_ped, w_speed, w_rep, final_du, final_rhs, G, g_up, Z, n_tiles, queue, split, 0, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0));
     }
     RATO_LAUNCH_CHECK();
     if (stats_behind)

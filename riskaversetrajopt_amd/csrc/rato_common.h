@@ -137,6 +137,15 @@ __host__ __device__ __forceinline__ size_t packed_tile_stride(size_t payload_flo
 // pair(t, s) = t(t-1)/2 + s for 0 <= s < t  (row-major causal packing)
 __host__ __device__ __forceinline__ int pair_row_offset(int t) { return (t * (t - 1)) >> 1; }
 
+// A streaming (non-temporal) 4-byte store at a constant byte offset from p.  As an instruction of its own: behind a
+// run-time flag the optimiser merges __builtin_nontemporal_store with the ordinary store of the other branch and drops the
+// hint.  (Used for write-once output streams far larger than the memory-side cache: drone.hip, driving.hip.)
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void store_streaming(float* p, float v) {
+  static_assert(BYTE_OFFSET >= 0 && BYTE_OFFSET < 4096, "immediate offset of a global store");
+  asm volatile("global_store_dword %0, %1, off offset:%2 nt" : : "v"(p), "v"(v), "n"(BYTE_OFFSET) : "memory");
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int nblocks_for(int32_t M) { return (M + RATO_BLOCK - 1) / RATO_BLOCK; }

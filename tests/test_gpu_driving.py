@@ -173,7 +173,10 @@ def test_C5_shard_size_properties():
     us = swerve(S)
     r = d.linearize_device(us)
     again = d.linearize_device(us)
-    assert bool((again["G"] == r["G"]).all()) and bool((again["g_up"] == r["g_up"]).all())   # run-to-run bitwise
+    # run-to-run bitwise (the lanes of the last tile beyond M are never written: two allocations need not agree there)
+    n_valid = M - (M // r["tile"]) * r["tile"]
+    assert torch.equal(again["G"][:-1], r["G"][:-1]) and torch.equal(again["G"][-1, ..., :n_valid], r["G"][-1, ..., :n_valid])
+    assert torch.equal(again["g_up"], r["g_up"])
     # linearity: g_up + g == G.u through the packed layout
     _, _, g = d.eval_device(us, want_g=True)
     Gp = untile(r["G"], M)
