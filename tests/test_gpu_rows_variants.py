@@ -101,3 +101,41 @@ def test_two_captured_graphs_replayed_concurrently_do_not_share_a_tile_queue():
     torch.cuda.synchronize()
     assert torch.equal(untile(r["G"], M), refs[0]["G"]) and torch.equal(untile(outs[1]["G"], M), refs[1]["G"])
 
+
+
+def test_streaming_stores_change_no_output(tmp_path):
+    """RATO_NT_STORES=2 (the Jacobian written with non-temporal stores at every size) against RATO_NT_STORES=0 (never): the
+    launcher's choice between the two is a matter of cache residency only -- every output must be bit for bit the same.
+    (The switch is read once per process: two child processes.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "nt_digest.py"
+    script.write_text(
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from riskaversetrajopt_amd import drone_risk, drone_utils, driving\n"
+        "h = hashlib.sha256()\n"
+        "for M, S, fact in ((10007, 50, False), (3000, 20, True)):\n"
+        "    dW, mass, Q = drone_utils.sample_uncertain_parameters_device(M, S, seed=9)\n"
+        "    d = drone_risk.Model.from_device(S, dW, mass, Q, 'saa', 0.1, M=M)\n"
+        "    t = np.arange(S)[:, None]\n"
+        "    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)\n"
+        "    r = d.linearize_device(us, factored=fact)\n"
+        "    for a in (drone_risk.untile(r['G'], M), r['g_up'], r['Z'], r['sums']):\n"
+        "        h.update(a.cpu().numpy().tobytes())\n"
+        "for M, S in ((10000, 40), (300, 20)):\n"
+        "    dW, x0, ws, wr = driving.sample_uncertain_parameters_device(M, S, seed=9)\n"
+        "    c = driving.Model.from_device(S, dW, x0, ws, wr, 'saa', 0.05)\n"
+        "    t = np.arange(S)[:, None]\n"
+        "    us = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * (20.0 / S)\n"
+        "    r = c.linearize_device(us)\n"
+        "    for a in (driving.untile(r['G'], M), r['g_up'], r['Z']):\n"
+        "        h.update(a.cpu().numpy().tobytes())\n"
+        "print(h.hexdigest())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    digests = []
+    for v in ("0", "2"):
+        env = dict(os.environ, RATO_NT_STORES=v)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] and len(digests[0]) == 64
