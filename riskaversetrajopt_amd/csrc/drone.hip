@@ -1380,7 +1380,8 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
           // 2e5 1.110 -> 1.102 / 1.050 -> 1.025, 1e6 5.425 -> 5.311 / 5.097 -> 5.025; at 5e4 +1.2 % / -1.2 %.
           // The factored output needs the second workgroup (its tiles are a third as long: 0.2455 -> 0.2648 ms).
           // RATO_ROWS_SLOTS_PER_CU overrides.
-          const int qslots = (!W && slots_env < 1 && n_tiles >= 1024) ? cus : slots;
+          static const int qslots_env = [] { const char* e = getenv("RATO_ROWS_QSLOTS"); return e ? atoi(e) : 0; }();   // A/B: absolute
+          const int qslots = qslots_env > 0 ? qslots_env : ((!W && slots_env < 1 && n_tiles >= 1024) ? cus : slots);
           grid = qslots;
           // Products output: the LAST slots/2 tiles are handed out as quarter tiles (4 row-interleaved parts each).
           // The drain at the end of the launch is bounded per workgroup (~19 GB/s each, whatever the residency), so
