@@ -221,16 +221,33 @@ class Model:
     TILED_NOISE = True        # (class-level switch for A/B runs and the equality test)
 
     def _tiled_noise(self, dW, M):
-        """the [tile][2S][64] copy of ``dW`` the row-parallel kernel reads: made once per noise array, kept with it"""
+        """The [tile][2S][64] copy of the MODEL'S OWN noise that the row-parallel kernel reads; made once, kept with
+        the source tensor itself (compared by identity, never by address).  A caller's ``inputs`` are not cached
+        (``None``: they go through the kernel that reads dW as it lies); an in-place refill of ``self._dW`` through raw
+        pointers needs ``set_noise`` / ``invalidate_noise``."""
+        if dW is not self._dW:
+            return None
         c = getattr(self, "_dW_tiled_cache", None)
-        if c is None or c[0] != dW.data_ptr() or c[1] != dW._version or c[2].device != dW.device:
+        if c is None or c[0] is not dW or c[1] != dW._version or c[3] != (M, self.S):
             n = int(self._lib.rato_car_tiled_noise_floats(M, self.S))
             t = torch.empty(n, dtype=torch.float32, device=dW.device)
             _lib.check(self._lib.rato_car_tile_noise(_lib.ptr(dW), M, self.S, _lib.ptr(t), _lib.current_stream()),
                        "rato_car_tile_noise")
-            c = (dW.data_ptr(), dW._version, t)
+            c = (dW, dW._version, t, (M, self.S))
             self._dW_tiled_cache = c
         return c[2]
+
+    def invalidate_noise(self):
+        """Forget every copy derived from ``self._dW`` (after an in-place refill of the noise array)."""
+        self._dW_tiled_cache = None
+
+    def set_noise(self, dW):
+        """Replace the batch's Brownian increments (kernel layout [S][2][M], fp32, on the model's device)."""
+        dW = _lib.require_f32_device(dW, "dW")
+        if tuple(dW.shape) != (self.S, 2, int(self._ws.numel())):
+            raise ValueError(f"dW must be ({self.S}, 2, {int(self._ws.numel())}), got {tuple(dW.shape)}")
+        self._dW = dW
+        self.invalidate_noise()
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, out=None, want_Z=True, rows_out=0, stats_request=None):
         """-> dict: G [n_tiles][n_pairs][2][TILE], g_up [S][M], Z [M], final_du [4][2S], final_rhs [4]
@@ -265,16 +282,17 @@ class Model:
         p.rows_out = int(rows_out)      # 1: g_up receives g itself (base of the cut oracle's delta form, cvar_cuts.py)
         if stats_request is not None:   # (workspace, out, alpha): the launch also computes the statistics of its Z
             stats.request_in_launch(p, *stats_request)
+        tiled = self._tiled_noise(dW, M) if (dW is not None and cols_per_thread == -1 and self.TILED_NOISE) else None
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
             _lib.check(self._lib.rato_car_linearize_philox(
                 C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
                 _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
                 _lib.ptr(final_rhs), _lib.current_stream()), "rato_car_linearize_philox")
-        elif cols_per_thread == -1 and self.TILED_NOISE:
+        elif cols_per_thread == -1 and self.TILED_NOISE and tiled is not None:
             # the row-parallel kernel reads the batch's noise re-tiled ONCE ([tile][2S][64]: a tile's noise is one block
             # instead of 2S rows M floats apart -- reads beside the store stream); same outputs bit for bit
             _lib.check(self._lib.rato_car_linearize_tiled(
-                C.byref(p), _lib.ptr(us), _lib.ptr(self._tiled_noise(dW, M)), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
+                C.byref(p), _lib.ptr(us), _lib.ptr(tiled), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
                 _lib.ptr(self._scratch), _lib.ptr(G), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(final_du),
                 _lib.ptr(final_rhs), _lib.current_stream()), "rato_car_linearize_tiled")
         else:

@@ -238,16 +238,34 @@ class Model:
     TILED_NOISE = True        # (class-level switch for A/B runs and the equality test)
 
     def _tiled_noise(self, dW, M, ld):
-        """the [tile][3S][64] copy of ``dW`` the row-parallel kernel reads: made once per noise array, kept with it"""
+        """The [tile][3S][64] copy of the MODEL'S OWN noise that the row-parallel kernel reads; made once, kept with
+        the source tensor itself (compared by identity: an address can be recycled by the allocator, a live tensor
+        cannot).  A caller's ``inputs`` are never cached -- ``None`` sends them through the kernel that reads dW as it
+        lies.  Whoever rewrites ``self._dW`` in place through raw pointers (the library's samplers do not bump a
+        tensor's version counter) must call ``set_noise`` / ``invalidate_noise``."""
+        if dW is not self._dW:
+            return None
         c = getattr(self, "_dW_tiled_cache", None)
-        if c is None or c[0] != dW.data_ptr() or c[1] != dW._version or c[2].device != dW.device or c[3] != (M, ld):
+        if c is None or c[0] is not dW or c[1] != dW._version or c[3] != (M, ld, self.S):
             n = int(self._lib.rato_drone_tiled_noise_floats(M, self.S))
             t = torch.empty(n, dtype=torch.float32, device=dW.device)
             _lib.check(self._lib.rato_drone_tile_noise(_lib.ptr(dW), M, ld, self.S, _lib.ptr(t), _lib.current_stream()),
                        "rato_drone_tile_noise")
-            c = (dW.data_ptr(), dW._version, t, (M, ld))
+            c = (dW, dW._version, t, (M, ld, self.S))
             self._dW_tiled_cache = c
         return c[2]
+
+    def invalidate_noise(self):
+        """Forget every copy derived from ``self._dW`` (after an in-place refill of the noise array)."""
+        self._dW_tiled_cache = None
+
+    def set_noise(self, dW):
+        """Replace the batch's Brownian increments (kernel layout [S][3][ld], fp32, on the model's device)."""
+        dW = _lib.require_f32_device(dW, "dW")
+        if tuple(dW.shape) != (self.S, 3, self._mass.numel()):
+            raise ValueError(f"dW must be ({self.S}, 3, {self._mass.numel()}), got {tuple(dW.shape)}")
+        self._dW = dW
+        self.invalidate_noise()
 
     def linearize_device(self, us_mat, inputs=None, cols_per_thread=0, samples_per_lane=0, out=None,
                          want_Z=True, events=None, factored=None, want_A22=False, reduce=True, rows_out=0, stats_request=None):
@@ -316,6 +334,8 @@ class Model:
         p = self._params(M, ld, rows_out)
         if stats_request is not None:
             stats.request_in_launch(p, *stats_request)
+        # (re-tiled BEFORE the start event: the one-time copy is not part of the linearize launch that is timed)
+        tiled = self._tiled_noise(dW, M, ld) if (dW is not None and cpt == -1 and self.TILED_NOISE) else None
         if events is not None:
             events[0].record()
         if dW is None:      # noise regenerated while a tile is staged: the same numbers, no array, no reads
@@ -323,11 +343,11 @@ class Model:
                 C.byref(p), _lib.ptr(us), self._noise_seed, self._sampler_dt, _lib.ptr(mass), _lib.ptr(Qsym),
                 _lib.ptr(G), _lib.ptr(Wf), _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part),
                 _lib.current_stream()), "rato_drone_linearize_philox")
-        elif cpt == -1 and self.TILED_NOISE:
+        elif cpt == -1 and self.TILED_NOISE and tiled is not None:
             # the row-parallel kernel reads the batch's noise re-tiled ONCE ([tile][3S][64]: a tile's noise is one block
             # instead of 3S rows ld floats apart -- reads beside the store stream cost more than their bytes); same outputs
             _lib.check(self._lib.rato_drone_linearize_tiled(
-                C.byref(p), _lib.ptr(us), _lib.ptr(self._tiled_noise(dW, M, ld)), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
+                C.byref(p), _lib.ptr(us), _lib.ptr(tiled), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(G),
                 _lib.ptr(Wf), _lib.ptr(A22), _lib.ptr(g_up), _lib.ptr(Z), _lib.ptr(part), _lib.current_stream()),
                 "rato_drone_linearize_tiled")
         else:

@@ -319,3 +319,28 @@ def test_tiled_noise_gives_the_same_linearization_bit_for_bit(M, S):
     d2 = driving.Model.from_device(S, dW2, x0, ws_, wr, 'saa', 0.05)
     c = d2.linearize_device(us)
     assert not torch.equal(c["Z"], a["Z"])
+
+
+def test_per_sample_linearization_never_reuses_another_samples_noise():
+    """ADVICE r4 (high), driving twin: one-sample ``inputs`` are never served from the model's re-tiled noise cache."""
+    import torch
+    from riskaversetrajopt_amd import driving
+    S, M = 20, 5
+    o, d = _models(S, M, seed=3)
+    us = swerve(S)
+    Z_own = d.linearize_device(us)["Z"].clone()
+    args = lambda i: (o.states_init[i], o.omegas_speed[i], o.omegas_repulsive[i], o.DWs[i])
+    outs = [d.get_all_constraints_coeffs(us, *args(i)) for i in range(M)]
+    g_o = o.get_all_constraints_coeffs(us)[-1]
+    for i in range(M):
+        np.testing.assert_allclose(outs[i][4], g_o[i], rtol=tol.GUP_RTOL, atol=tol.GUP_ATOL)
+    try:
+        driving.Model.TILED_NOISE = False
+        for i in range(M):
+            w = d.get_all_constraints_coeffs(us, *args(i))
+            for a, b in zip(outs[i], w):
+                assert np.array_equal(a, b), i
+    finally:
+        driving.Model.TILED_NOISE = True
+    assert not np.array_equal(outs[0][4], outs[1][4])
+    assert torch.equal(d.linearize_device(us)["Z"], Z_own)
