@@ -138,10 +138,12 @@ class DroneWork:
                 o["_Z"], o["sums"] = rec.Z_row[:ld], rec.sums
                 self.records.append(rec)
         else:
-            self.kernel = "drone_eval_kernel<philox>" if self.philox else "drone_eval_kernel"
+            self.kernel = "drone_eval_kernel<philox>" if self.philox else "drone_eval_tiles_kernel"
 
     def stats_in_launch(self):
         """small batches: the linearize launch itself carries the statistics of its Z (rato_saa.h: params.stats_*)"""
+        if self.mode == "eval":      # the Monte-Carlo step: tiled rollout + exact selection in ONE launch (small batches)
+            return not self.philox and bool(self.model._lib.rato_drone_eval_stats_in_launch(self.M))
         return (self.mode == "linearize" and self.kernel == "drone_linearize_rows_kernel"
                 and bool(self.model._lib.rato_drone_stats_in_launch(self.M, self.S)))
 
@@ -155,7 +157,8 @@ class DroneWork:
                                                stats_request=stats_request)
         if events is not None:
             events[0].record()
-        Z, _, _ = self.model.eval_device(self.us)
+        self.eval_bufs = getattr(self, "eval_bufs", [{}, {}])
+        Z, _, _ = self.model.eval_device(self.us, out=self.eval_bufs[slot], stats_request=stats_request)
         if events is not None:
             events[1].record()
         return {"Z": Z, "du_sum": None}
@@ -248,9 +251,11 @@ class DrivingWork:
                                                      " noise=regenerated(Philox4x32-10)" if self.philox else "")
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
-            self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_kernel"
+            self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_tiles_kernel"
 
     def stats_in_launch(self):
+        if self.mode == "eval":
+            return not self.philox and bool(self.model._lib.rato_car_eval_stats_in_launch(self.M))
         return (self.mode == "linearize" and self.kernel == "car_linearize_rows_kernel"
                 and bool(self.model._lib.rato_car_stats_in_launch(self.M, self.S)))
 
@@ -261,7 +266,8 @@ class DrivingWork:
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, out=self.outs[slot],
                                             stats_request=stats_request)
         else:
-            r = {"Z": self.model.eval_device(self.us)[0]}
+            self.eval_bufs = getattr(self, "eval_bufs", [{}, {}])
+            r = {"Z": self.model.eval_device(self.us, out=self.eval_bufs[slot], stats_request=stats_request)[0]}
         if events is not None:
             events[1].record()
         return r
@@ -591,7 +597,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         except Exception as e:                          # a diagnostic must never take the bench line down
             print(f"note: clock probe skipped ({e})", file=sys.stderr)
     final_stats = stats_out[(counter[0] - 1) & 1].cpu().numpy()
-    launch = ("hipGraph replay of the whole step" + (" (the statistics ride in the linearize launch)" if in_launch else "")) if use_graph else (
+    launch = ("hipGraph replay of the whole step" + (" (the statistics ride in the kernel's own launch)" if in_launch else "")) if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
         if pipelined else "eager, one stream, no overlap between steps")
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
@@ -691,6 +697,59 @@ def scp_driving_block(device):
             "in_sample": {k: st[k] for k in ("var", "cvar", "frac_satisfied")}}
 
 
+def launch_floor_block(device, torch):
+    """What a replayed step costs before any work: the wall-clock of one hipGraph replay holding ONE trivial kernel, and
+    the increment per further kernel node (the configurations up to 50,000 samples are timed as one replay per step:
+    `ms_per_step` of a small configuration = this floor + its kernels).  Measured live, outside every timed region."""
+    from riskaversetrajopt_amd import _lib, stats
+    lib = _lib.load()
+    ws = stats.new_workspace(1000, device)
+
+    def tiny():
+        _lib.check(lib.rato_risk_stats_init(_lib.ptr(ws), ws.numel(), _lib.current_stream()), "rato_risk_stats_init")
+
+    def replay_us(n_nodes, reps=400):
+        for _ in range(n_nodes):
+            tiny()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n_nodes):
+                tiny()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+    one, four = replay_us(1), replay_us(4)
+    return {"graph_replay_one_tiny_kernel_us": one, "per_further_node_us": (four - one) / 3.0,
+            "what": "wall-clock per hipGraph replay of one 256-thread kernel that zeroes 25 KB (rato_risk_stats_init), "
+                    "400 replays back to back; the second figure from a 4-node graph"}
+
+
+def mc_batch_block(work, torch, K=120):
+    """The reference's Monte-Carlo report evaluates 4 alpha x 30 repeats = 120 control sequences on one validation batch
+    (drone_risk.py:697-725, driving.py:675-740), one jitted call each.  rato_*_eval_batch: all K in ONE call (one rollout
+    launch over tiles x K, one launch of K exact selections) -> microseconds per sequence."""
+    us = work.us[None].repeat(K, 1, 1).contiguous()
+    us = us * (1.0 + 0.001 * torch.arange(K, device=us.device, dtype=us.dtype))[:, None, None]      # K different sequences
+    bufs = {}
+    for _ in range(5):
+        work.model.eval_batch_device(us, out=bufs)
+    torch.cuda.synchronize()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        work.model.eval_batch_device(us, out=bufs)
+    torch.cuda.synchronize()
+    per_call = (time.perf_counter() - t0) / reps
+    return {"sequences_per_call": K, "us_per_call": per_call * 1e6, "us_per_sequence": per_call * 1e6 / K,
+            "value": work.M * work.S * K / per_call, "unit": "samples*steps/s", "launch": "eager, one library call per batch"}
+
+
 def configs_block(args, device, stats, rdist, dist, torch):
     """BASELINE.json's other single-GPU configurations (C2 drone M=1e4 S=50, C3 driving M=1e4 S=40, C4 hopper M=5e4
     S=60 / 40 contacts, C5's shard: driving 125,000 samples per GPU S=40) as whole steps, after and outside the timed
@@ -699,18 +758,21 @@ def configs_block(args, device, stats, rdist, dist, torch):
     steps each (the reference times its configurations the same way: drone_times.py:509-550)."""
     import copy
     out = {}
-    for name, (wl, M, S, K) in {"C2": ("drone", 10000, 50, 300), "C3": ("driving", 10000, 40, 300),
-                                "C4": ("hopper", 50000, 60, 300), "C5": ("driving", 125000, 40, 150)}.items():
+    for name, (wl, M, S, K, mode) in {"C2": ("drone", 10000, 50, 300, "linearize"), "C3": ("driving", 10000, 40, 300, "linearize"),
+                                      "C4": ("hopper", 50000, 60, 300, "linearize"), "C5": ("driving", 125000, 40, 150, "linearize"),
+                                      # C2 / C3 in the reference's OWN form: the Monte-Carlo validation (drone_risk.py:643-725,
+                                      # driving.py:618-740: rollout -> max -> fraction satisfied / VaR / AVaR at M = 1e4)
+                                      "C2_eval": ("drone", 10000, 50, 500, "eval"), "C3_eval": ("driving", 10000, 40, 500, "eval")}.items():
         a = copy.copy(args)
         a.config, a.workload, a.M, a.S, a.steps, a.warmup = name, wl, M, S, K, 10
-        a.mode, a.philox, a.overlap, a.graph = "linearize", False, False, "auto"
+        a.mode, a.philox, a.overlap, a.graph = mode, False, False, "auto"
         a.packed_products, a.force_factored, a.cols_per_thread, a.samples_per_lane = True, False, 0, 0
         try:
             work = WORKLOADS[wl](a, device, seed=7)
             res = timed_region(work, a, 1, 0, device, stats, rdist, dist, torch, probe_clock=False)
             units = getattr(work, "C", work.S)
-            rb = roofline_block(work, res["kern_ms"], wl, "linearize", work.M, work.S,
-                                "products" if wl == "drone" else None, res["kern_src"])
+            rb = roofline_block(work, res["kern_ms"], wl, mode, work.M, work.S,
+                                "products" if (wl == "drone" and mode == "linearize") else None, res["kern_src"])
             ms = 1e3 * res["elapsed"] / K
             out[name] = {"workload": f"{work.name} M={work.M} S={work.S}" + (f" ({work.C} contacts)" if wl == "hopper" else ""),
                          "steps": K, "ms_per_step": ms, "value": work.M * units * K / res["elapsed"],
@@ -721,6 +783,10 @@ def configs_block(args, device, stats, rdist, dist, torch):
                          "algorithmic_bytes_per_launch": rb["algorithmic_bytes_per_launch"],
                          "traffic_from_profile": rb["traffic_from_profile"], "launch": res["launch"],
                          "stats": {"VaR": res["stats"][0], "CVaR": res["stats"][1], "frac_satisfied": res["stats"][2]}}
+            if mode == "eval":
+                out[name]["form"] = ("the reference's Monte-Carlo validation step (rollout -> max -> fraction / VaR / AVaR), one "
+                                     "control sequence per replayed step: rollout kernel + exact selection, two nodes")
+                out[name]["batched"] = mc_batch_block(work, torch)
             del work
             torch.cuda.empty_cache()
         except Exception as e:                             # a side block must never take the bench line down
@@ -842,6 +908,10 @@ def main():
                         delattr(w, attr)
             torch.cuda.empty_cache()
             line["configs"] = configs_block(args, device, stats, rdist, dist, torch)
+            try:
+                line["configs"]["launch_floor"] = launch_floor_block(device, torch)
+            except Exception as e:                        # noqa: BLE001
+                line["configs"]["launch_floor"] = {"error": repr(e)}
             if not args.no_scp:
                 try:                                      # an extra block: its failure must not cost the metric line
                     line["scp_driving"] = scp_driving_block(device)

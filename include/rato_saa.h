@@ -90,7 +90,8 @@ extern "C" {
  * params.stats_* -- the statistics of Z in extra workgroups of the row-parallel linearize launch itself)
  * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
  * The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 10
+#define RATO_ABI_VERSION 11
+#define RATO_STATS_IN_LAUNCH 1   /* params.stats_flags */
 int rato_abi_version(void);
 
 /* floats between consecutive tiles of a packed tile-blocked Jacobian whose tile holds payload_floats numbers */
@@ -156,7 +157,7 @@ typedef struct rato_drone_params {
   double* stats_out;
   double stats_alpha;
   float stats_thr;
-  int32_t stats_reserved;
+  int32_t stats_flags;       /* RATO_STATS_IN_LAUNCH: rato_drone_eval computes them in its own launch (default: behind it) */
 } rato_drone_params;
 
 /*
@@ -172,7 +173,16 @@ typedef struct rato_drone_params {
  *   Z     [M]               max_{j,t} g - tol
  *   xs    [S+1][6][M]       state trajectories (SoA of the reference's (M,S+1,6))
  *   g     [3 obs][S][M]     constraint values
+ * Without trajectories (xs == NULL) the tiled kernel runs: one wave per tile of 64 samples, the noise of 32 steps in
+ * flight before the first step, the vertical axis (which no obstacle row reads) not rolled out; Z and g to the bit as
+ * with trajectories.
+ * Monte-Carlo step in one call (ABI 11; drone_risk.py:643-725: rollout -> max -> fraction / VaR / AVaR): with
+ * p->stats_workspace / stats_out / stats_alpha / stats_thr set (and Z requested) the call also leaves the rato_risk_stats
+ * record of Z in stats_out -- by rato_risk_stats behind the kernel; with RATO_STATS_IN_LAUNCH in p->stats_flags, for
+ * batches without trajectories up to rato_drone_eval_stats_in_launch(M), in an extra workgroup of the SAME launch
+ * (measured slower than the two launches: DESIGN.md; kept for A/B).
  */
+int rato_drone_eval_stats_in_launch(int32_t M);
 int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW,
                     const float* mass, const float* Qsym,
                     float* Z, float* xs, float* g, void* stream);
@@ -223,6 +233,19 @@ int rato_drone_linearize(const rato_drone_params* p, const float* us, const floa
 int rato_drone_obstacle_constraints(const rato_drone_params* p, const float* xs,
                                     const float* Qsym, float* g, void* stream);
 
+/* The reference's Monte-Carlo report evaluates MANY control sequences on one validation batch (drone_risk.py:697-725:
+ * 4 alpha x 30 repeats; driving.py:675-740): K sequences in ONE call -- the rollouts of all of them in one launch
+ * (grid = tiles x K: a single sequence at M = 1e4 occupies 157 of the chip's 1024 SIMDs), the K exact selections in a
+ * second one.    us [K][S][n_u];  Z [K][ldz] (ldz >= M);  stats_out [K][RATO_N_STATS] or NULL (then alpha, thr,
+ * workspace are not read).  Row k is, to the bit, what rato_*_eval + rato_risk_stats give for sequence k. */
+int rato_drone_eval_batch(const rato_drone_params* p, int32_t K, const float* us, const float* dW, const float* mass,
+                          const float* Qsym, float* Z, int64_t ldz, double alpha, float thr, void* workspace,
+                          size_t workspace_bytes, double* stats_out, void* stream);
+/* (driving: rato_car_eval_batch, below) */
+/* the records of K rows of Z [K][ldz] -> out [K][RATO_N_STATS] (one launch while M <= 12,288) */
+int rato_risk_stats_batch(const float* Z, int64_t M, int64_t ldz, int32_t K, double alpha, float thr, void* workspace,
+                          size_t workspace_bytes, double* out, void* stream);
+
 /* ---------------------------------------------------------------- driving */
 
 /* Constants of driving_params.py:1-42 / Model.__init__ driving.py:84-120. */
@@ -250,7 +273,7 @@ typedef struct rato_car_params {
   double* stats_out;
   double stats_alpha;
   float stats_thr;
-  int32_t stats_reserved;
+  int32_t stats_flags;       /* as rato_drone_params.stats_flags */
 } rato_car_params;
 
 /* Scratch floats needed by the driving entry points for the shared ego
@@ -270,10 +293,19 @@ size_t rato_car_ego_scratch_floats(int32_t S);
  *   Z   [M]                 max_t(-distance_t) - tol
  *   xs  [S+1][8][M]
  *   g   [S][M]              -distance_t
+ * Without trajectories (xs == NULL) the rollout is ONE launch: every workgroup folds the sample-independent ego trajectory
+ * into its own LDS (the arithmetic of the ego prologue, to the bit) and rolls its tiles out (one wave per 64 samples, the
+ * noise of 32 steps in flight).  Monte-Carlo step in one call (ABI 11; driving.py:618-740): p->stats_* / stats_flags as
+ * for rato_drone_eval.
  */
+int rato_car_eval_stats_in_launch(int32_t M);
 int rato_car_eval(const rato_car_params* p, const float* us, const float* dW,
                   const float* x0_ped, const float* w_speed, const float* w_rep,
                   float* ego_scratch, float* Z, float* xs, float* g, void* stream);
+/* K control sequences in one call: see rato_drone_eval_batch.  us [K][S][2]. */
+int rato_car_eval_batch(const rato_car_params* p, int32_t K, const float* us, const float* dW, const float* x0_ped,
+                        const float* w_speed, const float* w_rep, float* Z, int64_t ldz, double alpha, float thr,
+                        void* workspace, size_t workspace_bytes, double* stats_out, void* stream);
 
 /* Model.separation_distances_at_all_times on GIVEN trajectories (driving.py:223-236):
  *   xs [S+1][8][M] -> dist [S][M] = ||p_ego(t+1) - p_ped(t+1)|| - d_min   (the constraint value is -dist). */

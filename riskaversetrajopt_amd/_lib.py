@@ -6,7 +6,7 @@ import os
 from . import _build
 
 _LIB = None
-ABI_VERSION = 10             # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
+ABI_VERSION = 11             # RATO_ABI_VERSION of include/rato_saa.h this binding was written against
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
@@ -22,7 +22,7 @@ class DroneParams(C.Structure):
                 ("x_final64", C.c_double * 6), ("obs_xy64", (C.c_double * 2) * 3),
                 # statistics in the same launch (row-parallel linearize kernel): workspace, record, tail level, threshold
                 ("stats_workspace", C.c_void_p), ("stats_out", C.c_void_p), ("stats_alpha", C.c_double),
-                ("stats_thr", C.c_float), ("stats_reserved", C.c_int32)]
+                ("stats_thr", C.c_float), ("stats_flags", C.c_int32)]
 
 
 class CarParams(C.Structure):
@@ -32,7 +32,7 @@ class CarParams(C.Structure):
                 ("dt64", C.c_double), ("beta64", C.c_double), ("speed_ped_des64", C.c_double), ("d_min64", C.c_double),
                 ("ego_init64", C.c_double * 4),
                 ("stats_workspace", C.c_void_p), ("stats_out", C.c_void_p), ("stats_alpha", C.c_double),
-                ("stats_thr", C.c_float), ("stats_reserved", C.c_int32)]
+                ("stats_thr", C.c_float), ("stats_flags", C.c_int32)]
 
 
 class CutConfig(C.Structure):
@@ -164,6 +164,14 @@ SIGNATURES = {
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
     "rato_drone_stats_in_launch": (C.c_int, [C.c_int32, C.c_int32]),
+    "rato_drone_eval_stats_in_launch": (C.c_int, [C.c_int32]),
+    "rato_drone_eval_batch": (C.c_int, [C.POINTER(DroneParams), C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                        C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
+    "rato_car_eval_batch": (C.c_int, [C.POINTER(CarParams), C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                      c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),
+    "rato_risk_stats_batch": (C.c_int, [c_float_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_float, C.c_void_p,
+                                        C.c_size_t, c_float_p, c_stream]),
+    "rato_car_eval_stats_in_launch": (C.c_int, [C.c_int32]),
     "rato_car_stats_in_launch": (C.c_int, [C.c_int32, C.c_int32]),
     "rato_risk_stats_recover": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),

@@ -230,6 +230,172 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
   if (Z) Z[m] = zmax - P.tol;
 }
 
+// ped_step and the distance row with every rounding spelled out: the contraction pattern the compiler chooses for them in
+// car_eval_kernel (read off its ISA; see step_axis_exact in drone.hip for why) -- for a kernel that has to reproduce
+// car_eval_kernel to the bit.
+// (-ffp-contract=fast lets the BACK END fuse any multiply into a following add whatever the pragma says: a product that
+//  must stay a product goes through an empty asm statement, which hides where it came from)
+__device__ __forceinline__ float unfused(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ void ped_step_exact(const rato_car_params& P, const PedConsts& c, float ex, float ey, float xi0,
+                                               float xi1, float& px, float& py, float& vx, float& vy) {
+#pragma clang fp contract(off)
+  const float dx = ex - px, dy = ey - py;
+  const float r2 = unfused(dx * dx) + unfused(dy * dy);
+  const float rinv = __builtin_amdgcn_rsqf(r2);
+  const float common = c.w_s * (P.speed_ped_des - vy);
+  const float F0 = __builtin_fmaf(-c.w_r, dx * rinv, common), F1 = __builtin_fmaf(-c.w_r, dy * rinv, common);
+  const float pxn = __builtin_fmaf(P.dt, vx, px), pyn = __builtin_fmaf(P.dt, vy, py);
+  vx = __builtin_fmaf(c.cn, xi0, __builtin_fmaf(P.dt, F0, vx));
+  vy = __builtin_fmaf(c.cn, xi1, __builtin_fmaf(P.dt, F1, vy));
+  px = pxn;
+  py = pyn;
+}
+__device__ __forceinline__ float separation_row_exact(const rato_car_params& P, float ex, float ey, float px, float py) {
+#pragma clang fp contract(off)
+  const float dx = ex - px, dy = ey - py;
+  const float d2 = unfused(dx * dx) + unfused(dy * dy);
+  return -__builtin_fmaf(d2, __builtin_amdgcn_rsqf(d2), -P.d_min);
+}
+
+// The Monte-Carlo form for small batches (driving.py:618-740: M = 1e4), for calls that want Z (and g) but no
+// trajectories -- see drone_eval_tiles_kernel (drone.hip) for the structure: one wave per tile of 64 samples, the noise of
+// 2 x CEV_TB steps in flight before the first step, the statistics of Z in the same launch.  The ego trajectory
+// (sample-independent) is folded by every workgroup into its own LDS exactly as car_ego_kernel does (fp64, rounded
+// once): ONE launch instead of the ego kernel + the rollout + the statistics, and the same Z / g to the bit.
+constexpr int CEV_TB = 16;
+constexpr int CEV_NW = RATO_BLOCK / RATO_WAVE;
+__host__ __device__ inline size_t car_eval_tiles_lds_bytes(int S) {   // ego xy (float2) [S+1] | us [2S] | fp64 v, cos, sin [S+1]
+  return (((size_t)(S + 1) * 2 + (size_t)S * 2 + 1) & ~size_t(1)) * sizeof(float) + (size_t)(S + 1) * 3 * sizeof(double);
+}
+
+// blockIdx.y = control sequence k of a batch of K (rato_car_eval_batch: us [K][S][2], Z [K][ldz]); K = 1: rato_car_eval.
+template <bool WANT_G>
+__global__ __launch_bounds__(RATO_BLOCK) void car_eval_tiles_kernel(
+    rato_car_params P, const float* __restrict__ us_base, const float* __restrict__ dW, const float* __restrict__ x0_ped,
+    const float* __restrict__ w_speed, const float* __restrict__ w_rep, float* __restrict__ Z_base, long ldz,
+    float* __restrict__ g, int n_tiles, const rato_sel::StatsTail tail) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cev_lds[];
+  if (tail.is_stats((int)blockIdx.x)) {
+    rato_sel::stats_tail_run<RATO_BLOCK>(tail, Z_base, (long)P.M, cev_lds);
+    return;
+  }
+  const int S = P.S;
+  const float* __restrict__ us = us_base + (size_t)blockIdx.y * S * 2;
+  float* __restrict__ Z = Z_base ? Z_base + (size_t)blockIdx.y * ldz : nullptr;
+  float* EGO = reinterpret_cast<float*>(cev_lds);                 // [S+1][2]
+  float* US = EGO + (size_t)(S + 1) * 2;                          // [S][2]
+  double* DV = reinterpret_cast<double*>(cev_lds + ((((size_t)(S + 1) * 2 + (size_t)S * 2 + 1) & ~size_t(1)) * sizeof(float)));
+  double* DCS = DV + (S + 1);
+  double* DSN = DCS + (S + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = (int)blockIdx.x * CEV_NW + wave;
+  const bool has_tile = tile < n_tiles;            // (wave-uniform; every wave helps with the ego tables)
+  const size_t M = (size_t)P.M;
+  const size_t m_raw = (size_t)(has_tile ? tile : 0) * RATO_WAVE + lane;
+  const bool valid = has_tile && m_raw < M;
+  const size_t m = m_raw < M ? m_raw : M - 1;
+  float xa[CEV_TB][2], xb[CEV_TB][2];
+  auto load = [&](float (&xi)[CEV_TB][2], int t0) {
+#pragma unroll
+    for (int i = 0; i < CEV_TB; ++i) {
+      const int t = (t0 + i < S) ? t0 + i : S - 1;
+      xi[i][0] = dW[(size_t)(t * 2 + 0) * M + m];
+      xi[i][1] = dW[(size_t)(t * 2 + 1) * M + m];
+    }
+  };
+  load(xa, 0);                                     // in flight while the ego tables are folded
+  load(xb, CEV_TB);
+  PedConsts c;
+  c.w_s = w_speed[m];
+  c.w_r = w_rep[m];
+  c.cn = sqrtf(P.dt) * P.beta;
+  float px = x0_ped[0 * M + m], py = x0_ped[1 * M + m], vx = x0_ped[2 * M + m], vy = x0_ped[3 * M + m];
+  for (int i = threadIdx.x; i < 2 * S; i += RATO_BLOCK) US[i] = us[i];
+  __syncthreads();
+  {
+    // the fold of car_ego_kernel, statement for statement (one thread per step, fp64, rounded once)
+    const double dt = P.dt;
+    for (int t = threadIdx.x; t <= S; t += RATO_BLOCK) {
+      double v = P.ego_init[2], ph = P.ego_init[3];
+      for (int k = 0; k < t; ++k) {
+        v += dt * (double)US[k * 2 + 0];
+        ph += dt * (double)US[k * 2 + 1];
+      }
+      double sn, cs;
+      sincos(ph, &sn, &cs);
+      DV[t] = v;
+      DCS[t] = cs;
+      DSN[t] = sn;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t <= S; t += RATO_BLOCK) {
+      double x = P.ego_init[0], y = P.ego_init[1];
+      for (int k = 0; k < t; ++k) {
+        x += dt * DV[k] * DCS[k];
+        y += dt * DV[k] * DSN[k];
+      }
+      EGO[t * 2 + 0] = (float)x;
+      EGO[t * 2 + 1] = (float)y;
+    }
+    __syncthreads();
+  }
+  if (!has_tile) return;
+  // the ego positions of 64 steps live in the lanes of two registers (lane l: position at step 64 c + l + 1) and reach
+  // the step as a v_readlane instead of an LDS read in front of every step
+  float egx = 0.0f, egy = 0.0f;
+  auto load_ego = [&](int t0) {
+    const int t = (t0 + lane + 1 <= S) ? t0 + lane + 1 : S;
+    egx = EGO[t * 2 + 0];
+    egy = EGO[t * 2 + 1];
+  };
+  load_ego(0);
+  float ex = EGO[0], ey = EGO[1];                 // ego position at the current step (carried)
+  float zmax = -INFINITY;
+  auto steps = [&](const float (&xi)[CEV_TB][2], int t0) {
+#pragma unroll
+    for (int i = 0; i < CEV_TB; ++i) {
+      const int t = t0 + i;
+      if (t < S) {
+        const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(egx), t & 63));
+        const float ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(egy), t & 63));
+        ped_step_exact(P, c, ex, ey, xi[i][0], xi[i][1], px, py, vx, vy);
+        const float gt = separation_row_exact(P, nx, ny, px, py);
+        ex = nx;
+        ey = ny;
+        zmax = fmaxf(zmax, gt);
+        if (WANT_G && valid) g[(size_t)t * M + m] = gt;
+      }
+    }
+  };
+  for (int t0 = 0; t0 < S; t0 += 2 * CEV_TB) {
+    if (t0 && (t0 & 63) == 0) load_ego(t0);
+    steps(xa, t0);
+    if (t0 + 2 * CEV_TB < S) load(xa, t0 + 2 * CEV_TB);
+    steps(xb, t0 + CEV_TB);
+    if (t0 + 3 * CEV_TB < S) load(xb, t0 + 3 * CEV_TB);
+  }
+  if (!Z) return;
+  if (!tail.ws) {
+    if (valid) Z[m] = zmax - P.tol;
+    return;
+  }
+  if (valid)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    unsigned* z_signal = tail.ws->sig;
+    const unsigned cnt = __hip_atomic_fetch_add(z_signal + rato_sel::SIG_Z_COUNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt == (unsigned)n_tiles - 1u) {
+      __hip_atomic_store(z_signal + rato_sel::SIG_Z_COUNT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(z_signal + rato_sel::SIG_Z_READY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // separation_distances_at_all_times on given trajectories (driving.py:223-236): xs [S+1][8][M] -> dist [S][M]
 __global__ __launch_bounds__(RATO_BLOCK) void car_distance_kernel(rato_car_params P, const float* __restrict__ xs,
                                                                  float* __restrict__ dist) {
@@ -911,18 +1077,101 @@ int launch_car_linearize(const rato_car_params* p, const float* dW, const float*
 
 extern "C" size_t rato_car_ego_scratch_floats(int32_t S) { return S > 0 ? ego_total(S) : 0; }
 
+namespace {
+constexpr int64_t CAR_EVAL_TILES_MAX_M = 1 << 20, CAR_EVAL_STATS_IN_LAUNCH_MAX_M = 65536;
+int car_eval_tiles_max_m() {
+  static const int64_t v = [] { const char* e = getenv("RATO_EVAL_TILES_MAX_M"); return e ? (int64_t)atoll(e) : CAR_EVAL_TILES_MAX_M; }();
+  return (int)v;
+}
+}  // namespace
+
+extern "C" int rato_car_eval_stats_in_launch(int32_t M) {
+  return M > 0 && M <= CAR_EVAL_STATS_IN_LAUNCH_MAX_M && M <= car_eval_tiles_max_m();
+}
+
+namespace {
+int car_eval_tiles_launch(const rato_car_params* p, int K, const float* us, const float* dW, const float* x0_ped,
+                          const float* w_speed, const float* w_rep, float* Z, int64_t ldz, float* g,
+                          const rato_sel::StatsTail& tail, int grid_launch, size_t lds, int n_tiles, hipStream_t st) {
+  if (g)
+    hipLaunchKernelGGL(car_eval_tiles_kernel<true>, dim3(grid_launch, K), dim3(RATO_BLOCK), lds, st, *p, us, dW, x0_ped, w_speed,
+                       w_rep, Z, (long)ldz, g, n_tiles, tail);
+  else
+    hipLaunchKernelGGL(car_eval_tiles_kernel<false>, dim3(grid_launch, K), dim3(RATO_BLOCK), lds, st, *p, us, dW, x0_ped, w_speed,
+                       w_rep, Z, (long)ldz, g, n_tiles, tail);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+bool car_eval_tiles_ok(const rato_car_params* p) {
+  return p->M <= car_eval_tiles_max_m() && car_eval_tiles_lds_bytes(p->S) <= 48 * 1024;
+}
+}  // namespace
+
 extern "C" int rato_car_eval(const rato_car_params* p, const float* us, const float* dW, const float* x0_ped,
                              const float* w_speed, const float* w_rep, float* ego_scratch, float* Z, float* xs,
                              float* g, void* stream) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !x0_ped || !w_speed || !w_rep || !ego_scratch) return RATO_EINVAL;
+  if (p->stats_workspace && (!Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0))) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
+  if (!xs && car_eval_tiles_ok(p)) {
+    // no trajectories wanted: ONE launch for the rollout (ego tables in every workgroup, tiled rollout); the statistics
+    // behind it (in the launch only on request: see rato_drone_eval)
+    const int n_tiles = (int)((p->M + RATO_WAVE - 1) / RATO_WAVE);
+    const int grid = (n_tiles + CEV_NW - 1) / CEV_NW;
+    rato_sel::StatsTail tail = {};
+    int grid_launch = grid;
+    size_t lds = car_eval_tiles_lds_bytes(p->S);
+    const bool in_launch = p->stats_workspace && (p->stats_flags & RATO_STATS_IN_LAUNCH) && rato_car_eval_stats_in_launch(p->M);
+    if (in_launch) {
+      int Gs = 0;
+      const int extra = rato_sel::stats_tail_workgroups<RATO_BLOCK>(p->M, Gs);
+      if (extra < 0) return RATO_EINVAL;
+      tail.ws = static_cast<rato_sel::Workspace*>(p->stats_workspace);
+      tail.out = p->stats_out;
+      tail.alpha = p->stats_alpha;
+      tail.thr = p->stats_thr;
+      tail.G = Gs;
+      tail.n_prod = grid;
+      rato_sel::stats_rank(p->M, p->stats_alpha, tail.k, tail.var_is_max);
+      grid_launch = grid + extra;
+      if (lds < rato_sel::rs_body_lds_bytes<RATO_BLOCK>()) lds = rato_sel::rs_body_lds_bytes<RATO_BLOCK>();
+    }
+    const int rc = car_eval_tiles_launch(p, 1, us, dW, x0_ped, w_speed, w_rep, Z, p->M, g, tail, grid_launch, lds, n_tiles, st);
+    if (rc != RATO_OK) return rc;
+    if (p->stats_workspace && !in_launch)
+      return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace,
+                             rato_risk_stats_workspace_bytes(p->M), p->stats_out, stream);
+    return RATO_OK;
+  }
   hipLaunchKernelGGL(car_ego_kernel, dim3(1), dim3(RATO_BLOCK), ego_lds_bytes(p->S), st, *p, us, ego_scratch,
                      (float*)nullptr, (float*)nullptr, 0);
   hipLaunchKernelGGL(car_eval_kernel<false>, dim3(rato::nblocks_for(p->M)), dim3(RATO_BLOCK), 0, st, *p, dW,
                      (uint64_t)0, 0.0f, x0_ped, w_speed, w_rep, ego_scratch, Z, xs, g);
   RATO_LAUNCH_CHECK();
+  if (p->stats_workspace)
+    return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace, rato_risk_stats_workspace_bytes(p->M),
+                           p->stats_out, stream);
   return RATO_OK;
+}
+
+// K control sequences against ONE resident batch in one call: us [K][S][2] -> Z [K][ldz] (+ stats_out [K][RATO_N_STATS]).
+extern "C" int rato_car_eval_batch(const rato_car_params* p, int32_t K, const float* us, const float* dW, const float* x0_ped,
+                                   const float* w_speed, const float* w_rep, float* Z, int64_t ldz, double alpha, float thr,
+                                   void* workspace, size_t workspace_bytes, double* stats_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || K < 1 || K > 65535 || !us || !dW || !x0_ped || !w_speed || !w_rep || !Z || ldz < p->M ||
+      car_eval_tiles_lds_bytes(p->S) > 48 * 1024)
+    return RATO_EINVAL;
+  if (stats_out && (!(alpha > 0.0) || !(alpha <= 1.0) || !workspace)) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  const int n_tiles = (int)((p->M + RATO_WAVE - 1) / RATO_WAVE);
+  const int grid = (n_tiles + CEV_NW - 1) / CEV_NW;
+  rato_sel::StatsTail tail = {};
+  const int rc = car_eval_tiles_launch(p, K, us, dW, x0_ped, w_speed, w_rep, Z, ldz, nullptr, tail, grid,
+                                       car_eval_tiles_lds_bytes(p->S), n_tiles, st);
+  if (rc != RATO_OK || !stats_out) return rc;
+  return rato_risk_stats_batch(Z, p->M, ldz, K, alpha, thr, workspace, workspace_bytes, stats_out, stream);
 }
 
 extern "C" int rato_car_eval_philox(const rato_car_params* p, const float* us, uint64_t seed, float sampler_dt,

@@ -56,6 +56,13 @@ __device__ __forceinline__ void step_axis(const rato_drone_params& P, const Samp
   v = vn;
 }
 
+// g_j at the horizontal position (px, py): 1 - (p - o_j)' Q_j (p - o_j)  (drone_risk.py:169-196); ONE expression for
+// every kernel that reports constraint values, so that they agree to the bit
+__device__ __forceinline__ float obstacle_value(const rato_drone_params& P, const SampleConsts& c, int j, float px, float py) {
+  const float dx = px - P.obs_xy[j][0], dy = py - P.obs_xy[j][1];
+  return 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
+}
+
 // PHILOX: the noise of step t is REGENERATED in the kernel (Philox4x32-10 at counter (m, t), philox.h) instead of
 // read from dW: bit-identical to rato_drone_sample's dW, no 12 B per sample-step of HBM reads, no 3 S floats per
 // sample of HBM capacity.  noise_scale = sqrt(sampler dt) (drone_utils.py:90).
@@ -113,8 +120,7 @@ __device__ __forceinline__ void drone_eval_block(
     }
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
-      const float dx = p[0] - P.obs_xy[j][0], dy = p[1] - P.obs_xy[j][1];
-      const float gj = 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
+      const float gj = obstacle_value(P, c, j, p[0], p[1]);
       zmax = fmaxf(zmax, gj);
       if (g) g[((size_t)j * S + t) * ld + m] = gj;
     }
@@ -152,6 +158,136 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
     if (gone == gridDim.x - 1) {
       __hip_atomic_store(tile_queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// step_axis / obstacle_value with every rounding spelled out, for a horizontal axis -- the contraction pattern the compiler
+// chooses for them inside drone_eval_kernel (it fuses the two horizontal axes into packed fp32 operations there;
+// read off its ISA: profiles/EXPERIMENTS.md, round 5).  -ffp-contract=fast leaves the pattern to the optimiser, and the
+// same source compiled into ANOTHER kernel came out one rounding different (1e-7 relative); a kernel that has to
+// reproduce drone_eval_kernel to the bit calls these (contraction off: only the written fmas fuse).
+__device__ __forceinline__ void step_axis_exact(const rato_drone_params& P, const SampleConsts& c, float u, float xi,
+                                                float& p, float& v) {
+#pragma clang fp contract(off)
+  const float kv = P.kd * v;
+  const float pn = __builtin_fmaf(P.dt, v, p);
+  const float s = __builtin_fmaf(P.kp, p, kv);
+  const float dq = v * (P.drag * fabsf(v));
+  const float w = c.inv_m * dq;
+  const float acc = __builtin_fmaf(c.inv_m, u - s, -w);
+  v = __builtin_fmaf(c.cn, xi, __builtin_fmaf(P.dt, acc, v));
+  p = pn;
+}
+__device__ __forceinline__ float obstacle_value_exact(const rato_drone_params& P, const SampleConsts& c, int j, float px, float py) {
+#pragma clang fp contract(off)
+  const float dx = px - P.obs_xy[j][0], dy = py - P.obs_xy[j][1];
+  float a = dy * (c.qs[j] * dx);
+  a = __builtin_fmaf(dx, c.q00[j] * dx, a);
+  a = __builtin_fmaf(dy, c.q11[j] * dy, a);
+  return 1.0f - a;
+}
+
+// Monte-Carlo validation batches (drone_risk.py:643-725: M = 1e4) are LATENCY bound: drone_eval_kernel at C2 runs 40
+// workgroups on 256 CUs and every one of its 50 steps waits for a global load issued one step earlier (20.6 us for
+// 6.5 MB: 0.8 us of HBM time).  This form, for calls that want Z (and g) but no trajectories:
+//   * one wave = one tile of 64 samples, four tiles per workgroup; the vertical axis is not rolled out at all (no
+//     obstacle row reads it: drone_risk.py:174 uses [:2,:2] of Q and the first two coordinates);
+//   * the noise of 2 x EV_TB steps is requested before the first step is taken and the next batch is always in flight
+//     (two register buffers): the rollout is bound by its own arithmetic chain, not by memory;
+//   * the statistics of Z ride in the same launch (params.stats_*: extra workgroups at the end of the grid run the exact
+//     selection as soon as the last tile's Z has landed -- rato_select.h), so that a Monte-Carlo step is ONE launch.
+// Same arithmetic per sample as drone_eval_kernel, rounding for rounding (step_axis_exact, obstacle_value_exact): Z and g
+// agree to the bit (tests/test_gpu_fused_stats.py).
+constexpr int EV_TB = 16;
+constexpr int EV_NW = RATO_BLOCK / RATO_WAVE;
+
+// blockIdx.y = control sequence k of a batch of K (rato_drone_eval_batch: us [K][S][3], Z [K][ldz]); K = 1: rato_drone_eval.
+template <bool WANT_G>
+__global__ __launch_bounds__(RATO_BLOCK) void drone_eval_tiles_kernel(
+    rato_drone_params P, const float* __restrict__ us_base, const float* __restrict__ dW, const float* __restrict__ mass,
+    const float* __restrict__ Qsym, float* __restrict__ Z_base, long ldz, float* __restrict__ g, int n_tiles,
+    const rato_sel::StatsTail tail) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ev_lds[];
+  if (tail.is_stats((int)blockIdx.x)) {
+    rato_sel::stats_tail_run<RATO_BLOCK>(tail, Z_base, (long)P.M, ev_lds);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = (int)blockIdx.x * EV_NW + wave;
+  if (tile >= n_tiles) return;                     // (wave-uniform)
+  const size_t M = (size_t)P.M, ld = (size_t)P.ld;
+  const size_t m_raw = (size_t)tile * RATO_WAVE + lane;
+  const bool valid = m_raw < M;
+  const size_t m = valid ? m_raw : M - 1;
+  const int S = P.S;
+  const float* __restrict__ us = us_base + (size_t)blockIdx.y * S * 3;
+  float* __restrict__ Z = Z_base ? Z_base + (size_t)blockIdx.y * ldz : nullptr;
+  float xa[EV_TB][2], xb[EV_TB][2];
+  auto load = [&](float (&xi)[EV_TB][2], int t0) {
+#pragma unroll
+    for (int i = 0; i < EV_TB; ++i) {
+      const int t = (t0 + i < S) ? t0 + i : S - 1;
+      xi[i][0] = dW[((size_t)t * 3 + 0) * ld + m];
+      xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
+    }
+  };
+  load(xa, 0);                                     // in flight before anything else
+  load(xb, EV_TB);
+  // the controls of 64 steps live in the lanes of two registers (lane l: step 64 c + l) and reach the step as a
+  // v_readlane: a scalar load per step put its memory latency into every step of the one wave a SIMD runs here
+  float ux = 0.0f, uy = 0.0f;
+  auto load_us = [&](int t0) {
+    const int t = (t0 + lane < S) ? t0 + lane : S - 1;
+    ux = us[t * 3 + 0];
+    uy = us[t * 3 + 1];
+  };
+  load_us(0);
+  const SampleConsts c = load_consts(P, mass, Qsym, ld, m);
+  float p[2] = {P.x_init[0], P.x_init[1]}, v[2] = {P.x_init[3], P.x_init[4]};
+  float zmax = -INFINITY;
+  auto steps = [&](const float (&xi)[EV_TB][2], int t0) {
+#pragma unroll
+    for (int i = 0; i < EV_TB; ++i) {
+      const int t = t0 + i;
+      if (t < S) {
+        const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ux), t & 63));
+        const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uy), t & 63));
+        step_axis_exact(P, c, u0, xi[i][0], p[0], v[0]);
+        step_axis_exact(P, c, u1, xi[i][1], p[1], v[1]);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) {
+          const float gj = obstacle_value_exact(P, c, j, p[0], p[1]);
+          zmax = fmaxf(zmax, gj);
+          if (WANT_G && valid) g[((size_t)j * S + t) * ld + m] = gj;
+        }
+      }
+    }
+  };
+  for (int t0 = 0; t0 < S; t0 += 2 * EV_TB) {
+    if (t0 && (t0 & 63) == 0) load_us(t0);         // (2 EV_TB divides 64: a chunk of controls never changes inside a batch)
+    steps(xa, t0);
+    if (t0 + 2 * EV_TB < S) load(xa, t0 + 2 * EV_TB);
+    steps(xb, t0 + EV_TB);
+    if (t0 + 3 * EV_TB < S) load(xb, t0 + 3 * EV_TB);
+  }
+  if (!Z) return;
+  if (!tail.ws) {
+    if (valid) Z[m] = zmax - P.tol;
+    return;
+  }
+  // statistics in this launch: Z as agent-scope stores, completed, then the tile is counted in; the tile that completes
+  // the count raises z_ready (the protocol of the row-parallel linearize kernels)
+  if (valid)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(Z) + m, __float_as_uint(zmax - P.tol), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    unsigned* z_signal = tail.ws->sig;
+    const unsigned cnt = __hip_atomic_fetch_add(z_signal + rato_sel::SIG_Z_COUNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt == (unsigned)n_tiles - 1u) {
+      __hip_atomic_store(z_signal + rato_sel::SIG_Z_COUNT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(z_signal + rato_sel::SIG_Z_READY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1163,10 +1299,81 @@ bool params64_ok(const rato_drone_params* p) {
 
 }  // namespace
 
+namespace {
+// rato_drone_eval without trajectories: the tiled kernel (one wave per 64 samples, noise batches in flight, statistics in
+// the launch).  EVAL_TILES_MAX_M: beyond it the launch is bandwidth bound either way and the plain kernel is kept.
+constexpr int64_t EVAL_TILES_MAX_M = 1 << 20, EVAL_STATS_IN_LAUNCH_MAX_M = 65536;
+int eval_tiles_max_m() {
+  static const int64_t v = [] { const char* e = getenv("RATO_EVAL_TILES_MAX_M"); return e ? (int64_t)atoll(e) : EVAL_TILES_MAX_M; }();
+  return (int)v;
+}
+// the statistics of Z in extra workgroups of an eval launch with `grid` producer workgroups of NT threads
+template <int NT>
+int stats_tail_for(const void* workspace, double* out, double alpha, float thr, int64_t M, int grid, rato_sel::StatsTail& tail,
+                   int& grid_launch, size_t& lds_launch) {
+  int Gs = 0;
+  const int extra = rato_sel::stats_tail_workgroups<NT>(M, Gs);
+  if (extra < 0) return RATO_EINVAL;
+  tail.ws = static_cast<rato_sel::Workspace*>(const_cast<void*>(workspace));
+  tail.out = out;
+  tail.alpha = alpha;
+  tail.thr = thr;
+  tail.G = Gs;
+  tail.n_prod = grid;
+  rato_sel::stats_rank(M, alpha, tail.k, tail.var_is_max);
+  grid_launch = grid + extra;
+  if (lds_launch < rato_sel::rs_body_lds_bytes<NT>()) lds_launch = rato_sel::rs_body_lds_bytes<NT>();
+  return RATO_OK;
+}
+}  // namespace
+
+// 1 when rato_drone_eval with params.stats_* AND RATO_STATS_IN_LAUNCH in params.stats_flags would compute the statistics in
+// its own launch for this batch
+extern "C" int rato_drone_eval_stats_in_launch(int32_t M) { return M > 0 && M <= EVAL_STATS_IN_LAUNCH_MAX_M && M <= eval_tiles_max_m(); }
+
+namespace {
+int drone_eval_tiles_launch(const rato_drone_params* p, int K, const float* us, const float* dW, const float* mass,
+                            const float* Qsym, float* Z, int64_t ldz, float* g, const rato_sel::StatsTail& tail, int grid_launch,
+                            size_t lds, int n_tiles, hipStream_t st) {
+  if (g)
+    hipLaunchKernelGGL(drone_eval_tiles_kernel<true>, dim3(grid_launch, K), dim3(RATO_BLOCK), lds, st, *p, us, dW, mass, Qsym, Z,
+                       (long)ldz, g, n_tiles, tail);
+  else
+    hipLaunchKernelGGL(drone_eval_tiles_kernel<false>, dim3(grid_launch, K), dim3(RATO_BLOCK), lds, st, *p, us, dW, mass, Qsym, Z,
+                       (long)ldz, g, n_tiles, tail);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
+}
+}  // namespace
+
 extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, const float* dW, const float* mass,
                                const float* Qsym, float* Z, float* xs, float* g, void* stream) {
   RATO_CLEAR_ERROR();
   if (!params_ok(p) || !us || !dW || !mass || !Qsym) return RATO_EINVAL;
+  if (p->stats_workspace && (!Z || !p->stats_out || !(p->stats_alpha > 0.0) || !(p->stats_alpha <= 1.0))) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  if (!xs && p->M <= eval_tiles_max_m()) {
+    const int n_tiles = (int)((p->M + RATO_WAVE - 1) / RATO_WAVE);
+    const int grid = (n_tiles + EV_NW - 1) / EV_NW;
+    rato_sel::StatsTail tail = {};
+    int grid_launch = grid;
+    size_t lds = 0;
+    // The statistics behind the kernel by default: measured (profiles/r05_*_mc_step.txt) a second node costs 3.4 us of a
+    // replayed graph and rs_small (1024 threads) 3.8, while the selection as ONE 256-thread workgroup of this launch (the
+    // producers' block size) + the hand-off took 16.  RATO_STATS_IN_LAUNCH in stats_flags asks for the one-launch form.
+    const bool in_launch = p->stats_workspace && (p->stats_flags & RATO_STATS_IN_LAUNCH) && rato_drone_eval_stats_in_launch(p->M);
+    if (in_launch) {
+      const int rc = stats_tail_for<RATO_BLOCK>(p->stats_workspace, p->stats_out, p->stats_alpha, p->stats_thr, p->M, grid, tail,
+                                                grid_launch, lds);
+      if (rc != RATO_OK) return rc;
+    }
+    const int rc = drone_eval_tiles_launch(p, 1, us, dW, mass, Qsym, Z, p->ld, g, tail, grid_launch, lds, n_tiles, st);
+    if (rc != RATO_OK) return rc;
+    if (p->stats_workspace && !in_launch)
+      return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace,
+                             rato_risk_stats_workspace_bytes(p->M), p->stats_out, stream);
+    return RATO_OK;
+  }
   const int nblk = rato::nblocks_for(p->M);
   // The block queue buys the READ-bound eval kernel nothing (same box, alternating, M = 1e6 / 1e7: 0.1264-0.1281 /
   // 1.159-1.168 ms without, 0.1257-0.1276 / 1.153-1.165 ms with): the XCD asymmetry that the row kernels' queue
@@ -1175,14 +1382,33 @@ extern "C" int rato_drone_eval(const rato_drone_params* p, const float* us, cons
   unsigned* queue = nullptr;
   int grid_x = nblk;
   if (eval_dyn && nblk > 4 * 8 * device_cus()) {   // more than four rounds of 8 workgroups per CU
-    queue = take_tile_queue(rato::as_stream(stream));
+    queue = take_tile_queue(st);
     if (queue) grid_x = 8 * device_cus();
   }
   dim3 grid(grid_x), block(RATO_BLOCK);
-  hipLaunchKernelGGL(drone_eval_kernel<false>, grid, block, 0, rato::as_stream(stream), *p, us, dW, (uint64_t)0, 0.0f,
+  hipLaunchKernelGGL(drone_eval_kernel<false>, grid, block, 0, st, *p, us, dW, (uint64_t)0, 0.0f,
                      mass, Qsym, Z, xs, g, queue, nblk);
   RATO_LAUNCH_CHECK();
+  if (p->stats_workspace)
+    return rato_risk_stats(Z, p->M, p->stats_alpha, p->stats_thr, p->stats_workspace, rato_risk_stats_workspace_bytes(p->M),
+                           p->stats_out, stream);
   return RATO_OK;
+}
+
+// K control sequences against ONE resident batch in one call: us [K][S][3] -> Z [K][ldz] (+ stats_out [K][RATO_N_STATS]).
+extern "C" int rato_drone_eval_batch(const rato_drone_params* p, int32_t K, const float* us, const float* dW, const float* mass,
+                                     const float* Qsym, float* Z, int64_t ldz, double alpha, float thr, void* workspace,
+                                     size_t workspace_bytes, double* stats_out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!params_ok(p) || K < 1 || K > 65535 || !us || !dW || !mass || !Qsym || !Z || ldz < p->M) return RATO_EINVAL;
+  if (stats_out && (!(alpha > 0.0) || !(alpha <= 1.0) || !workspace)) return RATO_EINVAL;
+  hipStream_t st = rato::as_stream(stream);
+  const int n_tiles = (int)((p->M + RATO_WAVE - 1) / RATO_WAVE);
+  const int grid = (n_tiles + EV_NW - 1) / EV_NW;
+  rato_sel::StatsTail tail = {};
+  const int rc = drone_eval_tiles_launch(p, K, us, dW, mass, Qsym, Z, ldz, nullptr, tail, grid, 0, n_tiles, st);
+  if (rc != RATO_OK || !stats_out) return rc;
+  return rato_risk_stats_batch(Z, p->M, ldz, K, alpha, thr, workspace, workspace_bytes, stats_out, stream);
 }
 
 extern "C" int rato_drone_eval_philox(const rato_drone_params* p, const float* us, uint64_t seed, float sampler_dt,

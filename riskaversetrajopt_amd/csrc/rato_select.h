@@ -196,21 +196,62 @@ __device__ bool find_bin_coop(const unsigned* __restrict__ hist, unsigned k, uns
 }
 
 
+// Unsigned wave minimum / maximum through DPP (the tree of wave_max_dpp; result in every lane).
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned a) {
+  const int top = (int)0xffffffffu;
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x111, 0xf, 0xf, false));
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x112, 0xf, 0xf, false));
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x114, 0xf, 0xf, false));
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x118, 0xf, 0xf, false));
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x142, 0xa, 0xf, false));
+  a = min(a, (unsigned)__builtin_amdgcn_update_dpp(top, (int)a, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned a) {
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x111, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x112, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+}
+
+constexpr int RS_CAND_MAX = 256;   // candidates of a chosen bin that are ranked directly (pairwise) instead of binned again
+
 // ONE workgroup of NT threads: the whole exact selection with the keys in registers (M <= RS_SMALL_MAX).  The body of
-// stats.hip's rs_small (NT = 1024) and of the statistics workgroup that rides at the end of a row-parallel linearize launch
-// (NT = 512).  h: B1 words, red: 5 * NT/64 doubles, redmax: NT/64 floats of LDS.  sig != NULL: wait until the producer of Z
-// has raised z_ready, lower it again.
+// stats.hip's rs_small (NT = 1024) and of the statistics workgroup that rides at the end of a row-parallel linearize /
+// tiled eval launch (NT = 512 / 256).  h: B1 words, red: 5 * NT/64 doubles, redmax: NT/64 floats of LDS.  sig != NULL:
+// wait until the producer of Z has raised z_ready, lower it again.
+//
+// Round 5: RANGE-NORMALISED bins.  Constraint values cluster (a binade holds 4 of the 2048 bins of the key's top 11
+// bits), so the first pass of a plain radix select filtered almost nothing, its LDS atomics serialised on a handful of
+// addresses, and all three passes (each: zero, histogram, a 2048-bin scan behind three barriers) were always paid:
+// ~3 us each.  Here the workgroup first reduces the minimum and maximum key, and a pass bins (key - lo) >> sh over the
+// range that is actually occupied: 2048 bins across [min, max] hold ~M / 2048 keys each, the atomics spread, and after
+// ONE pass the bin that holds the wanted rank has a handful of members -- which are gathered into LDS and ranked
+// pairwise (<= RS_CAND_MAX of them; a bin that is still crowded -- ties, extreme clustering -- is binned again on its
+// next 11 bits, down to single keys).  Same result as before to the bit (the k-th smallest key is what it is).
 template <int NT>
 __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha, unsigned k, int var_is_max, float thr,
-                              double* __restrict__ out, unsigned* sig, unsigned* h, double* red, float* redmax) {
+                              double* __restrict__ out, unsigned* sig, unsigned* h, double* red, float* redmax,
+                              unsigned* magic = nullptr) {
   constexpr int KEYS = (int)(RS_SMALL_MAX / NT), NW = NT / RATO_WAVE;
+  static_assert(RS_CAND_MAX + 8 <= B1, "the candidate list reuses the histogram's LDS");
   if (sig) {
-    const bool ok = wait_signal(sig + SIG_Z_READY);
-    if (threadIdx.x == 0) __hip_atomic_store(sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (magic: the workspace's tag -- a workspace that was never initialised, or that an earlier launch un-tagged, holds
+    //  no trustworthy flag: fail loudly instead of waiting on it)
+    const bool tagged = !magic || *magic == RS_MAGIC;
+    const bool ok = tagged && wait_signal(sig + SIG_Z_READY);
     if (!ok) {
+      // The wait expired (or the workspace is not tagged).  The flag is NOT lowered here: the producers are still
+      // running and will raise it later -- lowered now, it would stay up and the NEXT launch would select on a Z that is
+      // not written yet.  The workspace is un-tagged instead: the next call on it reports NaN until it is re-initialised.
       if (threadIdx.x < RATO_N_STATS) out[threadIdx.x] = __longlong_as_double(0x7ff8000000000000LL);
+      if (magic && threadIdx.x == 0) *magic = 0u;
       return;
     }
+    if (threadIdx.x == 0) __hip_atomic_store(sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const int tid = threadIdx.x;
   const int n = (int)M;
@@ -218,89 +259,123 @@ __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha,
   if (tid == 0) out[16 + 0] = (double)wall_clock64();
 #endif
   // every load of the thread in flight before anything else (Z comes from HBM: its producer's L2 was written back)
-  float z[KEYS];
-#pragma unroll
-  for (int u = 0; u < KEYS; ++u) {
-    const int i = tid + u * NT;
-    z[u] = (i < n) ? Z[i] : 0.0f;
-  }
-  for (int i = tid; i < B1; i += NT) h[i] = 0;
-  __syncthreads();
   unsigned key[KEYS];
   double sum = 0.0, cnt = 0.0;
   float mx = -INFINITY;
+  unsigned kmin = 0xffffffffu, kmax = 0u;
   {
-    // constraint values cluster (a binade holds only 4 of the 2048 first-pass bins), and same-address LDS atomics
-    // serialise: a thread folds runs of equal bins of its own elements into one atomic (measured: 18 -> 12 us at
-    // M = 1e4 of clustered values)
-    unsigned run_bin = 0xffffffffu, run_cnt = 0;
+    float z[KEYS];
+#pragma unroll
+    for (int u = 0; u < KEYS; ++u) {
+      const int i = tid + u * NT;
+      z[u] = (i < n) ? Z[i] : 0.0f;
+    }
 #pragma unroll
     for (int u = 0; u < KEYS; ++u) {
       const int i = tid + u * NT;
       key[u] = key_of(z[u]);
       if (i < n) {
-        const unsigned bin = key[u] >> 21;
-        if (bin != run_bin) {
-          if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
-          run_bin = bin;
-          run_cnt = 0;
-        }
-        ++run_cnt;
         sum += (double)z[u];
         cnt += (z[u] <= thr) ? 1.0 : 0.0;
         mx = fmaxf(mx, z[u]);
+        kmin = min(kmin, key[u]);
+        kmax = max(kmax, key[u]);
       }
     }
-    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+  }
+  unsigned* mm = reinterpret_cast<unsigned*>(red);   // [2 NW]: the waves' minima | maxima (red is free until the end)
+  kmin = wave_min_u32_dpp(kmin);
+  kmax = wave_max_u32_dpp(kmax);
+  if ((tid & 63) == 0) {
+    mm[tid >> 6] = kmin;
+    mm[NW + (tid >> 6)] = kmax;
   }
   __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    kmin = min(kmin, mm[w]);
+    kmax = max(kmax, mm[NW + w]);
+  }
 #ifdef RATO_RS_DIAG
   if (tid == 0) out[16 + 1] = (double)wall_clock64();
 #endif
-  unsigned b1, k1, b2, k2, b3, k3;
-  find_bin<B1, NT>(h, k, b1, k1);
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 2] = (double)wall_clock64();
-#endif
-  for (int i = tid; i < B2; i += NT) h[i] = 0;
-  __syncthreads();
+  // lo: lower end of the key range still in play; sh: bits below the 11 this pass bins on; krem: wanted rank inside it
+  unsigned lo = kmin, krem = k;
+  const unsigned range = kmax - kmin;
+  int sh = (range == 0u) ? 0 : (32 - __clz((int)range)) - 11;
+  if (sh < 0) sh = 0;
+  unsigned width = 0u;         // candidates are the keys with key - lo < width (0: every key, first pass)
+  unsigned tkey = 0u;
+  for (int level = 0;; ++level) {
+    for (int i = tid; i < B1; i += NT) h[i] = 0;
+    __syncthreads();
+    {
+      unsigned run_bin = 0xffffffffu, run_cnt = 0;   // runs of equal bins of a thread's own elements -> one LDS atomic
 #pragma unroll
-  for (int u = 0; u < KEYS; ++u) {
-    const int i = tid + u * NT;
-    if (i < n && (key[u] >> 21) == b1) atomicAdd(&h[(key[u] >> 10) & (B2 - 1)], 1u);
-  }
-  __syncthreads();
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 3] = (double)wall_clock64();
-#endif
-  find_bin<B2, NT>(h, k1, b2, k2);
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 4] = (double)wall_clock64();
-#endif
-  for (int i = tid; i < B3; i += NT) h[i] = 0;
-  __syncthreads();
-  const unsigned prefix = (b1 << 11) | b2;
+      for (int u = 0; u < KEYS; ++u) {
+        const int i = tid + u * NT;
+        const unsigned rel = key[u] - lo;
+        if (i < n && (level == 0 || rel < width)) {
+          const unsigned bin = rel >> sh;
+          if (bin != run_bin) {
+            if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+            run_bin = bin;
+            run_cnt = 0;
+          }
+          ++run_cnt;
+        }
+      }
+      if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+    }
+    __syncthreads();
+    unsigned b, kr;
+    find_bin<B1, NT>(h, krem, b, kr);
+    const unsigned c = h[b];     // members of the chosen bin (uniform: every thread reads the same word)
+    lo += b << sh;
+    krem = kr;
+    width = 1u << sh;            // (sh <= 21)
+    if (sh == 0) {               // a bin is one key
+      tkey = lo;
+      break;
+    }
+    __syncthreads();             // everybody has read h[b]: the histogram's LDS becomes the candidate list
+    if (c <= (unsigned)RS_CAND_MAX) {
+      unsigned* cand = h;        // [c] keys | h[B1 - 2]: fill counter | h[B1 - 1]: the selected key
+      if (tid == 0) h[B1 - 2] = 0u;
+      __syncthreads();
 #pragma unroll
-  for (int u = 0; u < KEYS; ++u) {
-    const int i = tid + u * NT;
-    if (i < n && (key[u] >> 10) == prefix) atomicAdd(&h[key[u] & (B3 - 1)], 1u);
+      for (int u = 0; u < KEYS; ++u) {
+        const int i = tid + u * NT;
+        if (i < n && key[u] - lo < width) cand[atomicAdd(&h[B1 - 2], 1u)] = key[u];
+      }
+      __syncthreads();
+      if (tid < (int)c) {        // the candidate with  #{< x} <= krem < #{<= x}  (equal keys all qualify, and agree)
+        const unsigned x = cand[tid];
+        unsigned lt = 0, le = 0;
+        for (unsigned j = 0; j < c; ++j) {
+          const unsigned y = cand[j];
+          lt += (y < x) ? 1u : 0u;
+          le += (y <= x) ? 1u : 0u;
+        }
+        if (lt <= krem && krem < le) h[B1 - 1] = x;
+      }
+      __syncthreads();
+      tkey = h[B1 - 1];
+      break;
+    }
+    sh = (sh > 11) ? sh - 11 : 0;   // still crowded: its next 11 bits
   }
-  __syncthreads();
-#ifdef RATO_RS_DIAG
-  if (tid == 0) out[16 + 5] = (double)wall_clock64();
-#endif
-  find_bin<B3, NT>(h, k2, b3, k3);
 #ifdef RATO_RS_DIAG
   if (tid == 0) out[16 + 6] = (double)wall_clock64();
 #endif
-  const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
   const float t = value_of(tkey);
   double tail = 0.0, ngt = 0.0, neq = 0.0;
 #pragma unroll
   for (int u = 0; u < KEYS; ++u) {
     const int i = tid + u * NT;
     if (i < n) {
-      tail += (key[u] > tkey) ? ((double)z[u] - (double)t) : 0.0;
+      const float z = value_of(key[u]);
+      tail += (key[u] > tkey) ? ((double)z - (double)t) : 0.0;
       ngt += (key[u] > tkey) ? 1.0 : 0.0;
       neq += (key[u] == tkey) ? 1.0 : 0.0;
     }
@@ -316,6 +391,7 @@ __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha,
   ngt = rato::wave_sum_dpp(ngt);
   neq = rato::wave_sum_dpp(neq);
   mx = rato::wave_max_dpp(mx);
+  __syncthreads();               // (red held the key range of the waves until every thread had read it)
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
     red[0 * NW + w] = sum; red[1 * NW + w] = cnt; red[2 * NW + w] = tail; red[3 * NW + w] = ngt; red[4 * NW + w] = neq;
@@ -421,12 +497,11 @@ __device__ void rs_coop_body(const float* __restrict__ Z, long M, double alpha, 
   }
   flush_hist<B3, NT>(h, ws->hist3);
   ok = ok && find_bin_coop<B3, NT>(ws->hist3, k2, c2, b3, k3, c3);
-  if (!ok) {   // the histograms never added up: the workspace was not clean.  NaN out, un-tag the workspace.
+  if (!ok) {   // the histograms never added up (unclean workspace) or a wait expired.  NaN out, un-tag the workspace.
+    // (z_ready is left alone: after an expired wait the producers are still running and will raise it -- lowered here it
+    //  would stay up for the next launch; an un-tagged workspace makes that launch fail loudly until it is re-initialised)
     if (tid < RATO_N_STATS) out[tid] = __longlong_as_double(0x7ff8000000000000LL);
-    if (tid == 0) {
-      ws->magic = 0;
-      if (companion) __hip_atomic_store(ws->sig + SIG_Z_READY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) ws->magic = 0;
     return;
   }
   const unsigned tkey = (b1 << 21) | (b2 << 10) | b3;
@@ -559,7 +634,7 @@ __device__ __forceinline__ void stats_tail_run(const StatsTail& t, const float* 
   unsigned* h = reinterpret_cast<unsigned*>(lds);
   double* red = reinterpret_cast<double*>(h + B1);
   float* redmax = reinterpret_cast<float*>(red + 6 * (NT / RATO_WAVE));
-  if (t.G == 0) rs_small_body<NT>(Z, M, t.alpha, t.k, t.var_is_max, t.thr, t.out, t.ws->sig, h, red, redmax);
+  if (t.G == 0) rs_small_body<NT>(Z, M, t.alpha, t.k, t.var_is_max, t.thr, t.out, t.ws->sig, h, red, redmax, &t.ws->magic);
   else rs_coop_body<NT>(Z, M, t.alpha, t.k, t.var_is_max, t.thr, t.G, t.ws, t.out, (int)blockIdx.x - t.n_prod, 1, h, red);
 }
 

@@ -272,6 +272,16 @@ __global__ __launch_bounds__(RS1_T) void rs_small(const float* __restrict__ Z, l
   rs_small_body<RS1_T>(Z, M, alpha, k, var_is_max, thr, out, nullptr, h, red, redmax);   // rato_select.h (no producer to wait for)
 }
 
+// K independent selections in one launch (rato_risk_stats_batch): workgroup k on row k of Z [K][ldz] -> out [K][RATO_N_STATS]
+__global__ __launch_bounds__(RS1_T) void rs_small_batch(const float* __restrict__ Z, long M, long ldz, double alpha, unsigned k,
+                                                        int var_is_max, float thr, double* __restrict__ out) {
+  __shared__ unsigned h[B1];
+  __shared__ double red[5 * (RS1_T / RATO_WAVE)];
+  __shared__ float redmax[RS1_T / RATO_WAVE];
+  rs_small_body<RS1_T>(Z + (size_t)blockIdx.x * ldz, M, alpha, k, var_is_max, thr, out + (size_t)blockIdx.x * RATO_N_STATS, nullptr,
+                       h, red, redmax);
+}
+
 // ---- ONE launch, a FEW workgroups for RS_SMALL_MAX < M <= RS_COOP_MAX (BASELINE config C4: M = 5e4; the metric
 // config: M = 1e5).  The five launches above cost ~4 us each of dependent-launch latency for a few hundred ns of work;
 // here G <= 64 workgroups of 1024 threads keep their keys in REGISTERS (<= 16 per thread), accumulate the same three
@@ -482,6 +492,29 @@ extern "C" int rato_risk_stats_init(void* workspace, size_t workspace_bytes, voi
 extern "C" int rato_risk_stats(const float* Z, int64_t M, double alpha, float thr, void* workspace,
                                size_t workspace_bytes, double* out, void* stream) {
   return risk_stats_impl(Z, M, alpha, thr, workspace, workspace_bytes, out, nullptr, 0, 0, 1.0, nullptr, stream);
+}
+
+// The records of K rows of Z [K][ldz] (the Z of K control sequences on one sample batch: rato_*_eval_batch) -> out [K][N]:
+// one launch of K workgroups while a row fits the one-workgroup form (M <= 12,288), K stream-ordered rato_risk_stats calls
+// on the one workspace otherwise.
+extern "C" int rato_risk_stats_batch(const float* Z, int64_t M, int64_t ldz, int32_t K, double alpha, float thr, void* workspace,
+                                     size_t workspace_bytes, double* out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (!Z || !out || M <= 0 || ldz < M || K < 1 || !(alpha > 0.0) || !(alpha <= 1.0)) return RATO_EINVAL;
+  if (M <= RS_SMALL_MAX && K <= 65535) {
+    unsigned k;
+    int var_is_max;
+    stats_rank(M, alpha, k, var_is_max);
+    hipLaunchKernelGGL(rs_small_batch, dim3((unsigned)K), dim3(RS1_T), 0, rato::as_stream(stream), Z, (long)M, (long)ldz, alpha, k,
+                       var_is_max, thr, out);
+    RATO_LAUNCH_CHECK();
+    return RATO_OK;
+  }
+  for (int32_t i = 0; i < K; ++i) {
+    const int rc = rato_risk_stats(Z + (size_t)i * ldz, M, alpha, thr, workspace, workspace_bytes, out + (size_t)i * RATO_N_STATS, stream);
+    if (rc != RATO_OK) return rc;
+  }
+  return RATO_OK;
 }
 
 // Recovery path of the one-launch forms: a call that ended in NaN statistics (its wait for the workgroups of its own launch

@@ -156,24 +156,93 @@ class Model:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- rollout + separation distances (K3) -------------------------------
-    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
+    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None, out=None, stats_request=None):
+        """-> (Z [M], xs [S+1][8][M] or None, g [S][M] or None), device tensors.  ``out``: a dict whose ``_Z`` / ``_g``
+        buffers are reused.  ``stats_request`` = (workspace, record, alpha): the call also leaves the ``rato_risk_stats``
+        record of Z in ``record`` -- in the SAME launch for small batches without trajectories
+        (rato_car_eval_stats_in_launch), by ``rato_risk_stats`` behind the kernel otherwise (``mc_step_device``)."""
         dW, x0, ws, wr = inputs if inputs is not None else (self._dW, self._x0, self._ws, self._wr)
         M = ws.numel()
         us = self._us_device(us_mat)
-        Z = self._empty(M)
+        o = out if out is not None else {}
+
+        def reuse(key, shape):
+            t = o.get(key)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t
+            return self._empty(*shape)
+
+        Z = reuse("_Z", (M,))
         xs = self._empty(self.S + 1, n_x, M) if want_xs else None
-        g = self._empty(self.S, M) if want_g else None
+        g = reuse("_g", (self.S, M)) if want_g else None
+        o["_Z"], o["_g"] = Z, g
         p = self._params(M)
+        if stats_request is not None:        # (workspace, record, alpha[, in_launch])
+            stats.request_in_launch(p, *stats_request[:3], flags=(stats.STATS_IN_LAUNCH if (len(stats_request) > 3 and
+                                                                                             stats_request[3]) else 0))
         if dW is None:                                   # noise regenerated in the kernel (Philox, csrc/philox.h)
             _lib.check(self._lib.rato_car_eval_philox(C.byref(p), _lib.ptr(us), self._noise_seed, float(self.dt),
                                                       _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr),
                                                       _lib.ptr(self._scratch), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
                                                       _lib.current_stream()), "rato_car_eval_philox")
+            if stats_request is not None:
+                wsp, rec, alpha = stats_request[:3]
+                stats.risk_stats_device(Z, alpha, workspace=wsp, out=rec)
             return Z, xs, g
         _lib.check(self._lib.rato_car_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws),
                                            _lib.ptr(wr), _lib.ptr(self._scratch), _lib.ptr(Z), _lib.ptr(xs),
                                            _lib.ptr(g), _lib.current_stream()), "rato_car_eval")
         return Z, xs, g
+
+    def mc_step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, inputs=None, in_launch=False):
+        """One Monte-Carlo validation step on the device (driving.py:630-671: rollout -> max_t(-distance) -> fraction
+        satisfied / VaR / AVaR) as ONE library call -- for small batches one launch (ego tables, tiled rollout and the
+        exact selection).  -> (Z [M], record double[N_STATS]), device tensors."""
+        alpha = self.alpha if alpha is None else alpha
+        M = (inputs[2] if inputs is not None else self._ws).numel()
+        if workspace is None:
+            workspace = stats.new_workspace(M, self.device)
+        if stats_out is None:
+            stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
+        Z, _, _ = self.eval_device(us_mat, inputs=inputs, out=out, stats_request=(workspace, stats_out, alpha, in_launch))
+        return Z, stats_out
+
+    def eval_batch_device(self, us_batch, alpha=None, want_stats=True, out=None, workspace=None):
+        """K control sequences on the model's batch in ONE call (rato_car_eval_batch; the reference's Monte-Carlo report,
+        driving.py:675-740, evaluates its 4 alpha x 30 repeats one at a time).  ``us_batch`` (K, S, n_u) ->
+        (Z [K][M] device, records [K][N_STATS] device double or None); row k equals ``eval_device`` /
+        ``stats.risk_stats_device`` on sequence k to the bit."""
+        dW, x0, ws, wr = self._dW, self._x0, self._ws, self._wr
+        if dW is None:
+            raise _lib.RatoError("eval_batch_device reads a materialised dW (this Model regenerates its noise)")
+        alpha = self.alpha if alpha is None else alpha
+        M = ws.numel()
+        if isinstance(us_batch, torch.Tensor) and us_batch.is_cuda:
+            us = us_batch.float().contiguous()
+        else:
+            us = torch.as_tensor(np.ascontiguousarray(np.asarray(us_batch), dtype=np.float32), device=self.device)
+        if us.dim() != 3 or tuple(us.shape[1:]) != (self.S, n_u):
+            raise ValueError(f"us_batch must be (K,{self.S},{n_u}), got {tuple(us.shape)}")
+        K = us.shape[0]
+        o = out if out is not None else {}
+        Z = o.get("_Zb")
+        if Z is None or tuple(Z.shape) != (K, M):
+            Z = self._empty(K, M)
+        rec = workspace_ = None
+        if want_stats:
+            rec = o.get("_recb")
+            if rec is None or tuple(rec.shape) != (K, stats.N_STATS):
+                rec = torch.empty((K, stats.N_STATS), dtype=torch.float64, device=self.device)
+            workspace_ = workspace if workspace is not None else o.get("_wsb")
+            if workspace_ is None:
+                workspace_ = stats.new_workspace(M, self.device)
+        o["_Zb"], o["_recb"], o["_wsb"] = Z, rec, workspace_
+        p = self._params(M)
+        _lib.check(self._lib.rato_car_eval_batch(
+            C.byref(p), K, _lib.ptr(us), _lib.ptr(dW), _lib.ptr(x0), _lib.ptr(ws), _lib.ptr(wr), _lib.ptr(Z), M, float(alpha),
+            float(stats.SATISFIED_THRESHOLD), _lib.ptr(workspace_), workspace_.numel() if workspace_ is not None else 0,
+            _lib.ptr(rec), _lib.current_stream()), "rato_car_eval_batch")
+        return Z, rec
 
     def us_to_state_trajectories(self, us_mat):
         """driving.py:205-214 -> (M, S+1, n_x)."""
@@ -547,8 +616,14 @@ class Model:
         return Zh <= 1e-6, Zh
 
     def monte_carlo_statistics(self, us_mat, alpha=None):
-        Z, _, _ = self.eval_device(us_mat)
-        return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
+        """rollout -> Z -> fraction satisfied, VaR, CVaR (``mc_step_device``); a NaN record on finite Z is recovered
+        through ``stats.risk_stats``."""
+        alpha = self.alpha if alpha is None else alpha
+        Z, rec = self.mc_step_device(us_mat, alpha)
+        r = rec.cpu().numpy()
+        if np.isnan(r[0]):
+            return stats.risk_stats(Z, alpha)
+        return dict(zip(stats._STAT_NAMES, r.tolist()))
 
     monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
 

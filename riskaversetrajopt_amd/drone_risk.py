@@ -170,25 +170,95 @@ class Model:
         return self._empty(*shape) if shape[-1] == M else torch.zeros(shape, dtype=torch.float32, device=self.device)
 
     # ---- rollout + constraint values (K1) ----------------------------------
-    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None):
+    def eval_device(self, us_mat, want_xs=False, want_g=False, inputs=None, out=None, stats_request=None):
         """-> (Z [M], xs [S+1][6][M] or None, g [n_obs][S][M] or None): device tensors
-        (views of row-stride-ld buffers)."""
+        (views of row-stride-ld buffers).
+        ``out``: a dict whose ``_Z`` / ``_g`` buffers (shapes of an earlier call) are reused.
+        ``stats_request`` = (workspace, record, alpha): the call also leaves the ``rato_risk_stats`` record of Z in
+        ``record`` (double[N_STATS], device) -- in the SAME launch for small batches without trajectories
+        (rato_drone_eval_stats_in_launch), by ``rato_risk_stats`` behind the kernel otherwise (``mc_step_device``)."""
         dW, mass, Qsym, M = self._inputs(inputs)
         ld = mass.numel()
         us = self._us_device(us_mat)
-        Z = self._empty(ld)
+        o = out if out is not None else {}
+
+        def reuse(key, shape):
+            t = o.get(key)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t
+            return self._empty(*shape)
+
+        Z = reuse("_Z", (ld,))
         xs = self._empty(self.S + 1, n_x, ld) if want_xs else None
-        g = self._empty(n_obs, self.S, ld) if want_g else None
+        g = reuse("_g", (n_obs, self.S, ld)) if want_g else None
+        o["_Z"], o["_g"] = Z, g
         p = self._params(M, ld)
+        if stats_request is not None:        # (workspace, record, alpha[, in_launch])
+            stats.request_in_launch(p, *stats_request[:3], flags=(stats.STATS_IN_LAUNCH if (len(stats_request) > 3 and
+                                                                                             stats_request[3]) else 0))
         if dW is None:                                   # noise regenerated in the kernel (Philox, csrc/philox.h)
             _lib.check(self._lib.rato_drone_eval_philox(C.byref(p), _lib.ptr(us), self._noise_seed, self._sampler_dt,
                                                         _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs),
                                                         _lib.ptr(g), _lib.current_stream()), "rato_drone_eval_philox")
+            if stats_request is not None:
+                ws, rec, alpha = stats_request[:3]
+                stats.risk_stats_device(Z[:M], alpha, workspace=ws, out=rec)
             return Z[:M], (xs[..., :M] if want_xs else None), (g[..., :M] if want_g else None)
         _lib.check(self._lib.rato_drone_eval(C.byref(p), _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass),
                                              _lib.ptr(Qsym), _lib.ptr(Z), _lib.ptr(xs), _lib.ptr(g),
                                              _lib.current_stream()), "rato_drone_eval")
         return Z[:M], (xs[..., :M] if want_xs else None), (g[..., :M] if want_g else None)
+
+    def mc_step_device(self, us_mat, alpha=None, out=None, workspace=None, stats_out=None, inputs=None, in_launch=False):
+        """One Monte-Carlo validation step on the device (drone_risk.py:711-714: rollout -> max over (obstacle, t) ->
+        fraction satisfied / VaR / AVaR) as ONE library call -- for small batches one launch.
+        -> (Z [M], record double[N_STATS]), device tensors; ``out`` / ``workspace`` / ``stats_out`` are reused when given
+        (a captured step must pass them)."""
+        alpha = self.alpha if alpha is None else alpha
+        M = self._inputs(inputs)[3]
+        if workspace is None:
+            workspace = stats.new_workspace(M, self.device)
+        if stats_out is None:
+            stats_out = torch.empty(stats.N_STATS, dtype=torch.float64, device=self.device)
+        Z, _, _ = self.eval_device(us_mat, inputs=inputs, out=out, stats_request=(workspace, stats_out, alpha, in_launch))
+        return Z, stats_out
+
+    def eval_batch_device(self, us_batch, alpha=None, want_stats=True, out=None, workspace=None):
+        """K control sequences on the model's batch in ONE call (rato_drone_eval_batch): what the reference's Monte-Carlo
+        report does one sequence at a time for its 4 alpha x 30 repeats (drone_risk.py:697-725).  ``us_batch``
+        (K, S, n_u) -> (Z [K][M] device, records [K][N_STATS] device double or None).  Row k equals, to the bit, what
+        ``eval_device`` / ``stats.risk_stats_device`` give for sequence k."""
+        dW, mass, Qsym, M = self._inputs(None)
+        if dW is None:
+            raise _lib.RatoError("eval_batch_device reads a materialised dW (this Model regenerates its noise)")
+        alpha = self.alpha if alpha is None else alpha
+        if isinstance(us_batch, torch.Tensor) and us_batch.is_cuda:
+            us = us_batch.float().contiguous()
+        else:
+            us = torch.as_tensor(np.ascontiguousarray(np.asarray(us_batch), dtype=np.float32), device=self.device)
+        if us.dim() != 3 or tuple(us.shape[1:]) != (self.S, n_u):
+            raise ValueError(f"us_batch must be (K,{self.S},{n_u}), got {tuple(us.shape)}")
+        K, ld = us.shape[0], mass.numel()
+        o = out if out is not None else {}
+        Z = o.get("_Zb")
+        if Z is None or tuple(Z.shape) != (K, ld):
+            Z = self._empty(K, ld)
+        rec = None
+        if want_stats:
+            rec = o.get("_recb")
+            if rec is None or tuple(rec.shape) != (K, stats.N_STATS):
+                rec = torch.empty((K, stats.N_STATS), dtype=torch.float64, device=self.device)
+            if workspace is None:
+                workspace = o.get("_wsb")
+            if workspace is None:
+                workspace = stats.new_workspace(M, self.device)
+        o["_Zb"], o["_recb"], o["_wsb"] = Z, rec, workspace
+        p = self._params(M, ld)
+        _lib.check(self._lib.rato_drone_eval_batch(
+            C.byref(p), K, _lib.ptr(us), _lib.ptr(dW), _lib.ptr(mass), _lib.ptr(Qsym), _lib.ptr(Z), ld, float(alpha),
+            float(stats.SATISFIED_THRESHOLD), _lib.ptr(workspace), workspace.numel() if workspace is not None else 0,
+            _lib.ptr(rec), _lib.current_stream()), "rato_drone_eval_batch")
+        return Z[:, :M], rec
 
     def us_to_state_trajectories(self, us_mat):
         """drone_risk.py:157-162 -> (M, S+1, n_x)."""
@@ -800,9 +870,15 @@ class Model:
         return Zh <= 1e-6, Zh
 
     def monte_carlo_statistics(self, us_mat, alpha=None):
-        """Fused device path: rollout -> Z -> fraction satisfied, VaR, CVaR."""
-        Z, _, _ = self.eval_device(us_mat)
-        return stats.risk_stats(Z, self.alpha if alpha is None else alpha)
+        """Fused device path: rollout -> Z -> fraction satisfied, VaR, CVaR (``mc_step_device``: one call, for small
+        batches one launch).  A NaN record on finite Z (a one-launch selection that gave up) is recovered through
+        ``stats.risk_stats``."""
+        alpha = self.alpha if alpha is None else alpha
+        Z, rec = self.mc_step_device(us_mat, alpha)
+        r = rec.cpu().numpy()
+        if np.isnan(r[0]):
+            return stats.risk_stats(Z, alpha)
+        return dict(zip(stats._STAT_NAMES, r.tolist()))
 
     monte_carlo_avar = staticmethod(stats.monte_carlo_avar)
     monte_carlo_var = staticmethod(stats.monte_carlo_var)

@@ -76,7 +76,10 @@ def risk_stats_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=Non
 FUSED_MAX_M = 524288               # 64 statistics workgroups x 512 threads x 16 keys
 
 
-def request_in_launch(params, workspace, out, alpha, thr=SATISFIED_THRESHOLD):
+STATS_IN_LAUNCH = 1                # RATO_STATS_IN_LAUNCH (params.stats_flags): rato_*_eval computes them in its own launch
+
+
+def request_in_launch(params, workspace, out, alpha, thr=SATISFIED_THRESHOLD, flags=0):
     """Fill the ``stats_*`` fields of a ``rato_drone_params`` / ``rato_car_params``: the row-parallel linearize launch
     given these params then also leaves the ``rato_risk_stats`` record of the Z it produces in ``out`` (device
     double[N_STATS]) -- computed by extra workgroups at the end of its grid as soon as the last tile's Z has landed,
@@ -87,6 +90,7 @@ def request_in_launch(params, workspace, out, alpha, thr=SATISFIED_THRESHOLD):
     params.stats_out = out.data_ptr()
     params.stats_alpha = float(alpha)
     params.stats_thr = float(thr)
+    params.stats_flags = int(flags)
 
 
 def risk_stats_recover_device(Z, alpha, thr=SATISFIED_THRESHOLD, workspace=None, out=None, stream=None):

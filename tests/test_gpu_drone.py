@@ -437,4 +437,4 @@ def test_in_place_noise_refill_needs_and_honours_invalidate():
         drone_risk.Model.TILED_NOISE = True
     assert torch.equal(b, c) and not torch.equal(a, b)
     with pytest.raises(ValueError):
-        d.set_noise(dW2[:, :2])
+        d.set_noise(dW2[:, :2].contiguous())
