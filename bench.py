@@ -72,10 +72,13 @@ def parse():
                     help="N=1: replay the step as ONE captured hipGraph (kernel time then comes from an eager pre-pass "
                          "with HIP events, since events cannot bracket a node inside a graph).  auto = on for "
                          "M <= 50,000 (BASELINE C2-C4), where an eager step is bound by host launch time, not by the GPU")
-    ap.add_argument("--overlap", action="store_true",
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=None,
                     help="run the exchange + risk statistics of step i on a side stream while the hot kernel of step "
-                         "i+1 runs (two output slots).  Off by default: measured on one GPU it gains nothing (the step "
-                         "is the dominant kernel + 7 us of partial sums + launch gaps; DESIGN.md 5)")
+                         "i+1 runs (two output slots; dist.PipelinedSteps).  DEFAULT FOR N > 1: every rank runs the exact "
+                         "selection on all M_total gathered samples, which at C5 (1e6) is a third of the shard's kernel "
+                         "time when paid behind it.  Off by default at N = 1, where it gains nothing (DESIGN.md 5)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="N > 1: kernel -> sums -> all-gather -> selection serially on one stream (A/B against the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` block (BASELINE C2-C5 as whole steps after the metric configuration)")
@@ -480,27 +483,38 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     use_graph = world == 1 and not args.overlap and (args.graph == "on" or (args.graph == "auto" and M <= 50000))
     pipelined = args.overlap and not use_graph
-    main_stream = torch.cuda.current_stream()
-    side = torch.cuda.Stream() if pipelined else main_stream
-    ev_lin = [torch.cuda.Event() for _ in range(2)]       # hot kernel of the slot finished
-    ev_free = [torch.cuda.Event() for _ in range(2)]      # statistics of the slot finished (its buffers are free)
+    # N > 1 (default) / --overlap: the exchange + statistics of step n beside the hot kernel of step n+1 (dist.PipelinedSteps)
+    pipe = rdist.PipelinedSteps(2, device) if pipelined else None
     counter = [0]
     in_launch = (world == 1 and not pipelined and hasattr(work, "stats_in_launch") and work.stats_in_launch()
                  and not os.environ.get("RATO_BENCH_NO_IN_LAUNCH"))
 
+    def finish(slot, r):
+        """sample sums -> [one all-gather of the record when N > 1] -> exact VaR / CVaR / fraction satisfied"""
+        sums = work.sums(r)
+        if getattr(work, "records", None):                # zero-copy record: [sums | Z] already in place
+            sums, Z_all = rdist.exchange_record(work.records[slot])
+        else:
+            sums, Z_all = rdist.exchange(sums, r["Z"], agreed=True)   # the one collective (no-op at N=1; equal shards
+            #                                                            were verified once, above)
+        stats.risk_stats_device(Z_all, args.alpha, workspace=wss[slot], out=stats_out[slot])
+        return sums
+
     def step(i=None):
         """One pass of the hot path: dominant kernel -> partial sums -> [one all-gather of the record when N > 1] ->
-        exact VaR / CVaR / fraction satisfied.  (--overlap: the exchange + statistics of step n run on a side
-        stream beside the hot kernel of step n+1; both streams are drained before the clock stops.)"""
+        exact VaR / CVaR / fraction satisfied.  (Pipelined: the exchange + statistics of step n run on a side stream
+        beside the hot kernel of step n+1; both streams are drained before the clock stops.)"""
+        if pipelined:
+            slot = pipe.step(lambda s: work.hot_kernel(events=ev[i] if i is not None else None, slot=s), finish)
+            counter[0] += 1
+            return None
         slot = counter[0] & 1
         counter[0] += 1
-        if pipelined:
-            main_stream.wait_event(ev_free[slot])
-        if in_launch:   # small batches: the linearize launch carries the statistics of its Z (+ the sample sums behind it)
+        if in_launch:   # small batches: the kernel's own launch carries the statistics of its Z (+ the sample sums behind it)
             r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot,
                                 stats_request=(wss[slot], stats_out[slot], args.alpha))
             return work.sums(r)
-        fold = (world == 1 and isinstance(work, (DroneWork, HopperWork)) and work.mode == "linearize" and not pipelined
+        fold = (world == 1 and isinstance(work, (DroneWork, HopperWork)) and work.mode == "linearize"
                 and not os.environ.get("RATO_BENCH_NO_FOLD"))
         if fold:       # single GPU: linearize, then ONE launch for the sample sums + VaR / CVaR (2 launches per step)
             r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot, reduce=False)
@@ -508,26 +522,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
                                                        sums_out=r.get("sums"), out=stats_out[slot])
             return sums
         r = work.hot_kernel(events=ev[i] if i is not None else None, slot=slot)
-        if pipelined:
-            ev_lin[slot].record(main_stream)
-        # (only when pipelined: inside a hipGraph capture the current stream is the CAPTURE stream, and switching to a
-        #  stream looked up earlier would take the statistics launches out of the captured step)
-        with (torch.cuda.stream(side) if pipelined else contextlib.nullcontext()):
-            if pipelined:
-                side.wait_event(ev_lin[slot])
-            sums = work.sums(r)
-            if pipelined:
-                for t in (sums, r["Z"]):
-                    t.record_stream(side)
-            if getattr(work, "records", None):                # zero-copy record: [sums | Z] already in place
-                sums, Z_all = rdist.exchange_record(work.records[slot])
-            else:
-                sums, Z_all = rdist.exchange(sums, r["Z"], agreed=True)   # the one collective (no-op at N=1; equal
-                #                                                            shards were verified once, below)
-            stats.risk_stats_device(Z_all, args.alpha, workspace=wss[slot], out=stats_out[slot])
-            if pipelined:
-                ev_free[slot].record(side)
-        return sums
+        return finish(slot, r)
 
     # setup, not part of the W warm-up steps or of the timed region: ~10 ms of the hot kernel so that a short run
     # (e.g. K = 20, W = 3) does not time the first launches at idle clocks (measured: 0.301 vs 0.289 ms per step)
@@ -536,6 +531,8 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.drain()
     if use_graph:
         # eager pre-pass: per-launch kernel time with HIP events.  The launches are queued BEHIND a spin kernel long
         # enough for the host to issue all of them, so the events bracket back-to-back GPU work and the host's issue
@@ -565,6 +562,8 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             graph.replay()
         else:
             step(i)
+    if pipe is not None:
+        pipe.drain()                                     # the last step's exchange + statistics: inside the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -598,7 +597,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             print(f"note: clock probe skipped ({e})", file=sys.stderr)
     final_stats = stats_out[(counter[0] - 1) & 1].cpu().numpy()
     launch = ("hipGraph replay of the whole step" + (" (the statistics ride in the kernel's own launch)" if in_launch else "")) if use_graph else (
-        "eager; exchange + VaR/CVaR of step n on a side stream overlap the hot kernel of step n+1"
+        "eager; exchange + VaR/CVaR of step n on a side stream beside the hot kernel of step n+1 (dist.PipelinedSteps)"
         if pipelined else "eager, one stream, no overlap between steps")
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
                 "GPU, host issue rate excluded), mean over K launches" if use_graph
@@ -750,6 +749,111 @@ def mc_batch_block(work, torch, K=120):
             "value": work.M * work.S * K / per_call, "unit": "samples*steps/s", "launch": "eager, one library call per batch"}
 
 
+def c5_rank_local_block(work, args, device, stats, rdist, torch, world=8, K=100):
+    """What EVERY rank of the 8-GPU C5 run pays locally per step, measured on this one GPU: its shard's kernel (125,000
+    samples) and, for the exchange, everything but the wire -- rato_unpack_records over `world` records and the exact
+    selection over all M_total = 1e6 gathered samples -- serially behind the kernel and pipelined beside the next step's
+    kernel (dist.PipelinedSteps, the N > 1 default).  The records of the other ranks are copies of this rank's."""
+    from riskaversetrajopt_amd import _lib
+    lib = _lib.load()
+    M, rec = work.M, work.records[0]
+    all_ = rec.buf.repeat(world).contiguous()
+    Z_all = torch.empty(world * M, dtype=torch.float32, device=device)
+    total = torch.empty(max(rec.n_sums, 1), dtype=torch.float64, device=device)
+    ws = [stats.new_workspace(world * M, device) for _ in range(2)]
+    out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
+
+    def local_exchange(slot, r=None):
+        _lib.check(lib.rato_unpack_records(_lib.ptr(all_), world, rec.n_sums, M, rec.rec_bytes, _lib.ptr(total),
+                                           _lib.ptr(Z_all), _lib.current_stream()), "rato_unpack_records")
+        stats.risk_stats_device(Z_all, args.alpha, workspace=ws[slot], out=out[slot])
+
+    def timed(fn, reps):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def events_us(fn, reps=50):
+        torch.cuda._sleep(20_000_000)                     # the launches queue up behind a spin: back-to-back device time
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / reps
+    unpack_us = events_us(lambda: _lib.check(lib.rato_unpack_records(
+        _lib.ptr(all_), world, rec.n_sums, M, rec.rec_bytes, _lib.ptr(total), _lib.ptr(Z_all), _lib.current_stream()), "unpack"))
+    select_us = events_us(lambda: stats.risk_stats_device(Z_all, args.alpha, workspace=ws[0], out=out[0]))
+    kernel_us = events_us(lambda: work.hot_kernel(slot=0), 30)
+    serial_us = timed(lambda: (work.hot_kernel(slot=0), local_exchange(0)), K)
+    pipe = rdist.PipelinedSteps(2, device)
+
+    def piped():
+        pipe.step(lambda s: work.hot_kernel(slot=s), local_exchange)
+    piped_us = timed(piped, K)
+    pipe.drain()
+    return {"world": world, "M_total": world * M,
+            "kernel_us": kernel_us, "unpack_records_us": unpack_us, "selection_M_total_us": select_us,
+            "step_serial_us": serial_us, "step_pipelined_us": piped_us,
+            "what": "one GPU: shard kernel + rato_unpack_records(world records) + exact selection over M_total samples; "
+                    "eager steps, wall-clock per step over %d steps; kernel / unpack / selection alone by HIP events, "
+                    "back to back.  The wire time of the all-gather (4 MB in total over xGMI) is NOT in these numbers" % K}
+
+
+def beyond_cache_block(args, device, stats, rdist, dist, torch):
+    """The headline kernel where the memory-side cache cannot help: drone_risk linearize, products, M = 300,000 (180 MB of
+    noise: beyond the 128 MB up to which the launcher keeps the inputs cached by writing the 9 GB Jacobian with streaming
+    stores; rato_drone_rows_streaming_stores says 0) -- every input comes from HBM on every launch.  Same protocol as the
+    main line, K = 12 steps."""
+    import copy
+    from riskaversetrajopt_amd import _lib
+    a = copy.copy(args)
+    a.config, a.workload, a.M, a.S, a.steps, a.warmup = "metric", "drone", 300000, 50, 12, 3
+    a.mode, a.philox, a.overlap, a.graph = "linearize", False, False, "off"
+    a.packed_products, a.force_factored, a.cols_per_thread, a.samples_per_lane = True, False, 0, 0
+    work = WORKLOADS["drone"](a, device, seed=7)
+    res = timed_region(work, a, 1, 0, device, stats, rdist, dist, torch, probe_clock=False)
+    rb = roofline_block(work, res["kern_ms"], "drone", "linearize", work.M, work.S, "products", res["kern_src"])
+    out = {"workload": f"drone_risk linearize M={work.M} S={work.S}, Jacobian written as products",
+           "streaming_stores": bool(_lib.load().rato_drone_rows_streaming_stores(work.M, work.S, 0)),
+           "noise_bytes": work.M * work.S * 12, "kernel": rb["kernel"], "kernel_ms": res["kern_ms"],
+           "achieved": rb["achieved"], "peak": rb["peak"], "unit": "GB/s", "frac": rb["frac"],
+           "algorithmic_bytes_per_launch": rb["algorithmic_bytes_per_launch"],
+           "ms_per_step": 1e3 * res["elapsed"] / a.steps, "value": work.M * work.S * a.steps / res["elapsed"]}
+    del work
+    torch.cuda.empty_cache()
+    return out
+
+
+def c5_prediction_block(c5, args, device, stats, rdist, dist, torch):
+    """BASELINE C5 as a whole -- driving M = 1e6 -- on ONE GPU (the strong-scaling reference), against what a rank of the
+    8-GPU run pays locally (``rank_local``): the predicted 8-GPU step and speed-up, wire time of the one all-gather NOT
+    included (no multi-GPU node in this pool; 4 MB in total, ~0.5 MB per peer link)."""
+    import copy
+    a = copy.copy(args)
+    a.config, a.workload, a.M, a.S, a.steps, a.warmup = "C5", "driving", 1000000, 40, 10, 2
+    a.mode, a.philox, a.overlap, a.graph = "linearize", False, False, "off"
+    a.packed_products, a.force_factored, a.cols_per_thread, a.samples_per_lane = True, False, 0, 0
+    work = WORKLOADS["driving"](a, device, seed=7)
+    res = timed_region(work, a, 1, 0, device, stats, rdist, dist, torch, probe_clock=False)
+    one_gpu_us = 1e6 * res["elapsed"] / a.steps
+    del work
+    torch.cuda.empty_cache()
+    rl = c5["rank_local"]
+    return {"one_gpu_M_1e6_step_us": one_gpu_us, "one_gpu_M_1e6_kernel_us": 1e3 * res["kern_ms"],
+            "step_serial_us": rl["step_serial_us"], "step_pipelined_us": rl["step_pipelined_us"],
+            "speedup_serial": one_gpu_us / rl["step_serial_us"], "speedup_pipelined": one_gpu_us / rl["step_pipelined_us"],
+            "target": ">= 6x at 8 GPUs (BASELINE.json north_star)", "wire": "unknown, not included: the all-gather of 8 x 0.5 MB "
+            "records; pipelined it has a whole kernel time (%.0f us) to hide in" % rl["kernel_us"]}
+
+
 def configs_block(args, device, stats, rdist, dist, torch):
     """BASELINE.json's other single-GPU configurations (C2 drone M=1e4 S=50, C3 driving M=1e4 S=40, C4 hopper M=5e4
     S=60 / 40 contacts, C5's shard: driving 125,000 samples per GPU S=40) as whole steps, after and outside the timed
@@ -783,6 +887,11 @@ def configs_block(args, device, stats, rdist, dist, torch):
                          "algorithmic_bytes_per_launch": rb["algorithmic_bytes_per_launch"],
                          "traffic_from_profile": rb["traffic_from_profile"], "launch": res["launch"],
                          "stats": {"VaR": res["stats"][0], "CVaR": res["stats"][1], "frac_satisfied": res["stats"][2]}}
+            if name == "C5":
+                try:
+                    out[name]["rank_local"] = c5_rank_local_block(work, a, device, stats, rdist, torch)
+                except Exception as e:                     # noqa: BLE001
+                    out[name]["rank_local"] = {"error": repr(e)}
             if mode == "eval":
                 out[name]["form"] = ("the reference's Monte-Carlo validation step (rollout -> max -> fraction / VaR / AVaR), one "
                                      "control sequence per replayed step: rollout kernel + exact selection, two nodes")
@@ -829,6 +938,8 @@ def main():
         return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.overlap is None:
+        args.overlap = world > 1
 
     is_drone_lin = args.workload == "drone" and args.mode == "linearize"
     variants = [None]
@@ -908,6 +1019,22 @@ def main():
                         delattr(w, attr)
             torch.cuda.empty_cache()
             line["configs"] = configs_block(args, device, stats, rdist, dist, torch)
+            try:
+                line["configs"]["C5"]["predicted_8gpu"] = c5_prediction_block(line["configs"]["C5"], args, device, stats, rdist,
+                                                                               dist, torch)
+            except Exception as e:                        # noqa: BLE001
+                line["configs"]["C5"]["predicted_8gpu"] = {"error": repr(e)}
+            try:                                          # the cache-independent figure next to the headline
+                line["roofline_beyond_cache"] = beyond_cache_block(args, device, stats, rdist, dist, torch)
+                p8 = line["configs"]["C5"].get("predicted_8gpu", {})
+                if "one_gpu_M_1e6_kernel_us" in p8:       # driving M = 1e6 (320 MB of noise): measured for the C5 prediction
+                    alg = 1000000 * 4 * (2 * 40 + 6 + 1) + 2 * 40 * 4 + 1000000 * 4 * (40 + 40 * 39)
+                    gbps = alg / (p8["one_gpu_M_1e6_kernel_us"] * 1e-6) / 1e9
+                    line["roofline_beyond_cache"]["driving_M_1e6"] = {
+                        "kernel": "car_linearize_rows_kernel", "kernel_ms": p8["one_gpu_M_1e6_kernel_us"] * 1e-3,
+                        "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg}
+            except Exception as e:                        # noqa: BLE001
+                line["roofline_beyond_cache"] = {"error": repr(e)}
             try:
                 line["configs"]["launch_floor"] = launch_floor_block(device, torch)
             except Exception as e:                        # noqa: BLE001

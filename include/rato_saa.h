@@ -253,6 +253,11 @@ int rato_risk_stats_batch(const float* Z, int64_t M, int64_t ldz, int32_t K, dou
  * in its own launch for this batch (small batches), 0 when it would issue rato_risk_stats behind the kernel. */
 int rato_drone_stats_in_launch(int32_t M, int32_t S);
 int rato_car_stats_in_launch(int32_t M, int32_t S);
+/* 1 when the row-parallel linearize kernel would write this batch's Jacobian with streaming (non-temporal) stores: the
+ * output is far beyond the 256 MB memory-side cache (>= 256 MB) and the batch's noise fits it (<= 128 MB), so that the
+ * noise stays cached from one linearization to the next.  factored: the drone's (Phi, W) output. */
+int rato_drone_rows_streaming_stores(int64_t M, int32_t S, int32_t factored);
+int rato_car_rows_streaming_stores(int64_t M, int32_t S);
 
 typedef struct rato_car_params {
   int32_t M;

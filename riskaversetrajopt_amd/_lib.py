@@ -164,6 +164,8 @@ SIGNATURES = {
     "rato_risk_stats": (C.c_int, [c_float_p, C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t,
                                   c_float_p, c_stream]),
     "rato_drone_stats_in_launch": (C.c_int, [C.c_int32, C.c_int32]),
+    "rato_drone_rows_streaming_stores": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
+    "rato_car_rows_streaming_stores": (C.c_int, [C.c_int64, C.c_int32]),
     "rato_drone_eval_stats_in_launch": (C.c_int, [C.c_int32]),
     "rato_drone_eval_batch": (C.c_int, [C.POINTER(DroneParams), C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                         C.c_int64, C.c_double, C.c_float, C.c_void_p, C.c_size_t, c_float_p, c_stream]),

@@ -1210,6 +1210,14 @@ constexpr size_t CAR_ROWS_LDS_MAX = 160 * 1024;
 size_t car_rows_lds_bytes(int S) { return car_rows_lds_floats(S) * sizeof(float); }
 }  // namespace
 
+// the launcher's store policy for the row-parallel kernel (see rato_drone_rows_streaming_stores)
+extern "C" int rato_car_rows_streaming_stores(int64_t M, int32_t S) {
+  static const int nt_env = [] { const char* e = getenv("RATO_NT_STORES"); return e ? atoi(e) : 1; }();
+  const double out_bytes = (double)M * (double)rato::pair_row_offset(S) * 2.0 * 4.0;
+  const double in_bytes = (double)M * S * 2.0 * 4.0;
+  return (nt_env == 2 || (nt_env == 1 && out_bytes >= 256e6 && in_bytes <= 128e6)) ? 1 : 0;
+}
+
 extern "C" int rato_car_linearize_plan(int32_t M, int32_t S, int32_t* cols_per_thread, int32_t* tile) {
   if (M <= 0 || S <= 0 || !cols_per_thread || !tile) return RATO_EINVAL;
   int c = *cols_per_thread;
@@ -1327,10 +1335,7 @@ int car_linearize_impl(const rato_car_params* p, const float* us, const float* d
     dim3 grid(grid_launch), block(CROWS_NW * RATO_WAVE);
     // streaming stores for the Jacobian when the output is far beyond the memory-side cache and the inputs fit (drone.hip):
     // C5 shard (800 MB out, 40 MB in) -11.7 %; M = 1e6 (6.4 GB out, 320 MB in) ordinary stores (+2 % with streaming ones)
-    static const int nt_env = [] { const char* e = getenv("RATO_NT_STORES"); return e ? atoi(e) : 1; }();
-    const double out_bytes = (double)p->M * (double)rato::pair_row_offset(p->S) * 2.0 * 4.0;
-    const double in_bytes = (double)p->M * p->S * 2.0 * 4.0;
-    const bool nt_stores = nt_env == 2 || (nt_env == 1 && out_bytes >= 256e6 && in_bytes <= 128e6);
+    const bool nt_stores = rato_car_rows_streaming_stores(p->M, p->S) != 0;
     if (queue) {
       // the last `tail_tiles` tiles of the queue as `tail_split` parts each (RATO_CAR_TAIL_SPLIT / RATO_CAR_TAIL_TILES).
       // OFF by default: unlike the drone's products output it does not pay here -- C5 shard (M = 125,000, 1954 tiles

@@ -1650,10 +1650,7 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
     }
     // streaming stores for the Jacobian: when the output cannot stay in the 256 MB memory-side cache anyway and the batch's
     // inputs (the noise) can -- RATO_NT_STORES=0 never / 2 always (A/B).  M = 1e5, S = 50: 3 GB out, 60 MB in: yes.
-    static const int nt_env = [] { const char* e = getenv("RATO_NT_STORES"); return e ? atoi(e) : 1; }();
-    const double out_bytes = (double)p->M * (double)rato::pair_row_offset(p->S) * (W ? 2.0 : 6.0) * 4.0;
-    const double in_bytes = (double)p->M * p->S * 3.0 * 4.0;
-    const bool nt_stores = nt_env == 2 || (nt_env == 1 && out_bytes >= 256e6 && in_bytes <= 128e6);
+    const bool nt_stores = rato_drone_rows_streaming_stores(p->M, p->S, W ? 1 : 0) != 0;
 #define RATO_ROWS_LAUNCH(F, PH)                                                                                     \
   hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid_launch), dim3(ROWS_NW * RATO_WAVE), lds_launch, st, \
                      *p, n_whole, split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, \
@@ -1684,6 +1681,15 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
   return RATO_EINVAL;
 }
 }  // namespace
+
+// The launcher's store policy for the row-parallel kernel (1: the Jacobian goes out as streaming stores): when the output
+// cannot stay in the 256 MB memory-side cache anyway (>= 256 MB) and the batch's noise can (<= 128 MB).
+extern "C" int rato_drone_rows_streaming_stores(int64_t M, int32_t S, int32_t factored) {
+  static const int nt_env = [] { const char* e = getenv("RATO_NT_STORES"); return e ? atoi(e) : 1; }();
+  const double out_bytes = (double)M * (double)rato::pair_row_offset(S) * (factored ? 2.0 : 6.0) * 4.0;
+  const double in_bytes = (double)M * S * 3.0 * 4.0;
+  return (nt_env == 2 || (nt_env == 1 && out_bytes >= 256e6 && in_bytes <= 128e6)) ? 1 : 0;
+}
 
 extern "C" int rato_drone_linearize(const rato_drone_params* p, const float* us, const float* dW,
                                     const float* mass, const float* Qsym, float* G, float* W, float* A22,

@@ -362,3 +362,68 @@ def broadcast_from_rank0(arr, device, group=None):
         t = t.to(device)
     dist.broadcast(t, src=0, group=group)
     return t.cpu().numpy()
+
+
+# ---- the N > 1 step as a two-slot software pipeline ---------------------------------------------------------------------
+class PipelinedSteps:
+    """[hot kernel of step n + 1]  beside  [exchange + statistics of step n].
+
+    The one exchange of an evaluation and the exact selection on the gathered Z (``M_total`` samples on EVERY rank) are
+    small, latency-bound work behind a kernel that saturates the store path: issued on the same stream they are paid
+    in full on every step (C5: 0.154 ms of kernel + the sums + an all-gather + a selection over 1e6 samples).  Here a step
+    ``produce``s into one of ``n_slots`` output slots on the caller's stream, and the ``consume`` of the PREVIOUS step --
+    exchange, unpack, statistics, on the previous slot -- is issued to a side stream right behind it, so that it runs
+    beside the producer of this step.  A slot is reused only after its consumer has finished (events).  ``drain()`` issues
+    the last consumer and waits for both streams: results are complete, and identical to the serial order bit for bit
+    (same kernels on the same buffers; tests/test_dist_gloo.py, tests/test_gpu_dist.py).
+
+    Host tensors / no GPU (the gloo tests of the logic): no streams, the same ISSUE order -- produce(n + 1), then
+    consume(n)."""
+
+    def __init__(self, n_slots=2, device=None):
+        self.n_slots = int(n_slots)
+        self.cuda = bool(device is not None and torch.device(device).type == "cuda")
+        self.pending = None
+        self.results = [None] * self.n_slots
+        self.issued = []                                  # ("produce" | "consume", step): the order work was issued in
+        self._step = 0
+        if self.cuda:
+            self.main = torch.cuda.current_stream(device)
+            self.side = torch.cuda.Stream(device)
+            self.ev_done = [torch.cuda.Event() for _ in range(self.n_slots)]
+            self.ev_free = [torch.cuda.Event() for _ in range(self.n_slots)]
+
+    def step(self, produce, consume):
+        """``produce(slot)`` -> anything (handed to ``consume(slot, produced)`` one step later, whose return value lands in
+        ``results[slot]``).  -> slot used."""
+        slot = self._step % self.n_slots
+        if self.cuda:
+            self.main.wait_event(self.ev_free[slot])     # the consumer that last read this slot has finished
+        out = produce(slot)
+        self.issued.append(("produce", self._step))
+        if self.cuda:
+            self.ev_done[slot].record(self.main)
+        self._flush()                                     # the previous step's consumer: beside this step's producer
+        self.pending = (slot, consume, out, self._step)
+        self._step += 1
+        return slot
+
+    def _flush(self):
+        if self.pending is None:
+            return
+        slot, consume, out, n = self.pending
+        self.pending = None
+        if self.cuda:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_done[slot])
+                self.results[slot] = consume(slot, out)
+                self.ev_free[slot].record(self.side)
+        else:
+            self.results[slot] = consume(slot, out)
+        self.issued.append(("consume", n))
+
+    def drain(self):
+        self._flush()
+        if self.cuda:
+            self.side.synchronize()
+            self.main.synchronize()

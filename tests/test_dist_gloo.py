@@ -162,3 +162,71 @@ def test_comm_selfcheck_agrees_on_every_rank(tmp_path):
     assert not res[0]["bad"]["ok"] and not res[0]["bad"]["identical_on_every_rank"]
     from riskaversetrajopt_amd import dist as rdist
     assert rdist.comm_selfcheck(None)["ok"]                 # single process: nothing to check
+
+
+# ---- round 5: the N > 1 step as a two-slot pipeline (dist.PipelinedSteps: what bench.py --gpus N runs by default) ----------
+def _pipeline_worker(rank, world, port, M_local, K, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import stats as ostats
+    from riskaversetrajopt_amd import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    alpha, n_sums = 0.1, 5
+
+    def data(n):                                         # this rank's shard of step n
+        rng = np.random.RandomState(1000 * n + rank)
+        return torch.from_numpy(rng.randn(M_local).astype(np.float32) - 1.0), torch.from_numpy(rng.randn(n_sums))
+
+    def statistics(total, Z_all):
+        Z = Z_all.numpy().astype(np.float64)
+        return np.concatenate([[ostats.monte_carlo_var(Z, alpha), ostats.monte_carlo_avar(Z, alpha), np.mean(Z <= 1e-6)],
+                               total.numpy()])
+
+    # serial order: produce(n), exchange(n), statistics(n)
+    rec = rdist.Record(n_sums, M_local, "cpu")
+    serial = []
+    for n in range(K):
+        Z, sums = data(n)
+        rec.Z.copy_(Z)
+        rec.sums.copy_(sums)
+        serial.append(statistics(*rdist.exchange_record(rec)))
+    # pipelined order: produce(n + 1) is issued BEFORE the exchange + statistics of step n, two output slots
+    recs = [rdist.Record(n_sums, M_local, "cpu"), rdist.Record(n_sums, M_local, "cpu")]
+    pipe = rdist.PipelinedSteps(2, None)
+    got = {}
+
+    def produce(n):
+        def f(slot):
+            Z, sums = data(n)
+            recs[slot].Z.copy_(Z)
+            recs[slot].sums.copy_(sums)
+            return n
+        return f
+
+    def consume(slot, n):
+        got[n] = statistics(*rdist.exchange_record(recs[slot]))
+        return n
+    for n in range(K):
+        pipe.step(produce(n), consume)
+    assert len(got) == K - 1                              # the last step's consumer is still pending ...
+    pipe.drain()
+    assert len(got) == K                                  # ... until the pipeline is drained
+    order = pipe.issued
+    for n in range(K - 1):
+        assert order.index(("produce", n + 1)) < order.index(("consume", n))     # the overlap: next producer first
+        assert order.index(("consume", n)) < (order.index(("produce", n + 2)) if n + 2 < K else len(order))   # slot reuse
+    for n in range(K):
+        assert np.array_equal(got[n], serial[n]), (n, got[n], serial[n])         # bit for bit the serial statistics
+    np.save(os.path.join(tmpdir, f"pipe_{rank}.npy"), np.stack([got[n] for n in range(K)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_steps_equal_the_serial_order_world2_gloo(tmp_path):
+    """bench.py --gpus N (N > 1) overlaps the exchange + statistics of step n with the hot kernel of step n + 1
+    (dist.PipelinedSteps).  World 2 over gloo, host records: same statistics as the serial order bit for bit, identical on
+    both ranks, the consumer of a slot always issued before the slot is produced into again."""
+    world, K = 2, 7
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), 1500, K, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pipe_0.npy"), np.load(tmp_path / "pipe_1.npy")
+    assert np.array_equal(a, b) and a.shape == (K, 3 + 5)

@@ -168,3 +168,55 @@ def test_sharded_oracle_recovers_together_when_one_rank_gives_up(tmp_path):
     for k in range(6):
         us, _, _ = single.solve_reduced(us, k)
     np.testing.assert_allclose(us0, us, rtol=0, atol=2e-5)
+
+
+def test_pipelined_steps_on_the_device_equal_the_serial_order():
+    """dist.PipelinedSteps with real streams: linearize of step n + 1 on the main stream beside [unpack of 4 emulated
+    records + exact selection over all of them] of step n on the side stream, two output slots -- the statistics of every
+    step equal the serial order bit for bit (what bench.py --gpus N runs by default, minus the wire)."""
+    import torch
+    from riskaversetrajopt_amd import _lib, dist as rdist, driving, stats
+    M, S, world, K = 30000, 40, 4, 9
+    dW, x0, ws_, wr = driving.sample_uncertain_parameters_device(M, S, seed=9)
+    d = driving.Model.from_device(S, dW, x0, ws_, wr, 'saa', 0.05)
+    lib, dev = _lib.load(), d.device
+    t = np.arange(S)[:, None]
+    us = [np.hstack([0.4 * np.cos(0.3 * t + 0.1 * k) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * (20.0 / S) for k in range(K)]
+    outs = [d.linearize_device(us[0]), d.linearize_device(us[0])]
+    recs = []
+    for o in outs:
+        rec = rdist.Record(0, M, dev)
+        o["Z"] = rec.Z
+        recs.append(rec)
+    keys = ("G", "g_up", "Z", "final_du", "final_rhs")
+    outs = [{k: o[k] for k in keys} for o in outs]
+    Z_all = [torch.empty(world * M, dtype=torch.float32, device=dev) for _ in range(2)]
+    total = torch.empty(1, dtype=torch.float64, device=dev)
+    wss = [stats.new_workspace(world * M, dev) for _ in range(2)]
+    rec_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=dev)
+
+    def consume(slot, _):
+        all_ = recs[slot].buf.repeat(world)               # the other ranks' records: copies of this one
+        _lib.check(lib.rato_unpack_records(_lib.ptr(all_), world, 0, M, recs[slot].rec_bytes, _lib.ptr(total),
+                                           _lib.ptr(Z_all[slot]), _lib.current_stream()), "rato_unpack_records")
+        stats.risk_stats_device(Z_all[slot], 0.05, workspace=wss[slot], out=rec_out[slot])
+        return rec_out[slot].clone()
+
+    serial = []
+    for k in range(K):
+        d.linearize_device(us[k], out=outs[k & 1])
+        serial.append(consume(k & 1, None).cpu().numpy())
+    pipe = rdist.PipelinedSteps(2, dev)
+    got = []
+
+    def consume_and_keep(slot, _):
+        r = consume(slot, _)
+        got.append(r)
+        return r
+    for k in range(K):
+        pipe.step(lambda s, k=k: d.linearize_device(us[k], out=outs[s]), consume_and_keep)
+    pipe.drain()
+    assert len(got) == K
+    for k in range(K):
+        assert np.array_equal(got[k].cpu().numpy(), serial[k]), k
+    assert not np.array_equal(serial[0], serial[1])

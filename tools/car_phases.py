@@ -20,7 +20,7 @@ us = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * 
 for _ in range(3):
     r = d.linearize_device(us)
 torch.cuda.synchronize()
-n_wg = 512
+n_wg = int(os.environ.get("NWG", 512))
 raw = r["g_up"].reshape(-1)[:n_wg * 8].cpu().numpy().reshape(n_wg, 8)
 tiles, stage, roll, rows, nxt, total = (raw[:, i] for i in range(6))
 us_ = 1e-2                                    # ticks -> microseconds

@@ -22,7 +22,7 @@ us = np.hstack([0.4 * np.cos(0.3 * t) + 0.1, 0.03 * np.sin(0.5 * t) + 0.004]) * 
 for _ in range(4):
     r = d.linearize_device(us)
 torch.cuda.synchronize()
-n_wg = 512
+n_wg = int(os.environ.get("NWG", 512))
 raw = r["g_up"].reshape(-1)[:n_wg * 64].cpu().numpy().reshape(n_wg, 64).astype(np.int64)
 n = raw[:, 0]
 ev = []
