@@ -310,6 +310,9 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
   std::vector<std::pair<int, int>> cut_rows;   // (row of the master, ring slot)
   const int n_kept = (cvar && c.recycle) ? *n_keep_io : 0;
   if (n_kept < 0 || n_kept > c.keep_max) return RATO_EINVAL;
+  // the kept slots index host tables below (is_kept, idle) whether or not their re-linearization is already in flight:
+  // checked here unconditionally, not only inside rato_cut_begin / rato_cut_define_drone
+  if (*n_keep_io < 0 || *n_keep_io > c.keep_max || !keep_ok(s, keep, *n_keep_io)) return RATO_EINVAL;
   master_s += seconds_since(t0);
 
   if (n_kept > 0 && S >= 2) {

@@ -8,6 +8,23 @@
 
 #include "rato_saa.h"
 
+// HARDWARE ASSUMPTIONS (gfx950 only; the device pass refuses any other target below):
+//  * wave = 64 lanes, DPP row_bcast / row_shr semantics of GFX9;
+//  * in-launch hand-offs between workgroups (rato_select.h: z_ready, the cooperative histograms; drone.hip / driving.hip:
+//    LDS progress words) publish data with RELAXED agent-scope atomic stores + `s_waitcnt vmcnt(0)` + a relaxed counter:
+//    this relies on agent-scope (sc1) stores being written through to the device's point of coherence before the wait
+//    retires -- true on gfx942 / gfx950, outside the HSA memory model (a release fence per tile would write back the
+//    XCD's whole L2 in the middle of the store stream: measured 56 -> 194 us).  The fenced alternative stays testable:
+//    statistics behind the kernel (fused=False / large batches) use no hand-off at all;
+//  * statistics workgroups sit at the END of the grid and the launcher only enables them while every workgroup of the
+//    launch is resident at once, so that they cannot hold a slot a producer waits for (no reliance on dispatch order
+//    beyond "all resident"); their waits are bounded by the wall clock and fail loudly (NaN record, un-tagged workspace);
+//  * rato::store_streaming is inline assembly (`global_store_dword ... nt`, GFX94x/95x syntax): the compiler's waitcnt
+//    insertion does not see it, so it is only used for write-once outputs that nothing in the same kernel reads back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "librato_saa is written for gfx950 (MI355X) only: see the hardware assumptions in rato_common.h"
+#endif
+
 #define RATO_BLOCK 256           // 4 waves per workgroup (== RATO_TILE of rato_saa.h)
 #define RATO_WAVE 64
 

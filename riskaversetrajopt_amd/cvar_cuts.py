@@ -131,7 +131,8 @@ class CvarCutSolver:
             # every collective of the loop moves buffers whose lengths follow from (M, S, n_u, keep_max): agreed on here,
             # once, by every rank (the solver is built collectively, in the first solve_reduced after Model.shard()) --
             # which is what lets the per-cut all-gathers skip their own length check (dist.gather_concat, agreed=True)
-            rdist.check_equal_shards(((M * 1009 + S) * 1009 + n_u) * 1009 + self.keep_max, group)
+            for name, val in (("samples per rank M", M), ("horizon S", S), ("controls n_u", n_u), ("keep_max", self.keep_max)):
+                rdist.check_equal_shards(val, group, what=f"cutting-plane solver: {name}")
         if device is not None:                           # (None: a host oracle overrides evaluate / relinearize_kept_cuts
             self._alloc_device(device)                   #  -- tests/_host_cuts.py, the fp64 checker of this loop)
 

@@ -60,10 +60,10 @@ def shard_bounds(M_total, rank, world, equal=False):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def check_equal_shards(M_local, group=None):
-    """Collective: every rank must hold the same number of samples.  One tiny all-gather, done once per Record /
-    Model.shard(); raises on EVERY rank when the counts differ (a mismatched RCCL all-gather would hang or corrupt
-    silently, gloo errors on one rank only)."""
+def check_equal_shards(M_local, group=None, what="sample shards"):
+    """Collective: every rank must hold the same value (by default: its number of samples).  One tiny all-gather, done
+    once per Record / Model.shard(); raises on EVERY rank when the values differ (a mismatched RCCL all-gather would hang
+    or corrupt silently, gloo errors on one rank only).  ``what`` names the quantity in the message."""
     if not (dist.is_available() and dist.is_initialized()):
         return [int(M_local)]
     world = dist.get_world_size(group)
@@ -73,7 +73,7 @@ def check_equal_shards(M_local, group=None):
     dist.all_gather_into_tensor(every, mine, group=group)
     counts = [int(v) for v in every.cpu()]
     if len(set(counts)) != 1:
-        raise ValueError(f"sample shards differ across ranks: {counts}; the exchange needs equal M_local on every rank")
+        raise ValueError(f"{what} differ across ranks: {counts}; the exchange needs them equal on every rank")
     return counts
 
 
@@ -178,7 +178,7 @@ def exchange(sums64, Z32, group=None, agreed=False):
     world = dist.get_world_size(group)
     n_sums, M_local = sums64.numel(), Z32.numel()
     rec = pack_record(sums64.reshape(-1).to(torch.float64), Z32.to(torch.float32))
-    out = gather_concat(rec, group, agreed)
+    out = gather_concat(rec, group, agreed, what="exchange record lengths (8 n_sums + 4 M_local bytes)")
     sums, Z_all = unpack_records(out, world, n_sums, M_local)
     total = sums[0].clone()
     for r in range(1, world):          # fixed (rank) order: bitwise identical on every rank
@@ -305,7 +305,7 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def gather_concat(t, group=None, agreed=False):
+def gather_concat(t, group=None, agreed=False, what="buffer lengths"):
     """1-D tensor, equal length on every rank -> the concatenation in rank order (on every rank).
 
     A mismatched RCCL all-gather hangs or corrupts silently, so the equal length is verified with one tiny collective
@@ -317,7 +317,7 @@ def gather_concat(t, group=None, agreed=False):
     world = dist.get_world_size(group)
     src = t.contiguous()
     if not agreed:
-        check_equal_shards(src.numel(), group)
+        check_equal_shards(src.numel(), group, what=what)
     comm = device_comm(group) if src.is_cuda else None
     if comm is not None:
         from . import _lib
@@ -338,7 +338,7 @@ def gather_concat(t, group=None, agreed=False):
 def sum_in_rank_order(t, group=None, agreed=False):
     """Sum of a small tensor over the ranks, added in rank order: bitwise identical on every rank."""
     world = dist.get_world_size(group)
-    parts = gather_concat(t.reshape(-1), group, agreed).view(world, -1)
+    parts = gather_concat(t.reshape(-1), group, agreed, what="lengths of the summed vectors").view(world, -1)
     total = parts[0].clone()
     for r in range(1, world):
         total += parts[r]

@@ -518,7 +518,7 @@ class Model:
         import torch.distributed as tdist
         from . import dist as rdist
         rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
-        rdist.check_equal_shards(self.S, group)          # (... or the horizons: the lengths of every exchanged buffer)
+        rdist.check_equal_shards(self.S, group, what="horizons S")   # (... the lengths of every exchanged buffer)
         self._group, self._world = group, tdist.get_world_size(group)
         # buffers a single-process solve_reduced may have left behind are single-process shaped (pinned HOST sums that
         # the partial-sum kernel writes into directly): a sharded solve must not inherit them

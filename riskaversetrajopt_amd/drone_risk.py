@@ -706,7 +706,7 @@ class Model:
         import torch.distributed as tdist
         from . import dist as rdist
         rdist.check_equal_shards(self.M, group)          # raises on every rank if the shards differ
-        rdist.check_equal_shards(self.S, group)          # (... or the horizons: the lengths of every exchanged buffer)
+        rdist.check_equal_shards(self.S, group, what="horizons S")   # (... the lengths of every exchanged buffer)
         self._group, self._world = group, tdist.get_world_size(group)
         # buffers a single-process solve_reduced may have left behind are single-process shaped (pinned HOST sums that
         # the partial-sum kernel writes into directly): a sharded solve must not inherit them
@@ -778,7 +778,7 @@ class Model:
         sums = r["sums"]
         if world > 1:                                     # sample means over ALL shards, summed in rank order
             from . import dist as rdist
-            sums = rdist.sum_in_rank_order(sums, getattr(self, "_group", None))
+            sums = rdist.sum_in_rank_order(sums, getattr(self, "_group", None), agreed=True)   # 6S + 6 numbers: S agreed in shard()
         # ONE synchronisation for the sample sums, the non-finite count and (enqueued above) the kept cuts
         host = getattr(self, "_define_host", None)
         if host is None or host[0].numel() != sums.numel():

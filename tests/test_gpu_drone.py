@@ -202,7 +202,8 @@ def test_full_size_C2_properties():
         blk = G_dev[off:off + t]                                    # (t,2,3,M)
         Gu[:, t, :] = (blk * u[:t, :2, None, None]).sum(dim=(0, 1))
     resid = (r["g_up"] + g - Gu).abs().max().item()
-    assert resid < 5e-3 * max(1.0, g.abs().max().item() * 1e-2), resid
+    tol.report("C2 linearity |g_up + g - G.u| (fp32 row sums of up to 49 products, |g| up to ~1e3)", resid, tol.LINEARITY_ABS_DRONE_C2)
+    assert resid < tol.LINEARITY_ABS_DRONE_C2, resid
     # Z from linearize == Z from eval (same formulas, two kernels)
     Z_eval, _, _ = d.eval_device(us)
     assert (Z_eval - r["Z"]).abs().max().item() <= 1e-5 * max(1.0, Z_eval.abs().max().item())
