@@ -638,6 +638,74 @@ def kkt_block(model, us_final, iters, first_cvar, where):
     return kkt
 
 
+def scp_kernels_block(model, out, args):
+    """The device work of the SCP block kernel by kernel: every kernel of an oracle round trip and of a subproblem's
+    definition launched 200 x back to back on the bench batch (HIP events; a kernel costs the same between copies of itself
+    as between the others: profiles/EXPERIMENTS.md), with the number of launches the timed SCP made of it and what bounds
+    it.  Reproducible from `rocprofv3 --kernel-trace --stats -- python scp_bench.py` (profiles/r05_*_scp_kernel_stats.csv)."""
+    import torch
+    from riskaversetrajopt_amd import _lib, stats as rstats
+    cs = model._cut_solver
+    M, S, dev = cs.M, cs.S, model.device
+    st = _lib.current_stream()
+    us = np.asarray(out["us"], dtype=np.float64).reshape(-1)
+    cs.set_linearization_point(us)
+    cs.evaluate(None, None, 0, None, us * 1.001, slot=cs.cap - 1)          # a cut at a nearby point: a realistic tail
+    slot = torch.full((1,), cs.cap - 1, dtype=torch.int32, device=dev)
+    m_buf, arg_buf = cs.ring_m[cs.cap - 1], cs.ring_arg[cs.cap - 1]
+    part = torch.zeros((cs.nblk, cs.nc), dtype=torch.float64, device=dev)
+    ws = rstats.new_workspace(M, dev)
+    rec = torch.empty(rstats.N_STATS, dtype=torch.float64, device=dev)
+    sums = torch.empty(cs.nc, dtype=torch.float64, device=dev)
+    cs._x_np[:] = (us * 0.001).reshape(S, cs.n_u)
+    _lib.copy_async(cs.x_dev, cs.x_host, st)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def us_per_launch(fn, n=200):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+    K = max(1, len(cs.keep))
+    slots_k = torch.as_tensor((list(cs.keep) or [cs.cap - 1])[:K], dtype=torch.int32, device=dev)
+    part_k = torch.zeros((cs.nblk, K * cs.nc), dtype=torch.float64, device=dev)
+    t_row = us_per_launch(lambda: cs._rollout_rowmax(m_buf, arg_buf, st))
+    t_sel = us_per_launch(lambda: rstats.risk_stats_device(m_buf, cs.alpha, workspace=ws, out=rec))
+    t_tail = us_per_launch(lambda: cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slot), 1, part, st))
+    t_fin = us_per_launch(lambda: rstats.sum_partials(part, out=sums, stream=st))
+    t_union = us_per_launch(lambda: cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slots_k), K, part_k, st))
+    gb = {}
+    t_gen = us_per_launch(lambda: gb.update(model.linearize_generators_device(out["us"], out=gb or None, rows_out=1, tables=False,
+                                                                              defer_check=True)), 100)
+    iters, first = int(args.scp_iters), 2
+    trips = int(out["cuts"].sum()) + int((out["cuts"] >= 0).sum() - first)       # one confirming evaluation per CVaR subproblem
+    FP64_OPS = 256 * 4 * 16 * 2.4e9                                               # vector fp64 instructions-lanes per second
+    rows = {
+        "drone_rowmax_rollout_kernel": {"us": t_row, "calls": trips, "bound": "fp64 instruction issue",
+                                        "frac": M * S * 60 / (t_row * 1e-6) / FP64_OPS,
+                                        "how": "60 fp64 operations per sample-step against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz"},
+        "rs_coop (exact selection over m)": {"us": t_sel, "calls": trips, "bound": "latency: four dependent global phases",
+                                             "frac": None},
+        "drone_tail_rows_rollout_kernel": {"us": t_tail, "calls": trips, "bound": "latency of one wave's chain per block",
+                                           "frac": None},
+        "cut_finish_kernel (as sum_partials_kernel<double>)": {"us": t_fin, "calls": trips, "bound": "launch", "frac": None},
+        "drone_linearize_generators_kernel<false,false> + sums": {"us": t_gen, "calls": iters, "bound": "fp64 instruction issue",
+                                                                  "frac": None},
+        f"drone_tail_rows_rollout_union_kernel (K = {K} kept cuts)": {"us": t_union, "calls": iters - first - 1,
+                                                                      "bound": "latency", "frac": None},
+    }
+    for r in rows.values():
+        r["total_ms"] = r["us"] * r["calls"] * 1e-3
+    return {"per_launch": "HIP events over 200 launches back to back on the bench batch (includes ~3.6 us of launch per kernel)",
+            "oracle_round_trips": trips, "kernels": rows,
+            "device_ms_of_round_trips": sum(r["total_ms"] for k, r in rows.items() if r["calls"] == trips)}
+
+
 def scp_block(work, args):
     """The second half of the BASELINE metric: SCP wall-clock for the drone at the bench's M and S, with the
     reference's timing protocol (drone_times.py:509-550 / drone_risk.py:510-532: a fixed 60 iterations from the
@@ -654,8 +722,13 @@ def scp_block(work, args):
     out = scp.run_drone_reduced(model, num_scp_iters_max=args.scp_iters, verbose=False)
     wall = time.perf_counter() - t0
     st = model.monte_carlo_statistics(out["us"], alpha=args.alpha)
+    try:
+        kernels = scp_kernels_block(model, out, args)
+    except Exception as e:                              # a diagnostic must never take the bench line down
+        kernels = {"error": f"{type(e).__name__}: {e}"}
     kkt = kkt_block(model, out["us"], args.scp_iters, 2, "drone_risk.py:327-368")
     return {"system": "drone_risk", "M": work.M, "S": work.S, "alpha": args.alpha, "iters": args.scp_iters, "kkt": kkt,
+            "kernels": kernels,
             "cut_tolerance": 1e-9, "loop": "rato_cut_solve (native cutting-plane loop, one library call per subproblem)",
             "protocol": "drone_times.py:509-550: fixed iteration count from the initial guess, per-iteration define / "
                         "solve wall-clock, medians + cumulative; run after the timed throughput region",

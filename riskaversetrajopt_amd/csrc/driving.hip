@@ -1008,6 +1008,23 @@ __global__ __launch_bounds__(CROWS_NW* RATO_WAVE) void car_linearize_rows_kernel
     task = next_task();
   }
   // ---- next tile
+#if RATO_CDIAG == 6
+  if (!LOOP) {   // (one unit per workgroup: its end stamp, behind a barrier so that every wave's rows are in)
+    __syncthreads();
+    if (threadIdx.x == 0 && dg_n < 20) dg_tl[3 + 3 * dg_n] = (unsigned)wall_clock64();
+    ++dg_n;
+  }
+#endif
+#if RATO_CDIAG_PHASES
+  if (!LOOP) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long now = wall_clock64();
+      dg_rows += now - dg_mark;
+      dg_mark = now;
+    }
+  }
+#endif
   if (!LOOP) break;
   __syncthreads();   // every wave has finished this tile's rows: the sample tables are dead, head[] may be rewritten
 #if RATO_CDIAG == 6

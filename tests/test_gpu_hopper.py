@@ -100,7 +100,10 @@ def test_golden_fixture(name):
     assert abs(st["var"] - f["var"]) < 5e-5 and abs(st["cvar"] - f["avar"]) < 5e-5
 
 
-D1_ATOL_C4, D2_ATOL_C4 = 1e-5 * np.sqrt(50000), 1e-4 * np.sqrt(50000)     # (until measured: RATO_TOL_REPORT)
+# lambda-weighted Hessian sums over 5e4 samples, |D| up to 6e2 (hardware sin / cos: 1.5e-6 per term, fp32 block partials):
+# measured max |err| 7.9e-5 (D1), 1.09e-2 (D2) -- profiles/r05_tolerances.txt.  D1: 3x measured (round 4: 2.2e-3);
+# D2: the round-4 limit, 2.1x measured, kept (3x measured would be looser)
+D1_ATOL_C4, D2_ATOL_C4 = 2.5e-4, 1e-4 * np.sqrt(50000)
 
 
 def test_full_size_C4_properties():
