@@ -679,9 +679,14 @@ def scp_kernels_block(model, out, args):
     t_tail = us_per_launch(lambda: cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slot), 1, part, st))
     t_fin = us_per_launch(lambda: rstats.sum_partials(part, out=sums, stream=st))
     t_union = us_per_launch(lambda: cs._rollout_tail_rows(cs.ring_m, cs.ring_arg, cs.ring_res, _lib.ptr(slots_k), K, part_k, st))
-    gb = {}
-    t_gen = us_per_launch(lambda: gb.update(model.linearize_generators_device(out["us"], out=gb or None, rows_out=1, tables=False,
-                                                                              defer_check=True)), 100)
+    import ctypes as C
+    nd = model._native_define                                # the buffers rato_cut_define_drone linearizes into
+    dW_, mass_, Q_, _ = model._inputs(None)
+    pp = model._params(M, mass_.numel(), 1)
+    lib = _lib.load()
+    t_gen = us_per_launch(lambda: _lib.check(lib.rato_drone_linearize_generators(
+        C.byref(pp), _lib.ptr(nd["us_dev"]), _lib.ptr(dW_), _lib.ptr(mass_), _lib.ptr(Q_), _lib.ptr(nd["A22"]), None, None, None,
+        _lib.ptr(nd["part"]), st), "rato_drone_linearize_generators"), 100)
     iters, first = int(args.scp_iters), 2
     trips = int(out["cuts"].sum()) + int((out["cuts"] >= 0).sum() - first)       # one confirming evaluation per CVaR subproblem
     FP64_OPS = 256 * 4 * 16 * 2.4e9                                               # vector fp64 instructions-lanes per second
@@ -694,8 +699,8 @@ def scp_kernels_block(model, out, args):
         "drone_tail_rows_rollout_kernel": {"us": t_tail, "calls": trips, "bound": "latency of one wave's chain per block",
                                            "frac": None},
         "cut_finish_kernel (as sum_partials_kernel<double>)": {"us": t_fin, "calls": trips, "bound": "launch", "frac": None},
-        "drone_linearize_generators_kernel<false,false> + sums": {"us": t_gen, "calls": iters, "bound": "fp64 instruction issue",
-                                                                  "frac": None},
+        "drone_linearize_generators_kernel<false,false>": {"us": t_gen, "calls": iters, "bound": "fp64 instruction issue",
+                                                           "frac": None},
         f"drone_tail_rows_rollout_union_kernel (K = {K} kept cuts)": {"us": t_union, "calls": iters - first - 1,
                                                                       "bound": "latency", "frac": None},
     }

@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python
 f=$(find $O -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv under $O"; exit 1; }
 cp "$f" $R/gpurun_out/${tag}_scp_kernel_stats.csv
-timeout 60 python3 - "$f" <<'PY' < /dev/null
+timeout 60 python3 - "$f" <<'PY'
 import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     m = re.search(r'(\w+_kernel|rs_coop|rs_small|rs_\w+|sum_partials\w*|__amd_\w+)', r['Name'])
