@@ -186,6 +186,13 @@ class DroneWork:
         noise = M * B * 3 * S if self.philox else 0                            # not read when it is regenerated
         return eval_in - noise + M * B * (3 * S + jac) + nblk * (6 * S + 6) * B       # g_up, Jacobian | partials
 
+    def needed_bytes(self):
+        """eval: what the tiled kernel has to move -- the vertical axis' noise is read by no obstacle row
+        (drone_risk.py:174) and is not loaded: 8 S + 44 bytes per sample instead of SURVEY 8(d)'s 12 S + 44"""
+        if self.mode != "eval" or self.philox:
+            return None
+        return self.M * B * (2 * self.S + 1 + 9 + 1) + 3 * self.S * B
+
     def cpu_baseline(self, n, alpha):
         """The oracle's C restatement (oracle/saa_oracle.c, OpenMP over samples) on the same workload at the SAME M:
         every sample's dense linearization is formed in the reference's shapes ((3,S,3S) Jacobian rows, g_up, the
@@ -254,7 +261,7 @@ class DrivingWork:
                                                      " noise=regenerated(Philox4x32-10)" if self.philox else "")
             self.kernel = "car_linearize_rows_kernel" if r["cols_per_thread"] == -1 else "car_linearize_kernel"
         else:
-            self.kernel = "car_eval_kernel<philox>" if self.philox else "car_eval_tiles_kernel"
+            self.kernel = "car_eval_kernel<philox>" if self.philox else ("car_eval_tiles_kernel" if self.M <= (1 << 20) else "car_eval_kernel")
 
     def stats_in_launch(self):
         if self.mode == "eval":
@@ -431,7 +438,12 @@ def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
     alg = work.algorithmic_bytes()
     achieved = alg / (kern_ms * 1e-3) / 1e9
     tr = pmc_traffic(workload, mode, M, S, jacobian)
-    return {"bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
+    needed = work.needed_bytes() if hasattr(work, "needed_bytes") else None
+    extra = {}
+    if needed:      # SURVEY 8(d)'s figure counts an input the kernel does not need: the fraction on the bytes it moves
+        extra = {"bytes_needed_per_launch": needed, "achieved_on_bytes_needed": needed / (kern_ms * 1e-3) / 1e9,
+                 "frac_on_bytes_needed": needed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    return {**extra, "bound": "hbm", "kernel": work.kernel, "variant": getattr(work, "variant", ""),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "frac_of_measured_copy_6290": achieved / 6290.0,
             # store-only replay of the row kernels' pattern (512 resident workgroups, one 1.88 MB tile each, tiles on
@@ -693,7 +705,11 @@ def scp_kernels_block(model, out, args):
     rows = {
         "drone_rowmax_rollout_kernel": {"us": t_row, "calls": trips, "bound": "fp64 instruction issue",
                                         "frac": M * S * 60 / (t_row * 1e-6) / FP64_OPS,
-                                        "how": "60 fp64 operations per sample-step against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz"},
+                                        "how": "60 fp64 operations per sample-step against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one "
+                                               "wave64 fp64 instruction per 4 cycles per SIMD).  That peak needs 8 waves per SIMD: "
+                                               "measured (tools/fp64bench.hip, profiles/r05_fp64bench.txt) a SIMD issues one per "
+                                               "10.4 / 5.9 / 5.5 / 4.7 cycles with 1 / 2 / 4 / 8 resident waves whatever their "
+                                               "independent chains, and M = 1e5 is 1.5 waves per SIMD"},
         "rs_coop (exact selection over m)": {"us": t_sel, "calls": trips, "bound": "latency: four dependent global phases",
                                              "frac": None},
         "drone_tail_rows_rollout_kernel": {"us": t_tail, "calls": trips, "bound": "latency of one wave's chain per block",
