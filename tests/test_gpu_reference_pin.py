@@ -76,6 +76,13 @@ def test_drone_vs_reference_execution(name):
                 continue
             A, l, u = d.get_constraints_coeffs(us, it)
             assert_qp_close(A, l, u, csc(f, f"{kind}_qp{it}_A"), f[f"{kind}_qp{it}_l"], f[f"{kind}_qp{it}_u"], 3 * S)
+    # the Monte-Carlo report's form (drone_risk.py:697-725): both control sequences in ONE call, against the recorded Z / flags
+    Zb, rec = d.eval_batch_device(np.stack([f["init_us"], f["graze_us"]]), alpha=0.3)
+    for k, kind in enumerate(("init", "graze")):
+        Zk = Zb[k].double().cpu().numpy()
+        np.testing.assert_allclose(Zk, f[f"{kind}_Z"], rtol=tol.G_RTOL, atol=tol.G_ATOL)
+        tol.assert_satisfied_close(Zk <= 1e-6, f[f"{kind}_Z"])
+        assert abs(float(rec[k, 0]) - float(f[f"{kind}_var"])) < tol.RISK_ATOL * max(1.0, abs(float(f[f"{kind}_var"])))
     P, q = d.get_objective_coeffs()
     Pr = csc(f, "P")
     assert (sp.csc_matrix(P) != Pr).nnz == 0 and np.array_equal(q, f["q"])
@@ -116,6 +123,12 @@ def test_driving_vs_reference_execution(name):
             l_ref = f[f"{kind}_qp{it}_l"]
             l_ref = np.where(np.isnan(l_ref), 0.0, l_ref)      # -inf * 0 of driving.py:413 (see test_reference_pin.py)
             assert_qp_close(A, l, u, csc(f, f"{kind}_qp{it}_A"), l_ref, f[f"{kind}_qp{it}_u"], 2 * S)
+    # the Monte-Carlo report's form (driving.py:675-740): both control sequences in ONE call, against the recorded Z / flags
+    Zb, _ = d.eval_batch_device(np.stack([f["init_us"], f["swerve_us"]]))
+    for k, kind in enumerate(("init", "swerve")):
+        Zk = Zb[k].double().cpu().numpy()
+        np.testing.assert_allclose(Zk, f[f"{kind}_Z"], rtol=tol.G_RTOL, atol=tol.G_ATOL)
+        tol.assert_satisfied_close(Zk <= 1e-6, f[f"{kind}_Z"])
 
 
 @pytest.mark.parametrize("name", ["ref_hopper_S30_M30", "ref_hopper_S60_M24"])
