@@ -978,6 +978,7 @@ def configs_block(args, device, stats, rdist, dist, torch):
                          "kernel": rb["kernel"], "kernel_ms": res["kern_ms"], "step_over_kernel": ms / res["kern_ms"],
                          "bound": "hbm" if wl != "hopper" else "valu (transcendental issue; HBM fraction for completeness)",
                          "achieved_GBps": rb["achieved"], "frac": rb["frac"],
+                         "frac_on_bytes_needed": rb.get("frac_on_bytes_needed"),
                          "algorithmic_bytes_per_launch": rb["algorithmic_bytes_per_launch"],
                          "traffic_from_profile": rb["traffic_from_profile"], "launch": res["launch"],
                          "stats": {"VaR": res["stats"][0], "CVaR": res["stats"][1], "frac_satisfied": res["stats"][2]}}
