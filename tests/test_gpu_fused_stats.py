@@ -125,8 +125,10 @@ def test_refused_where_it_cannot_work():
 # ---- round 5: the Monte-Carlo step (rollout -> Z -> statistics) as one call / one launch --------------------------------
 @pytest.mark.parametrize("system,M,S", [("drone", 1, 20), ("drone", 300, 20), ("drone", 10000, 50), ("drone", 12289, 33),
                                         ("drone", 50000, 50), ("drone", 70001, 20), ("drone", 4097, 126),
+                                        ("drone", 100, 1), ("drone", 130, 64), ("drone", 130, 65), ("drone", 70, 129),
                                         ("driving", 1, 20), ("driving", 257, 20), ("driving", 10000, 40),
-                                        ("driving", 50000, 40), ("driving", 70001, 17), ("driving", 3000, 90)])
+                                        ("driving", 50000, 40), ("driving", 70001, 17), ("driving", 3000, 90),
+                                        ("driving", 100, 1), ("driving", 130, 64), ("driving", 130, 65), ("driving", 70, 129)])
 def test_tiled_eval_equals_the_plain_kernel_and_its_statistics_the_separate_launch(system, M, S):
     """rato_*_eval without trajectories runs the tiled kernel (one wave per 64 samples, noise batches in flight, the ego
     tables folded in the launch for driving); with trajectories the plain one.  Z and g agree to the bit; the record the
