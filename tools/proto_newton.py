@@ -1,0 +1,102 @@
+"""Prototype: SQP with a sample-density Hessian of the CVaR constraint vs Kelley (CPU, dense fp64 oracle, small M)."""
+import sys, time, numpy as np
+sys.path.insert(0, '/root/repo')
+from oracle import drone as od
+from tests import _host_cuts as hc
+from riskaversetrajopt_amd import scp, dense_qp
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+HFRAC = float(sys.argv[4]) if len(sys.argv) > 4 else 0.02      # boundary band: this fraction of the samples on each side
+rng = np.random.RandomState(7)
+DWs, masses, obs_Qs = od.sample_uncertain_parameters(rng, 'saa', M=M, S=S)
+om = od.Model(S, DWs, masses, obs_Qs, 'saa', 0.1)
+mdl = hc.DroneReducedOracle(om)
+cs = mdl.cs
+nU, n = cs.nU, cs.nU + 1
+aM = cs.alphaM
+
+def oracle(G, base, x, want_H=True):
+    rows = G @ x + base
+    arg = rows.argmax(axis=1)
+    idx = np.arange(rows.shape[0])
+    m = rows[idx, arg]
+    w, t = cs._weights(m)
+    gi = G[idx, arg]
+    g = (w[:, None] * gi).sum(0) / aM
+    phi = float(w @ m) / aM
+    H = None
+    if want_H:
+        order = np.sort(m)
+        k = int(M - np.floor(aM) - 1)
+        nb = max(int(HFRAC * M), 8)
+        lo, hi = order[max(k - nb, 0)], order[min(k + nb, M - 1)]
+        B = (m >= lo) & (m <= hi)
+        width = hi - lo
+        gb = gi[B]
+        d = gb - gb.mean(0)
+        H = d.T @ d / (aM * width)               # density (|B| / width) x covariance of the gradients in the band / (alpha M) ... 
+        # row switching inside tail samples
+        rows2 = rows.copy(); rows2[idx, arg] = -np.inf
+        arg2 = rows2.argmax(axis=1); m2 = rows2[idx, arg2]
+        hs = width
+        sw = (w > 0) & (m - m2 < hs)
+        if sw.any():
+            dd = gi[sw] - G[idx[sw], arg2[sw]]
+            H = H + (w[sw, None] * dd).T @ dd / (aM * 2 * hs)
+    return phi, t, g, H
+
+def qp(Q, qv, F, f, A, b, bounds_idx):
+    while True:
+        AA = list(A); bb = list(b)
+        for (i, sgn) in bounds_idx:
+            e = np.zeros(n); e[i] = sgn; AA.append(e); bb.append(cs.u_max)
+        z, lam = dense_qp.solve(Q, qv, F, f, np.array(AA).reshape(-1, n), np.array(bb))
+        new = [(i, 1.0) for i in range(nU) if z[i] > cs.u_max + 1e-9 and (i, 1.0) not in bounds_idx] + \
+              [(i, -1.0) for i in range(nU) if z[i] < cs.u_min - 1e-9 and (i, -1.0) not in bounds_idx]
+        if not new:
+            return z, lam
+        bounds_idx += new
+
+us = mdl.initial_guess_us_mat()
+for k in range(iters):
+    if k < 2:
+        us, _, info = mdl.solve_reduced(us, k, tol=1e-10)
+        continue
+    fdu, frhs, gdu, gup = mdl.linearization(us)
+    G = gdu.reshape(M, -1, nU); gupf = gup.reshape(M, -1)
+    uk = np.asarray(us, dtype=np.float64).reshape(-1)
+    base = -(gupf - G @ uk)
+    F = np.hstack([fdu, np.zeros((fdu.shape[0], 1))]); f = frhs
+    # reference: Kelley
+    t0 = time.time()
+    us_ref, _, info = mdl.solve_reduced(us, k, tol=1e-10)
+    z_ref = np.concatenate([us_ref.reshape(-1), [info["slack"]]])
+    tk = time.time() - t0
+    # SQP
+    Pd, q = cs._Pd, cs.q
+    z = np.concatenate([uk, [0.0]])
+    lam_c = 0.0
+    hist = []
+    bounds_idx = []
+    for it in range(30):
+        x = z[:nU] - uk
+        phi, t, g, H = oracle(G, base, x)
+        viol = phi - cs.c_s * z[nU] - cs.rhs0
+        hist.append((np.abs(z - z_ref).max(), viol))
+        Q = Pd.copy(); Q[:nU, :nU] += lam_c * H
+        qq = q.copy(); qq[:nU] -= lam_c * (H @ z[:nU])
+        A = [np.concatenate([np.zeros(nU), [-1.0]]), np.concatenate([g, [-cs.c_s]])]
+        b = [0.0, cs.rhs0 + (g @ z[:nU] - phi)]
+        z_new, lam = qp(Q, qq, F, f, A, b, bounds_idx)
+        lam_c = lam[1]
+        step = np.abs(z_new - z).max()
+        z = z_new
+        if step < 1e-9:
+            break
+    x = z[:nU] - uk
+    phi, t, g, _ = oracle(G, base, x, want_H=False)
+    print(f"scp {k}: Kelley cuts {info['cuts']:3d} ({tk:.1f}s) | SQP iterations {it + 1}: |z - z_ref| " +
+          " ".join("%.0e" % h[0] for h in hist) + f" -> {np.abs(z - z_ref).max():.1e}; final viol {phi - cs.c_s * z[nU] - cs.rhs0:+.1e} lam {lam_c:.3f}", flush=True)
+    us = us_ref
