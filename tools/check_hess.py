@@ -1,6 +1,6 @@
 import os, sys, numpy as np
 sys.argv = [sys.argv[0], "3000", "20", "3", "0.02"]
-exec(open('/root/repo/tools/proto_newton.py').read().split("us = mdl.initial_guess_us_mat()")[0])
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'proto_newton.py')).read().split("us = mdl.initial_guess_us_mat()")[0])
 us = mdl.initial_guess_us_mat()
 for k in range(3):
     us, _, info = mdl.solve_reduced(us, k, tol=1e-10)

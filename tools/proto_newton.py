@@ -1,6 +1,6 @@
 """Prototype: SQP with a sample-density Hessian of the CVaR constraint vs Kelley (CPU, dense fp64 oracle, small M)."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import drone as od
 from tests import _host_cuts as hc
 from riskaversetrajopt_amd import scp, dense_qp

@@ -1,7 +1,7 @@
 """Prototype: two oracle evaluations per round trip (the master's point + a second point) -- how many ROUND TRIPS does a
 subproblem need?  CPU, fp64 streaming oracle."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import drone as od
 from tests import _host_cuts as hc
 from riskaversetrajopt_amd import scp, dense_qp

@@ -1,6 +1,6 @@
 """Prototype: variable-metric stabilised query points, Kelley-certified answer (CPU, fp64 streaming oracle)."""
 import sys, time, math, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import drone as od
 from tests import _host_cuts as hc
 from riskaversetrajopt_amd import scp, dense_qp
