@@ -120,7 +120,20 @@ class DroneWork:
                                                   noise_seed=seed if self.philox else None)
         self.us = self.model._us_device(graze_us(self.S, 3))
         self.out = None
+        self.retile_us = None
         if self.mode == "linearize":
+            if not self.philox:
+                # the one-time re-tiling of the batch's noise (what the row kernel reads): setup, timed here so that the line
+                # can say what it costs -- once per batch, then every linearization of the batch reads the copy
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record()
+                tiled = self.model._tiled_noise(self.model._dW, self.M, self.model._mass.numel())
+                b.record()
+                torch.cuda.synchronize()
+                if tiled is not None:
+                    self.retile_us = a.elapsed_time(b) * 1e3
             r = self.model.linearize_device(self.us, cols_per_thread=self.cpt, samples_per_lane=self.spl,
                                             factored=self.fact)
             self.fact = r["factored"]
@@ -1076,7 +1089,10 @@ def main():
                        "baseline_config": args.config,
                        "inputs": "resident in HBM before the timed region; the row-parallel drone / driving kernels read the "
                                  "batch's noise from a copy re-tiled once per batch (rato_*_tile_noise: one contiguous block per "
-                                 "tile of 64 samples, the same numbers)",
+                                 "tile of 64 samples, the same numbers)" + (
+                                     f"; that copy costs {work.retile_us:.0f} us ONCE per batch (first launch included), outside "
+                                     "the timed region -- an SCP that linearizes a batch 60 times pays it once"
+                                     if getattr(work, "retile_us", None) else ""),
                        "M_per_gpu": M, "S": S, "M_total": world * M,
                        "value_is_for": ("the SURVEY 8(d) contract: every structural nonzero of the Jacobian written "
                                         "(3S(S-1) numbers per sample)" if jacobian in ("products", "regenerated") else
