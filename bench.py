@@ -127,6 +127,8 @@ class DroneWork:
                 # can say what it costs -- once per batch, then every linearization of the batch reads the copy
                 import torch
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.model._tiled_noise(self.model._dW, self.M, self.model._mass.numel())     # (cold: loads the kernel)
+                self.model.invalidate_noise()
                 torch.cuda.synchronize()
                 a.record()
                 tiled = self.model._tiled_noise(self.model._dW, self.M, self.model._mass.numel())
@@ -1090,7 +1092,7 @@ def main():
                        "inputs": "resident in HBM before the timed region; the row-parallel drone / driving kernels read the "
                                  "batch's noise from a copy re-tiled once per batch (rato_*_tile_noise: one contiguous block per "
                                  "tile of 64 samples, the same numbers)" + (
-                                     f"; that copy costs {work.retile_us:.0f} us ONCE per batch (first launch included), outside "
+                                     f"; that copy costs {work.retile_us:.0f} us ONCE per batch (allocation + kernel), outside "
                                      "the timed region -- an SCP that linearizes a batch 60 times pays it once"
                                      if getattr(work, "retile_us", None) else ""),
                        "M_per_gpu": M, "S": S, "M_total": world * M,
