@@ -149,9 +149,29 @@ def monte_carlo_report(mc_model, us_list, alpha, verbose=False):
     """The out-of-sample validation block of the reference's scripts (drone_risk.py:697-725, driving.py:672-700):
     every solution in ``us_list`` (the SAA repeats of one alpha) is evaluated on the Monte-Carlo model's fresh
     samples (M = 10000 there) -- fraction of samples that satisfy the constraints, AVaR_alpha of the max constraint
-    value, control cost -- and the mean / median over the repeats are reported.  One rollout kernel + one exact
-    selection per solution, all on the device.  -> dict of per-solution arrays and the aggregates."""
+    value, control cost -- and the mean / median over the repeats are reported.  All repeats in ONE library call where the
+    model has the batched entry point (drone, driving: ``Model.eval_batch_device``), one rollout kernel + one exact selection
+    per solution otherwise; all on the device.  -> dict of per-solution arrays and the aggregates."""
     frac, avar, var, cost = [], [], [], []
+    batched = getattr(mc_model, "eval_batch_device", None)
+    if batched is not None and len(us_list) > 1 and getattr(mc_model, "_dW", None) is not None:
+        # all repeats of this alpha in ONE call (rato_*_eval_batch: one rollout launch over tiles x K, one launch of K
+        # exact selections); row k is what the per-solution call below gives for solution k, to the bit
+        from . import stats
+        _, rec = batched(np.stack([np.asarray(us) for us in us_list]), alpha=alpha)
+        rec = rec.cpu().numpy()
+        names = stats._STAT_NAMES
+        for k, us in enumerate(us_list):
+            st = dict(zip(names, rec[k].tolist()))
+            if np.isnan(st["var"]):                    # (a selection that gave up: the recovering per-solution path)
+                st = mc_model.monte_carlo_statistics(us, alpha=alpha)
+            frac.append(st["frac_satisfied"])
+            avar.append(st["cvar"])
+            var.append(st["var"])
+            cost.append(mc_model.monte_carlo_cost(us))
+            if verbose:
+                print("B_satisfied_vec =", frac[-1])
+        us_list = []
     for us in us_list:
         st = mc_model.monte_carlo_statistics(us, alpha=alpha)
         frac.append(st["frac_satisfied"])

@@ -416,6 +416,13 @@ def test_monte_carlo_report_matches_oracle():
         assert abs(rep["avar"][i] - ostats.monte_carlo_avar(Z, alpha)) < 2e-4 * max(1.0, abs(rep["avar"][i]))
         assert abs(rep["cost"][i] - o.monte_carlo_cost(us)) < 1e-9 * max(1.0, rep["cost"][i])
     assert rep["avar_median"] == np.median(rep["avar"]) and rep["cost_mean"] == np.mean(rep["cost"])
+    # the report went through ONE batched call (Model.eval_batch_device); solution by solution it must be the same numbers
+    for i, us in enumerate(us_list):
+        st = d.monte_carlo_statistics(us, alpha=alpha)
+        assert st["var"] == rep["var"][i] and st["frac_satisfied"] == rep["frac_satisfied"][i]
+        assert abs(st["cvar"] - rep["avar"][i]) <= 1e-12 * max(1.0, abs(st["cvar"]))
+    one = scp.monte_carlo_report(d, us_list[:1], alpha)                # (a single solution: the per-solution path)
+    assert one["var"][0] == rep["var"][0]
 
 
 def test_device_emitted_csc_values_with_padded_tiles():
