@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -461,6 +462,13 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_implicit_kernel(
 // BYVAL: x travels in the kernel arguments (S n_u <= XARG_MAX doubles) instead of device memory -- the one-call round
 // trip (rato_cut_oracle_rollout) then needs no upload in front of its first launch (an asynchronous 1.2 KB copy costs
 // ~25 us of host time on this stack, a quarter of the device time of the whole trip).
+// v_max_f64 as it is (fmax() first canonicalises both operands: two more 64-bit instructions per call); a NaN operand
+// yields the other one, like fmax
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 constexpr int XARG_MAX = 192;
 constexpr uint64_t READBACK_PENDING = 0x7ff8dead5a5abeefull;   // (rato_cut_oracle_rollout: a word of res_host not yet written)
 struct XArg {
@@ -487,12 +495,18 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   // and an obstacle row as  1 - [dx (q00 (dx + 2 dp_x) + qs (dy + dp_y)) + dy (q11 (dy + 2 dp_y) + qs dp_x)]
   // (= g + grad g . dp: 11 operations instead of 16).  One running maximum per obstacle, merged at the end.
   const double one_c1 = 1.0 - dt * kd * inv_m, c2 = dt * drag * inv_m, c22 = 2.0 * c2;
-  double q00[3], qs[3], q11[3];
+  // (round 5: the obstacle's centre leaves the two inner sums as per-sample constants -- kx = q00 ox + qs oy,
+  //  ky = q11 oy: 8 operations per row instead of 11 -- and the running maximum is a v_max_f64 with the step index selected
+  //  beside it: 3 instead of 4.  The kernel is bound by the ~10 cycles between two instructions of the only wave or two
+  //  on a SIMD, tools/fp64bench.hip: every instruction less is time.)
+  double q00[3], qs[3], q11[3], kx[3], ky[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     q00[j] = (double)Qsym[(size_t)(j * 3 + 0) * ld + m];
     qs[j] = (double)Qsym[(size_t)(j * 3 + 1) * ld + m];
     q11[j] = (double)Qsym[(size_t)(j * 3 + 2) * ld + m];
+    kx[j] = fma(q00[j], P.obs_xy64[j][0], qs[j] * P.obs_xy64[j][1]);
+    ky[j] = q11[j] * P.obs_xy64[j][1];
   }
   double p[2] = {P.x_init64[0], P.x_init64[1]}, v[2] = {P.x_init64[3], P.x_init64[4]};
   double dp[2] = {0.0, 0.0}, dv[2] = {0.0, 0.0};
@@ -509,11 +523,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
       xi[i][1] = dW[((size_t)t * 3 + 1) * ld + m];
     }
   };
-  auto steps = [&](const float (&xi)[TB][2], int t0) {
+  auto steps = [&](const float (&xi)[TB][2], int t0, auto guarded) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = t0 + i;
-      if (t < S) {
+      if (!decltype(guarded)::value || t < S) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const double av = fabs(v[a]);                           // at the state BEFORE the step
@@ -530,25 +544,31 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
         const double px2 = fma(2.0, dp[0], p[0]), py2 = fma(2.0, dp[1], p[1]), sy = p[1] + dp[1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const double ox = P.obs_xy64[j][0], oy = P.obs_xy64[j][1];
-          const double dx = p[0] - ox, dy = p[1] - oy;
-          const double ix = fma(qs[j], sy - oy, q00[j] * (px2 - ox));
-          const double iy = fma(qs[j], dp[0], q11[j] * (py2 - oy));
+          const double dx = p[0] - P.obs_xy64[j][0], dy = p[1] - P.obs_xy64[j][1];
+          const double ix = fma(qs[j], sy, fma(q00[j], px2, -kx[j]));     // q00 (dx + 2 dp_x) + qs (dy + dp_y)
+          const double iy = fma(qs[j], dp[0], fma(q11[j], py2, -ky[j]));  // q11 (dy + 2 dp_y) + qs dp_x
           const double val = fma(-dy, iy, fma(-dx, ix, 1.0));
-          const bool up = val > best[j];                          // ascending t: the smallest t among equal values
-          best[j] = up ? val : best[j];
-          best_t[j] = up ? t : best_t[j];
+          best_t[j] = (val > best[j]) ? t : best_t[j];            // ascending t: the smallest t among equal values
+          best[j] = max_f64(best[j], val);
         }
       }
     }
   };
   float xa[TB][2], xb[TB][2];
   load(xa, 0);
-  for (int t0 = 0; t0 < S; t0 += 2 * TB) {
+  int t0 = 0;
+  // whole double batches without a test per step (a guarded step is a conditional block: its merges cost 64-bit moves);
+  // the last S mod 16 steps behind their guards
+  for (; t0 + 2 * TB <= S; t0 += 2 * TB) {
     load(xb, t0 + TB);
-    steps(xa, t0);
+    steps(xa, t0, std::false_type{});
     load(xa, t0 + 2 * TB);
-    steps(xb, t0 + TB);
+    steps(xb, t0 + TB, std::false_type{});
+  }
+  if (t0 < S) {
+    load(xb, t0 + TB);
+    steps(xa, t0, std::true_type{});
+    steps(xb, t0 + TB, std::true_type{});
   }
   // merge the three maxima: the larger value, the smaller row index r = j S + t among equal values
   double bv = best[0];
@@ -563,12 +583,16 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   arg_out[m] = bi;
 }
 
+constexpr int TAIL_CSTRIDE = RATO_WAVE + 1;   // row stride of the sweep's term table (doubles): column threads on distinct banks
+__host__ __device__ inline size_t tail_ctab_doubles(int S) { return (size_t)2 * (S - 1) * TAIL_CSTRIDE; }
+
 // The tail phase of ONE cut for one block of 256 samples: thread i brings its sample's tail weight and arg-max row (step t0,
 // row group r0); on return (behind a barrier) acc [2 (S - 1) + 1] holds the block's column sums.  E: [S][2][64] floats.
 __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, const double* __restrict__ uk,
                                                  const float* __restrict__ dW, const float* __restrict__ mass,
                                                  const float* __restrict__ Qsym, float w0f, int t0, int r0,
-                                                 double* __restrict__ acc, float* __restrict__ E) {
+                                                 double* __restrict__ acc, float* __restrict__ E,
+                                                 double* __restrict__ Ctab) {
   const int S = P.S;
   const long M = P.M, ld = P.ld;
   const int nw = 2 * (S - 1), nc = nw + 1;
@@ -655,6 +679,7 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
       }
       double m0 = 0.0, m1 = 0.0;
       float e_k = (t_hi >= 1) ? E[(t_hi * 2 + a) * RATO_WAVE + lane] : 0.0f;   // (read one step ahead of its use)
+      double* __restrict__ Ca = Ctab ? Ctab + (size_t)a * (S - 1) * TAIL_CSTRIDE : nullptr;
       for (int k = t_hi; k >= 1; --k) {   // wave-uniform
         const float e_next = (k > 1) ? E[((k - 1) * 2 + a) * RATO_WAVE + lane] : 0.0f;
         const bool in = on && k <= ts;
@@ -669,6 +694,10 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
           c = wa * m1;
         }
         e_k = e_next;
+        if (Ca) {   // the lanes' terms of column k-1 go to LDS as they are; summed over the lanes after the sweep
+          Ca[(k - 1) * TAIL_CSTRIDE + lane] = c;
+          continue;
+        }
         const double s0 = rato::wave_sum_dpp(c);
         // column k-1 of this axis: kept in lane k-1's register while the horizon fits a wave (no LDS read-modify-write
         // in the chain), in LDS otherwise
@@ -681,8 +710,26 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
       }
     }
     __syncthreads();   // s_pt and the tables are free for the next chunk
+    if (Ctab) {
+      // columns 0 .. t_hi - 1 of both axes: one thread per (axis, column) adds the 64 lanes' terms in lane order.  (In
+      // the sweep a wave-wide fp64 sum per step was 20 of the ~35 instructions of a step of the only wave on its SIMD.)
+      for (int i = threadIdx.x; i < 2 * t_hi; i += RATO_BLOCK) {
+        const int ax = i / t_hi, j = i - ax * t_hi;
+        const double* __restrict__ row = Ctab + ((size_t)ax * (S - 1) + j) * TAIL_CSTRIDE;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+        for (int l = 0; l < 16; ++l) {
+          s0 += row[l];
+          s1 += row[16 + l];
+          s2 += row[32 + l];
+          s3 += row[48 + l];
+        }
+        acc[j * 2 + ax] += (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+    }
   }
-  if (cols_in_regs && a < 2 && lane < S - 1) acc[lane * 2 + a] = colsum;
+  if (!Ctab && cols_in_regs && a < 2 && lane < S - 1) acc[lane * 2 + a] = colsum;
   __syncthreads();
 }
 
@@ -694,13 +741,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
     rato_drone_params P, const double* __restrict__ uk, const float* __restrict__ dW, const float* __restrict__ mass,
     const float* __restrict__ Qsym, const float* __restrict__ m_base, const int* __restrict__ arg_base,
     const double* __restrict__ stats_base, long stats_stride, const int* __restrict__ slots, double alphaM,
-    double* __restrict__ part) {
+    double* __restrict__ part, int c_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char trr_lds[];
   const int S = P.S;
   const long M = P.M, ld = P.ld;
   const int nw = 2 * (S - 1), nc = nw + 1;
   double* acc = reinterpret_cast<double*>(trr_lds);                   // [nc] column sums of the block
-  float* E = reinterpret_cast<float*>(acc + nc);                      // [S][2][64] e22 of the current chunk
+  double* Ctab = c_tab ? acc + nc : nullptr;                          // [2][S-1][TAIL_CSTRIDE] the sweep's terms per lane
+  float* E = reinterpret_cast<float*>(acc + nc + (c_tab ? tail_ctab_doubles(S) : 0));   // [S][2][64] e22 of the current chunk
   const int K = gridDim.y, kk = blockIdx.y;
   const long slot = slots ? slots[kk] : 0;
   const float* __restrict__ mvals = m_base + slot * M;
@@ -719,7 +767,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
       t0 = a - r0 * S;
     }
   }
-  drone_tail_block(P, uk, dW, mass, Qsym, w0f, t0, r0, acc, E);
+  drone_tail_block(P, uk, dW, mass, Qsym, w0f, t0, r0, acc, E, Ctab);
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
@@ -1423,8 +1471,14 @@ extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const do
       !Qsym || !m_base || !arg_base || !stats_base || !part || K < 1 || K > 65535 || (!slots && K != 1) ||
       stats_stride < 11)
     return RATO_EINVAL;
-  const size_t lds = (size_t)(2 * (p->S - 1) + 1) * sizeof(double) + (size_t)p->S * 2 * RATO_WAVE * sizeof(float);
+  size_t lds = (size_t)(2 * (p->S - 1) + 1) * sizeof(double) + (size_t)p->S * 2 * RATO_WAVE * sizeof(float);
   if (lds + 4096 > 160 * 1024) return RATO_EINVAL;   // S <= 300 (4 KB: the static lists of the tail compaction)
+  // the sweep's per-lane terms in LDS (summed after the sweep) while two workgroups still fit a CU; RATO_TAIL_CTAB=0: the
+  // wave-wide sum inside every step of the sweep
+  static const int ctab_env = [] { const char* e = getenv("RATO_TAIL_CTAB"); return e ? atoi(e) : 1; }();
+  const size_t lds_c = lds + tail_ctab_doubles(p->S) * sizeof(double);
+  const int c_tab = (ctab_env && lds_c + 4096 <= 80 * 1024) ? 1 : 0;
+  if (c_tab) lds = lds_c;
   static rato::DynamicLdsLimit lds_limit;
   {
     const hipError_t e = lds_limit.ensure(lds, [](size_t bytes) {
@@ -1456,7 +1510,7 @@ extern "C" int rato_drone_tail_rows_rollout(const rato_drone_params* p, const do
   }
   dim3 grid((unsigned)rato::nblocks_for(p->M), (unsigned)K), block(RATO_BLOCK);
   hipLaunchKernelGGL(drone_tail_rows_rollout_kernel, grid, block, lds, rato::as_stream(stream), *p, uk, dW, mass, Qsym,
-                     m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part);
+                     m_base, arg_base, stats_base, (long)stats_stride, slots, alphaM, part, c_tab);
   RATO_LAUNCH_CHECK();
   return RATO_OK;
 }
