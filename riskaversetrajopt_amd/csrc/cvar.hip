@@ -583,6 +583,28 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_rowmax_rollout_kernel(
   arg_out[m] = bi;
 }
 
+// maximum of a non-negative int over the wave, in every lane (DPP tree: no LDS crossbar round trips)
+__device__ __forceinline__ unsigned wave_max_nonneg_dpp(int v) {
+  unsigned a = (unsigned)v;
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x111, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x112, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false));
+  a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+}
+
+#ifndef RATO_TDIAG
+#define RATO_TDIAG 0   // diagnostic build (tools/tail_timeline.py): 100 MHz ticks of the phases of drone_tail_rows_rollout_kernel
+#endif                 // replace the block's row of `part` (thread 0: wave 0 = the x axis)
+#if RATO_TDIAG
+#define TSTAMP(i) do { if (threadIdx.x == 0) tdiag[i] = (double)wall_clock64(); } while (0)
+__shared__ double tdiag[12];
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 constexpr int TAIL_CSTRIDE = RATO_WAVE + 1;   // row stride of the sweep's term table (doubles): column threads on distinct banks
 __host__ __device__ inline size_t tail_ctab_doubles(int S) { return (size_t)2 * (S - 1) * TAIL_CSTRIDE; }
 
@@ -599,10 +621,12 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   TailLane unused;
   TailLists lists;
+  TSTAMP(1);
   const int n_tail = compact_tail(w0f, t0, r0, (long)blockIdx.x * RATO_BLOCK, M, unused, &lists);
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) acc[i] = 0.0;
   __shared__ double s_pt[2][RATO_WAVE];   // p_{t*+1} of the chunk's samples, one axis per wave
   __syncthreads();
+  TSTAMP(2);
   // The two horizontal axes are independent chains (forward and adjoint) that meet only in the arg-max row's gradient:
   // wave a runs axis a.  One wave running both was bound by the latency of its own chain (a block has one wave of work).
   const double dt = P.dt64, kp = P.kp64, kd = P.kd64, drag = P.drag64;
@@ -615,16 +639,19 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
     const double w = on ? (double)lists.w[c0 + lane] : 0.0;
     const int tr = on ? lists.tr[c0 + lane] : 0;
     const int ts = tr & 0xfffff, rs = tr >> 20;
-    int t_hi = 0;   // wave-uniform: the forward pass only has to reach the largest t* of the chunk
-    {
-      int tm = on ? ts : 0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) tm = max(tm, __shfl_xor(tm, off, RATO_WAVE));
-      t_hi = __builtin_amdgcn_readfirstlane(tm);
-    }
+    // wave-uniform: the forward pass only has to reach the largest t* of the chunk
+    const int t_hi = (int)wave_max_nonneg_dpp(on ? ts : 0);
     double inv_m = 0.0, a21 = 0.0, dtm = 0.0;
+    float qf[3] = {0.0f, 0.0f, 0.0f};
     if (a < 2) {
-      inv_m = 1.0 / (double)mass[m];
+      // (everything the chunk reads from global memory is requested here, in front of the forward pass: the arg-max row's
+      //  Q used to be fetched behind it -- one more memory round trip in the chain of the block's only working waves)
+      const float mass_f = mass[m];
+      if (on) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qf[c] = Qsym[(size_t)(rs * 3 + c) * ld + m];
+      }
+      inv_m = 1.0 / (double)mass_f;
       a21 = -kp * dt * inv_m;
       dtm = dt * inv_m;
       const double cn = sqrt(dt) * P.beta64 * inv_m;
@@ -634,7 +661,7 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
       auto load = [&](float (&xi)[TB], int tb) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
-          const int t = (tb + i <= t_hi) ? tb + i : t_hi;
+          const int t = (tb + i < S) ? tb + i : S - 1;
           xi[i] = dW[((size_t)t * 3 + a) * ld + m];
         }
       };
@@ -657,21 +684,26 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
       };
       float xa[TB], xb[TB];
       load(xa, 0);
+#if RATO_TDIAG
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSTAMP(3);
+#endif
       for (int tb = 0; tb <= t_hi; tb += 2 * TB) {
         load(xb, tb + TB);
         steps(xa, tb);
         load(xa, tb + 2 * TB);
         steps(xb, tb + TB);
       }
+      TSTAMP(4);
     }
     __syncthreads();   // both axes' positions are in s_pt
+    TSTAMP(5);
     if (a < 2) {
       // g and grad_p g of the arg-max row at p_{t*+1}; adjoint sweep of this wave's axis:
       // mu_{t*+1} = e_0', mu_k = mu_{k+1} A_k; column k-1 of the row = W . (mu_k)[1] dt/m
       double wa = 0.0, gval = 0.0;
       if (on) {
-        const double q00 = (double)Qsym[(size_t)(rs * 3 + 0) * ld + m], qss = (double)Qsym[(size_t)(rs * 3 + 1) * ld + m],
-                     q11 = (double)Qsym[(size_t)(rs * 3 + 2) * ld + m];
+        const double q00 = (double)qf[0], qss = (double)qf[1], q11 = (double)qf[2];
         const double dx = s_pt[0][lane] - P.obs_xy64[rs][0], dy = s_pt[1][lane] - P.obs_xy64[rs][1];
         gval = 1.0 - (q00 * dx * dx + qss * dx * dy + q11 * dy * dy);
         const double wx = -(2.0 * q00 * dx + qss * dy), wy = -(qss * dx + 2.0 * q11 * dy);
@@ -708,8 +740,10 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
         const double sg = rato::wave_sum_dpp(w * gval);
         if (lane == 0) acc[nw] += sg;
       }
+      TSTAMP(6);
     }
     __syncthreads();   // s_pt and the tables are free for the next chunk
+    TSTAMP(7);
     if (Ctab) {
       // columns 0 .. t_hi - 1 of both axes: one thread per (axis, column) adds the 64 lanes' terms in lane order.  (In
       // the sweep a wave-wide fp64 sum per step was 20 of the ~35 instructions of a step of the only wave on its SIMD.)
@@ -731,6 +765,10 @@ __device__ __forceinline__ void drone_tail_block(const rato_drone_params& P, con
   }
   if (!Ctab && cols_in_regs && a < 2 && lane < S - 1) acc[lane * 2 + a] = colsum;
   __syncthreads();
+  TSTAMP(8);
+#if RATO_TDIAG
+  if (threadIdx.x == 0) tdiag[9] = (double)n_tail;
+#endif
 }
 
 // The cut of the rollout form: the tail samples of the block (compacted, walked by wave 0 in chunks of 64) re-run the
@@ -747,6 +785,7 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
   const long M = P.M, ld = P.ld;
   const int nw = 2 * (S - 1), nc = nw + 1;
   double* acc = reinterpret_cast<double*>(trr_lds);                   // [nc] column sums of the block
+  TSTAMP(0);
   double* Ctab = c_tab ? acc + nc : nullptr;                          // [2][S-1][TAIL_CSTRIDE] the sweep's terms per lane
   float* E = reinterpret_cast<float*>(acc + nc + (c_tab ? tail_ctab_doubles(S) : 0));   // [S][2][64] e22 of the current chunk
   const int K = gridDim.y, kk = blockIdx.y;
@@ -768,6 +807,11 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
     }
   }
   drone_tail_block(P, uk, dW, mass, Qsym, w0f, t0, r0, acc, E, Ctab);
+#if RATO_TDIAG
+  __syncthreads();
+  if (threadIdx.x < 12) acc[threadIdx.x] = threadIdx.x == 10 ? (double)wall_clock64() : tdiag[threadIdx.x];
+  __syncthreads();
+#endif
   for (int i = threadIdx.x; i < nc; i += RATO_BLOCK) part[((size_t)blockIdx.x * K + kk) * nc + i] = acc[i];
 }
 
