@@ -25,6 +25,7 @@
 #include <utility>
 #include <vector>
 
+#include "rato_common.h"
 #include "rato_saa.h"
 
 namespace {
@@ -91,6 +92,7 @@ struct rato_cut_solver {
   int nU = 0, n = 0, nc = 0, nres = 0, nblk = 0;
   std::vector<double> p_diag, q;
   hipEvent_t sums_ready = nullptr;   // rato_cut_define_drone: recorded behind the linearization's sample sums (lazily created)
+  bool kept_armed = false;           // sums_b_host was pre-set before the kept cuts' launch in flight (readback_arm): the wait may watch it
   const void* params() const { return c.system == 0 ? (const void*)&drone : (const void*)&car; }
   ~rato_cut_solver() {
     if (sums_ready) (void)hipEventDestroy(sums_ready);
@@ -221,6 +223,8 @@ extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int
   if (with_cuts && !keep_ok(s, keep, n_keep)) return RATO_EINVAL;
   const int rc = stage_inputs(s, u_lin, nullptr, nullptr, keep, with_cuts ? n_keep : 0, st);
   if (rc != RATO_OK) return rc;
+  s->kept_armed = with_cuts && rato::readback_poll_enabled();
+  if (s->kept_armed) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);
   return kept_cuts_launch(s, with_cuts ? n_keep : 0, stream);
 }
 
@@ -246,6 +250,12 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
   if (with_cuts && !keep_ok(s, keep, n_keep)) return RATO_EINVAL;
   for (int i = 0; i < nU; ++i) us_host[i] = (float)us[i];
   hipError_t e = hipSuccess;
+  // the sample sums land in pinned memory and are watched for (rato_common.h: readback_*); with the non-finite count
+  // (a copy node behind them) the event below is waited for instead
+  const bool watch = rato::readback_poll_enabled() && !bad_dev;
+  if (watch) rato::readback_arm(sums_host, ncols);
+  s->kept_armed = with_cuts && rato::readback_poll_enabled();
+  if (s->kept_armed) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);
   int rc = stage_inputs(s, us, us_host, us_dev, keep, with_cuts ? n_keep : 0, st);   // us, u_k (fp64) and the kept slots: one launch
   if (rc != RATO_OK) return rc;
   rc = rato_drone_linearize_generators(&s->drone, us_dev, s->c.s0, s->c.s1, s->c.s2, A22, nullptr, nullptr, Z, part,
@@ -260,14 +270,16 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
   }
   // The host continues (sample sums -> equality rows -> the master's factorisation) as soon as the SUMS are back; the kept
   // cuts' re-linearization behind them is waited for by rato_cut_solve(kept_in_flight = 1), after it has built the master.
-  if (!s->sums_ready) {
-    e = hipEventCreateWithFlags(&s->sums_ready, hipEventDisableTiming);
+  if (!watch) {
+    if (!s->sums_ready) {
+      e = hipEventCreateWithFlags(&s->sums_ready, hipEventDisableTiming);
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
+    }
+    e = hipEventRecord(s->sums_ready, st);
     if (e != hipSuccess) return RATO_EHIP - (int)e;
   }
-  e = hipEventRecord(s->sums_ready, st);
-  if (e != hipSuccess) return RATO_EHIP - (int)e;
   if ((rc = kept_cuts_launch(s, with_cuts ? n_keep : 0, stream)) != RATO_OK) return rc;
-  e = hipEventSynchronize(s->sums_ready);
+  e = watch ? rato::readback_wait(sums_host, ncols, st) : hipEventSynchronize(s->sums_ready);
   if (e != hipSuccess) return RATO_EHIP - (int)e;
   if (bad_host && *bad_host) return RATO_ENONFINITE;
   return RATO_OK;
@@ -321,7 +333,10 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
     if (!kept_in_flight) {
       if ((rc = rato_cut_begin(s, u_lin, keep, n_kept, stream)) != RATO_OK) return rc;
     }
-    hipError_t e = hipStreamSynchronize(st);
+    // (the kept cuts' sums were armed where they were launched: rato_cut_begin / rato_cut_define_drone)
+    const bool armed = s->kept_armed;
+    s->kept_armed = false;
+    hipError_t e = armed ? rato::readback_wait(c.sums_b_host, n_kept * nc, st) : hipStreamSynchronize(st);
     if (e != hipSuccess) return RATO_EHIP - (int)e;
     oracle_s += seconds_since(t0);
     t0 = std::chrono::steady_clock::now();

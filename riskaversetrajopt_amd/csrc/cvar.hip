@@ -470,7 +470,6 @@ __device__ __forceinline__ double max_f64(double a, double b) {
   return r;
 }
 constexpr int XARG_MAX = 192;
-constexpr uint64_t READBACK_PENDING = 0x7ff8dead5a5abeefull;   // (rato_cut_oracle_rollout: a word of res_host not yet written)
 struct XArg {
   double v[XARG_MAX];
 };
@@ -1649,15 +1648,9 @@ extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const
   if (S < 1 || M < 1) return RATO_EINVAL;
   const int nc = 2 * (S - 1) + 1;
   hipError_t e = hipSuccess;
-  // Read-back: the last launch writes the record into res_host (pinned, device-visible), and the host watches those words
-  // arrive instead of asking the runtime for the end of the stream (hipStreamSynchronize enqueues a completion packet behind
-  // the last kernel and waits for ITS signal: measured ~10 us per round trip, of ~70).  Every word is pre-set to a NaN
-  // payload no arithmetic produces; an aligned 8-byte store arrives whole.  RATO_CUT_POLL=0: hipStreamSynchronize.
-  static const int poll_env = [] { const char* v = getenv("RATO_CUT_POLL"); return v ? atoi(v) : 1; }();
+  // read-back: the last launch writes the record into res_host (pinned) and the host watches it arrive (rato_common.h)
   const int n_words = RATO_N_STATS + (S > 1 ? nc : 0);
-  volatile uint64_t* watch = reinterpret_cast<volatile uint64_t*>(res_host);
-  if (poll_env)
-    for (int i = 0; i < n_words; ++i) watch[i] = READBACK_PENDING;
+  if (rato::readback_poll_enabled()) rato::readback_arm(res_host, n_words);
   if (S * n_u > XARG_MAX) {   // long horizons: x goes through device memory; otherwise it rides in the kernel arguments
     e = hipMemcpyAsync(x_dev, x_host, sizeof(double) * (size_t)S * n_u, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return RATO_EHIP - (int)e;
@@ -1683,21 +1676,7 @@ extern "C" int rato_cut_oracle_rollout(int32_t system, const void* params, const
   // (res_host must be device-visible host memory: no copy node follows)
   rc = rato::launch_cut_finish(part_dev, (int)rato::nblocks_for(M), S > 1 ? nc : 0, res_dev, res_host, RATO_N_STATS, st);
   if (rc != RATO_OK) return rc;
-  if (poll_env) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; ++spins) {
-      int pending = 0;
-      for (int i = 0; i < n_words; ++i) pending += watch[i] == READBACK_PENDING;
-      if (!pending) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return RATO_OK;
-      }
-      __builtin_ia32_pause();
-      // a launch that failed never writes: after 2 s ask the runtime (which reports the error, or waits for a slow board)
-      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-    }
-  }
-  e = hipStreamSynchronize(st);
+  e = rato::readback_wait(res_host, n_words, st);
   if (e != hipSuccess) return RATO_EHIP - (int)e;
   return RATO_OK;
 }

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "rato_saa.h"
@@ -242,6 +245,39 @@ class TileQueuePool {
 // rec_host[0 .. n_stats) = rec_dev[0 .. n_stats) -- one launch (rec_host: pinned, device-visible host memory)
 int launch_cut_finish(const double* part, int nblocks, int ncols, double* rec_dev, double* rec_host, int n_stats,
                       hipStream_t st);
+
+// Read-back of a few doubles that a kernel writes into PINNED, device-visible host memory: the host pre-sets every word
+// to a NaN payload no arithmetic produces (arm) and then watches the words arrive (wait) instead of asking the runtime
+// for the end of the stream -- hipStreamSynchronize / hipEventSynchronize enqueue a completion packet behind the last
+// kernel and wait for ITS signal: ~6-10 us per wait on this stack, and an event in the middle of a stream was seen to
+// resolve only behind LATER kernels.  An aligned 8-byte store arrives whole.  After 2 s without the words the runtime is
+// asked after all (a failed launch never writes: the error comes out there).  RATO_CUT_POLL=0: always ask the runtime.
+constexpr uint64_t READBACK_PENDING = 0x7ff8dead5a5abeefull;
+inline bool readback_poll_enabled() {
+  static const int v = [] { const char* e = getenv("RATO_CUT_POLL"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+inline void readback_arm(double* host, int n) {
+  volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(host);
+  for (int i = 0; i < n; ++i) w[i] = READBACK_PENDING;
+}
+inline hipError_t readback_wait(const double* host, int n, hipStream_t st) {   // st: what to synchronise if the words stay away
+  if (readback_poll_enabled()) {
+    const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(host);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+      int pending = 0;
+      for (int i = 0; i < n; ++i) pending += w[i] == READBACK_PENDING;
+      if (!pending) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return hipSuccess;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
+  }
+  return hipStreamSynchronize(st);
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember, per device, the largest size a
 // launch site has raised its kernels to (the first, uncaptured call of a shape makes the runtime call; later calls --

@@ -746,7 +746,10 @@ class Model:
             # the benchmarked configuration: define (rato_cut_define_drone) and solve (rato_cut_solve) are one native call each
             cs = self._reduced_cut_solver(int(self._inputs(None)[3]), mass.numel())
             cs.implicit = None
-            cs.rollout = ("drone", self._params(cs.M, mass.numel()), dW, mass, Qsym)
+            rp = getattr(self, "_rollout_params", None)      # (built once: ~20 us of ctypes field stores per call otherwise)
+            if rp is None or rp[0] != (cs.M, mass.numel()):
+                rp = self._rollout_params = ((cs.M, mass.numel()), self._params(cs.M, mass.numel()))
+            cs.rollout = ("drone", rp[1], dW, mass, Qsym)
             cs.check_finite = False
             if cs.native_loop_applies():
                 return self._solve_reduced_native(cs, us_mat_p, scp_iter, tol)
