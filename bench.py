@@ -70,8 +70,8 @@ def parse():
                          "on every rank, instead of falling back to torch.distributed's collective with a warning")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as ONE captured hipGraph (kernel time then comes from an eager pre-pass "
-                         "with HIP events, since events cannot bracket a node inside a graph).  auto = on for "
-                         "M <= 50,000 (BASELINE C2-C4), where an eager step is bound by host launch time, not by the GPU")
+                         "with HIP events, since events cannot bracket a node inside a graph).  auto = for "
+                         "M <= 50,000 (BASELINE C2-C4) probe replayed against eager back-to-back steps and time the faster form")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=None,
                     help="run the exchange + risk statistics of step i on a side stream while the hot kernel of step "
                          "i+1 runs (two output slots; dist.PipelinedSteps).  DEFAULT FOR N > 1: every rank runs the exact "
@@ -508,6 +508,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             raise SystemExit(3)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    eager_small, launch_probe = False, None
     use_graph = world == 1 and not args.overlap and (args.graph == "on" or (args.graph == "auto" and M <= 50000))
     pipelined = args.overlap and not use_graph
     # N > 1 (default) / --overlap: the exchange + statistics of step n beside the hot kernel of step n+1 (dist.PipelinedSteps)
@@ -580,13 +581,33 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         # clocks the capture pause and the spin kernel left behind; then the W warm-up steps proper
         for _ in range(200 + args.warmup):
             graph.replay()
+        torch.cuda.synchronize()
+        if args.graph == "auto":
+            # --graph auto: the timed steps are replayed or issued eagerly (back to back, no events: the kernel time comes
+            # from the pre-pass above), whichever a probe of both finds faster on this host.  A replay costs ~10 us + 3.4 us
+            # per node before any work on this stack (configs.launch_floor); an eager step costs the device's launch
+            # spacing (~4-5 us per kernel) as long as the host issues faster than the device works.
+            def probe(fn, n=150):
+                for _ in range(30):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e6
+            launch_probe = {"replay_us": probe(graph.replay), "eager_us": probe(step)}
+            if launch_probe["eager_us"] < launch_probe["replay_us"]:
+                eager_small = True
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if use_graph:
+        if use_graph and not eager_small:
             graph.replay()
+        elif eager_small:
+            step()
         else:
             step(i)
     if pipe is not None:
@@ -623,7 +644,10 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         except Exception as e:                          # a diagnostic must never take the bench line down
             print(f"note: clock probe skipped ({e})", file=sys.stderr)
     final_stats = stats_out[(counter[0] - 1) & 1].cpu().numpy()
-    launch = ("hipGraph replay of the whole step" + (" (the statistics ride in the kernel's own launch)" if in_launch else "")) if use_graph else (
+    launch = (("eager steps back to back, one stream (probe: %.1f us per eager step, %.1f replayed)" % (launch_probe["eager_us"], launch_probe["replay_us"]))
+              if eager_small else
+              "hipGraph replay of the whole step" + (" (the statistics ride in the kernel's own launch)" if in_launch else "")
+              + ((" (probe: %.1f us per replayed step, %.1f eager)" % (launch_probe["replay_us"], launch_probe["eager_us"])) if launch_probe else "")) if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream beside the hot kernel of step n+1 (dist.PipelinedSteps)"
         if pipelined else "eager, one stream, no overlap between steps")
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
@@ -1004,7 +1028,7 @@ def configs_block(args, device, stats, rdist, dist, torch):
                     out[name]["rank_local"] = {"error": repr(e)}
             if mode == "eval":
                 out[name]["form"] = ("the reference's Monte-Carlo validation step (rollout -> max -> fraction / VaR / AVaR), one "
-                                     "control sequence per replayed step: rollout kernel + exact selection, two nodes")
+                                     "control sequence per step: rollout kernel + exact selection, two launches (see `launch`)")
                 out[name]["batched"] = mc_batch_block(work, torch)
             del work
             torch.cuda.empty_cache()

@@ -129,6 +129,17 @@ class Model:
 
     # ---- plumbing ----------------------------------------------------------
     def _params(self, M):
+        """a fresh rato_car_params (a copy of a template built once per (M, S, dt, beta, ego state): see drone_risk)"""
+        key = (M, self.S, self.dt, self.beta, tuple(float(v) for v in self._ego_init))
+        cache = self.__dict__.setdefault("_params_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 64:
+                cache.clear()
+            t = cache[key] = self._params_build(M)
+        return _lib.CarParams.from_buffer_copy(t)
+
+    def _params_build(self, M):
         p = _lib.CarParams()
         p.M, p.S, p.dt, p.beta = M, self.S, self.dt, self.beta
         p.speed_ped_des = P.speed_ped_des

@@ -129,6 +129,18 @@ class Model:
         return inputs if inputs is not None else (self._dW, self._mass, self._Qsym, self.M)
 
     def _params(self, M, ld, rows_out=0):
+        """a fresh rato_drone_params for this Model (callers set the stats_* fields on it): a copy of a template built once
+        per (M, ld, rows_out, S, dt, beta, drag) -- ~40 ctypes field stores cost 15-20 us, more than a small kernel"""
+        key = (M, ld, int(rows_out), self.S, self.dt, self.beta, self.drag_coefficient)
+        cache = self.__dict__.setdefault("_params_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 64:
+                cache.clear()
+            t = cache[key] = self._params_build(M, ld, rows_out)
+        return _lib.DroneParams.from_buffer_copy(t)
+
+    def _params_build(self, M, ld, rows_out=0):
         p = _lib.DroneParams()
         p.M, p.ld, p.S = M, ld, self.S
         p.rows_out = int(rows_out)      # 1: the linearize kernels write g (not g_up = -g + G u_k) into their g_up buffer
