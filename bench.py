@@ -743,8 +743,9 @@ def scp_kernels_block(model, out, args):
     FP64_OPS = 256 * 4 * 16 * 2.4e9                                               # vector fp64 instructions-lanes per second
     rows = {
         "drone_rowmax_rollout_kernel": {"us": t_row, "calls": trips, "bound": "fp64 instruction issue",
-                                        "frac": M * S * 60 / (t_row * 1e-6) / FP64_OPS,
-                                        "how": "60 fp64 operations per sample-step against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one "
+                                        "frac": M * S * 57 / (t_row * 1e-6) / FP64_OPS,
+                                        "how": "57 fp64 instructions per sample-step (counted in the ISA of the main loop: 38 fma, 7 add, "
+                                               "4 mul, 3 max, 3 compare, 2 convert) against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one "
                                                "wave64 fp64 instruction per 4 cycles per SIMD).  That peak needs 8 waves per SIMD: "
                                                "measured (tools/fp64bench.hip, profiles/r05_fp64bench.txt) a SIMD issues one per "
                                                "10.4 / 5.9 / 5.5 / 4.7 cycles with 1 / 2 / 4 / 8 resident waves whatever their "

@@ -26,3 +26,9 @@ for system, M, S in [("drone", 10000, 50), ("driving", 10000, 40)]:
     for _ in range(n): g.replay()
     torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / n * 1e6
     print(f"{system} M={M} S={S}: eager {t_eager:.1f} us per step (host issue {t_host:.1f}) | replayed graph {t_graph:.1f}")
+    step_in = lambda: d.mc_step_device(us, workspace=ws, stats_out=st, out=bufs, in_launch=True)
+    for _ in range(200): step_in()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step_in()
+    torch.cuda.synchronize()
+    print(f"    statistics in the rollout's own launch, eager: {(time.perf_counter() - t0) / n * 1e6:.1f} us per step")
