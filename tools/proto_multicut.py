@@ -69,8 +69,19 @@ for k in range(iters):
     out = [f"scp {k}: Kelley {trips_ref:3d} trips"]
     # ---- multi-cut: variables (u, s, t, y_1..y_NG)
     for NG in NGS:
+        if NG < 0:
+            # groups by the RANK of m at the linearization point (descending): a deep-tail group that stays active, thin bands
+            # around the threshold where the samples enter and leave the tail, and the rest
+            edges = {-3: [0.09, 0.11, 1.0], -4: [0.085, 0.10, 0.115, 1.0], -6: [0.07, 0.09, 0.10, 0.11, 0.13, 1.0],
+                     -8: [0.06, 0.08, 0.09, 0.10, 0.11, 0.12, 0.14, 1.0]}[NG]
+            m_lin = rows_at(G, base, np.zeros(nU))[0]
+            rank = np.empty(M, dtype=np.int64); rank[np.argsort(-m_lin, kind="stable")] = np.arange(M)
+            grp = np.searchsorted(np.array(edges) * M, rank, side="right")
+            label, NG = NG, len(edges)
+        else:
+            label = NG
+            grp = (np.arange(M) * NG) // M                  # contiguous groups of samples (the device: blocks of 256)
         nv = nU + 2 + NG
-        grp = (np.arange(M) * NG) // M                      # contiguous groups of samples (the device: blocks of 256)
         Q = np.zeros((nv, nv)); Q[:n, :n] = cs._Pd
         Q[n:, n:] = EPS * np.eye(1 + NG)
         qv = np.concatenate([cs.q, np.zeros(1 + NG)])
@@ -104,6 +115,6 @@ for k in range(iters):
             viol = phi - cs.c_s * s - cs.rhs0
             if viol <= 1e-9 or trips > 400:
                 break
-        out.append(f"NG={NG}: {trips:3d} trips |dz| {np.abs(z[:n] - z_ref).max():.1e}")
+        out.append(f"NG={label}: {trips:3d} trips |dz| {np.abs(z[:n] - z_ref).max():.1e}")
     print(" | ".join(out), flush=True)
     us = z_ref[:nU].reshape(S, 3)
