@@ -18,8 +18,12 @@
  *     loop and say so where they are declared: rato_stream_synchronize,
  *     rato_cut_oracle_rollout (one oracle round trip of the cutting-plane loop:
  *     its results are read by the host master) and rato_cut_solve (the whole
- *     loop of one SCP subproblem).  Each waits for `stream` only
- *     (hipStreamSynchronize), never for the device.
+ *     loop of one SCP subproblem).  Each waits for the work it issued on
+ *     `stream` only, never for the device: by watching the words its last
+ *     launch writes into the caller's PINNED host buffers arrive (every kernel
+ *     in front of that launch has then completed; the HIP runtime is asked --
+ *     hipStreamSynchronize -- only when RATO_CUT_POLL=0 is set or the words stay
+ *     away for 2 s, e.g. after a failed launch, whose error comes out there).
  *   - no global state beyond cached device properties (CU count, LDS attribute) and, for the row-parallel
  *     linearize kernels on large batches, one self-cleaning two-word work queue per STREAM in device memory
  *     (up to 64 streams; launches on one stream are ordered and share it, a 65th stream falls back to the static
@@ -511,7 +515,9 @@ int rato_car_tail_rows_rollout(const rato_car_params* p, const double* uk, const
  *   x_host [S][n_u] doubles (pinned for an asynchronous copy) -> x_dev;  m_out / arg_out = rato_*_rowmax_rollout;
  *   res_dev[0..11) = rato_risk_stats(m_out, alpha, thr);  S > 1: part_dev = rato_*_tail_rows_rollout (K = 1, record =
  *   res_dev, stride 11 + nc), res_dev[11..11+nc) = its column sums, nc = 2(S-1) + 1;  res_dev -> res_host (PINNED,
- *   device-visible host memory: the last launch writes it directly, no copy node follows);  the stream is SYNCHRONISED before the call returns.  Replaces two copies, four calls and a synchronize of the host loop
+ *   device-visible host memory: the last launch writes it directly, no copy node follows);  the call RETURNS WHEN THE
+ *   RECORD HAS ARRIVED in res_host (see the conventions at the top: res_host is pre-set and watched; RATO_CUT_POLL=0:
+ *   hipStreamSynchronize).  Replaces two copies, four calls and a synchronize of the host loop
  *   (drone_risk.py:425-469 hands the whole QP to OSQP; here every cut of the reduced subproblem is one such trip).
  */
 int rato_cut_oracle_rollout(int32_t system, const void* params, const double* uk, const float* s0, const float* s1,
@@ -602,9 +608,10 @@ int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int32_t* keep,
  * (through the pinned us_host), rato_drone_linearize_generators at them without tables (A22 [S][3][ld]: kernel scratch;
  * Z [z_floats >= M] or NULL; part [ceil(M/256)][6S+6]), the sample sums reduced straight into sums_host (pinned, 6S+6 doubles),
  * the non-finite count of Z and part (bad_dev / bad_host pinned, or both NULL), rato_cut_begin(us, keep, n_keep).  WAITS
- * for the sample sums and the count only (an event behind them): the kept cuts' sums may still be in flight when it
- * returns -- follow with rato_cut_solve(kept_in_flight = 1), which builds the master first and then synchronises the stream
- * (or synchronise it yourself before reading sums_b_host).  RATO_ENONFINITE when the count is not zero. */
+ * for the sample sums only (watched in sums_host; with the non-finite count: an event behind the count's copy): the kept
+ * cuts' sums may still be in flight when it returns -- follow with rato_cut_solve(kept_in_flight = 1), which builds the
+ * master first and then waits for them (or synchronise the stream yourself before reading sums_b_host).
+ * RATO_ENONFINITE when the count is not zero. */
 int rato_cut_define_drone(rato_cut_solver* s, const double* us, float* us_host, float* us_dev, float* A22, float* Z,
                           int64_t z_floats, float* part, double* sums_host, uint32_t* bad_dev, uint32_t* bad_host,
                           const int32_t* keep, int32_t n_keep, void* stream);
