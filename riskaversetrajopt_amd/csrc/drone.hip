@@ -15,6 +15,7 @@
 
 #include "philox.h"
 #include "rato_common.h"
+#include <type_traits>
 #include "rato_select.h"
 
 namespace {
@@ -343,19 +344,37 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   constexpr int TB = 8;   // the noise of 8 steps (24 loads) is requested as one batch and the NEXT batch is in flight while a
                           // batch is consumed (two register buffers): the kernel is bound by load latency (one lane per
                           // sample, 50 sequential steps), not by bandwidth or flops
-  auto load_noise = [&](float (&xib)[TB][3], int t0) {
+  // Addresses: every array is walked through a UNIFORM row pointer (scalar registers) advanced by whole rows + the lane's
+  // 32-bit sample offset -- the rows' 64-bit index arithmetic was a quarter of this kernel's instructions, and the kernel is
+  // bound by instruction issue (~200 instructions per forward + backward step of the one or two waves of a SIMD).  The
+  // pointers stop at the last row, so a batch requested past the horizon re-reads row S - 1 (never consumed).
+  // (byte offsets as 32-bit numbers: `uniform pointer + zero-extended 32-bit lane offset` is the form the global
+  //  load / store instructions take directly -- scalar base, one offset register -- with no per-access 64-bit add)
+  const unsigned boff0 = (unsigned)m * 4u, boff1 = (unsigned)(ld + m) * 4u, boff2 = (unsigned)(2 * ld + m) * 4u;
+  auto at = [](const float* base, unsigned boff) -> const float& {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+  };
+  auto at_w = [](float* base, unsigned boff) -> float& {
+    return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff);
+  };
+  const size_t row3 = 3 * ld;
+  const float* nz = dW;                      // row 3 t of the noise
+  const float* const nz_last = dW + (size_t)(S - 1) * row3;
+  float* a22w = A22;                         // row 3 t of the table being written
+  auto load_noise = [&](float (&xib)[TB][3]) {   // the next 8 steps' noise
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-      const int tt = (t0 + i < S) ? t0 + i : S - 1;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) xib[i][a] = dW[(size_t)(tt * 3 + a) * ld + m];
+      xib[i][0] = at(nz, boff0);
+      xib[i][1] = at(nz, boff1);
+      xib[i][2] = at(nz, boff2);
+      nz = (nz != nz_last) ? nz + row3 : nz;
     }
   };
-  auto forward_steps = [&](const float (&xib)[TB][3], int t0) {
+  auto forward_steps = [&](const float (&xib)[TB][3], int t0, auto guarded) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
     const int t = t0 + i;
-    if (t < S) {
+    if (!decltype(guarded)::value || t < S) {
     const float* xi = xib[i];
     double a22[3];
 #pragma unroll
@@ -365,8 +384,9 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
       // product of up to S of them.  The consumers rebuild a22 = 1 - e22 in fp64 from the SAME fp32 number.
       const float e22 = (float)fma(c22, fabs(v[a]), c1);   // dt (kd + 2 drag |v|) / m
       a22[a] = 1.0 - (double)e22;
-      if (valid) A22[((size_t)t * 3 + a) * ld + m] = e22;
+      if (valid) at_w(a22w, a == 0 ? boff0 : (a == 1 ? boff1 : boff2)) = e22;
     }
+    a22w += row3;
     // d x_{t+1} = A_t d x_t + B u_t  (x, y): the forward form of the adjoint row sweep; d p(t+1) = (Phi u_bar)[t]
     if (TABLES) {
 #pragma unroll
@@ -406,12 +426,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   };
   {
     float xa[TB][3], xb[TB][3];
-    load_noise(xa, 0);
+    load_noise(xa);
+    // (every step behind its guard: whole unguarded batches, as in the cut oracle's rowmax kernel, let the scheduler hoist
+    //  two batches' loads and conversions and took this kernel from 139 to 298 registers -- one wave per SIMD, or spills)
     for (int t0 = 0; t0 < S; t0 += 2 * TB) {
-      load_noise(xb, t0 + TB);
-      forward_steps(xa, t0);
-      load_noise(xa, t0 + 2 * TB);
-      forward_steps(xb, t0 + TB);
+      load_noise(xb);
+      forward_steps(xa, t0, std::true_type{});
+      load_noise(xa);
+      forward_steps(xb, t0 + TB, std::true_type{});
     }
   }
   if (WANT_Z && Z && valid) Z[m] = (float)(zmax - P.tol64);
@@ -445,24 +467,27 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   for (int a = 0; a < 3; ++a) {
     mP0[a] = 1.0; mP1[a] = 0.0; mV0[a] = 0.0; mV1[a] = 1.0; dP[a] = 0.0; dV[a] = 0.0;
   }
-  auto load_e22 = [&](float (&e22b)[TB][3], int sb) {   // the table entries of 8 steps (same lane wrote them: program order)
+  const float* a22r = A22 + (size_t)(S - 1) * row3;   // row 3 s of the table being read back (stops at row 0)
+  auto load_e22 = [&](float (&e22b)[TB][3]) {   // the table entries of the next 8 steps down (same lane wrote them: program order)
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-      const int k = (sb - i > 0) ? sb - i : 0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) e22b[i][a] = A22[((size_t)k * 3 + a) * ld + m];
+      e22b[i][0] = at(a22r, boff0);
+      e22b[i][1] = at(a22r, boff1);
+      e22b[i][2] = at(a22r, boff2);
+      a22r = (a22r != A22) ? a22r - row3 : a22r;
     }
   };
-  auto backward_steps = [&](const float (&e22b)[TB][3], int sb) {
+  const double dtm_v = valid ? dtm : 0.0;   // a lane past the batch contributes zeros to every sum (no select per number)
+  auto backward_steps = [&](const float (&e22b)[TB][3], int sb, auto guarded) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
     const int s2 = sb - i;
-    if (s2 >= 0) {
+    if (!decltype(guarded)::value || s2 >= 0) {
     double eP[3], eV[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      eP[a] = mP1[a] * dtm;
-      eV[a] = mV1[a] * dtm;
+      eP[a] = mP1[a] * dtm_v;
+      eV[a] = mV1[a] * dtm_v;
       const double ua = (double)us[s2 * 3 + a];
       dP[a] += eP[a] * ua;
       dV[a] += eV[a] * ua;
@@ -470,14 +495,14 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
 #if RATO_GEN_LDS_REDUCE
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      Tw[((i & 3) * 6 + a) * 65 + lane] = valid ? eP[a] : 0.0;
-      Tw[((i & 3) * 6 + 3 + a) * 65 + lane] = valid ? eV[a] : 0.0;
+      Tw[((i & 3) * 6 + a) * 65 + lane] = eP[a];
+      Tw[((i & 3) * 6 + 3 + a) * 65 + lane] = eV[a];
     }
 #else
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const double sp = rato::wave_sum_dpp(valid ? eP[a] : 0.0);
-      const double sv = rato::wave_sum_dpp(valid ? eV[a] : 0.0);
+      const double sp = rato::wave_sum_dpp(eP[a]);
+      const double sv = rato::wave_sum_dpp(eV[a]);
       if (lane == 0) {
         gen_red[(wave * (S + 1) + s2) * 6 + a] = sp;
         gen_red[(wave * (S + 1) + s2) * 6 + 3 + a] = sv;
@@ -501,12 +526,12 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
   };
   {
     float ea[TB][3], eb[TB][3];
-    load_e22(ea, S - 1);
+    load_e22(ea);
     for (int sb = S - 1; sb >= 0; sb -= 2 * TB) {
-      load_e22(eb, sb - TB);
-      backward_steps(ea, sb);
-      load_e22(ea, sb - 2 * TB);
-      backward_steps(eb, sb - TB);
+      load_e22(eb);
+      backward_steps(ea, sb, std::true_type{});
+      load_e22(ea);
+      backward_steps(eb, sb - TB, std::true_type{});
     }
   }
 #pragma unroll
