@@ -820,7 +820,10 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_tail_rows_rollout_kernel(
 // both axes into LDS; at every cut's own t* the position the row is evaluated at), then the waves take a cut each and sweep its
 // adjoint over the chunk.  Launched per cut (gridDim.y = K, the kernel above) the K x ceil(M/256) one-wave workgroups
 // took 104 us for 9 cuts at M = 1e5 -- five latency-bound rounds; this form costs one forward pass + ceil(K / 8) sweeps.
-constexpr int TRU_NW = 8, TRU_KMAX = 16;
+#ifndef RATO_TRU_NW
+#define RATO_TRU_NW 8   // waves per workgroup of the union pass (A/B builds)
+#endif
+constexpr int TRU_NW = RATO_TRU_NW, TRU_KMAX = 16;
 __host__ __device__ inline size_t tail_union_lds_bytes(int S, int K) {
   const size_t nc = 2 * (size_t)(S - 1) + 1;
   return sizeof(double) * ((size_t)K * nc + (size_t)K * 2 * RATO_WAVE) + sizeof(float) * (size_t)S * 2 * RATO_WAVE +
