@@ -473,7 +473,7 @@ def roofline_block(work, kern_ms, workload, mode, M, S, jacobian, kern_src):
             "traffic_from_profile": tr}
 
 
-def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, probe_clock=True):
+def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, probe_clock=True, two_streams=False):
     """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; -> dict."""
     M = work.M
     stats_out = torch.empty((2, stats.N_STATS), dtype=torch.float64, device=device)
@@ -602,12 +602,20 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    two = None
+    if two_streams and not use_graph and not pipelined:   # consecutive (independent) steps on alternating streams: the
+        two = [torch.cuda.Stream(), torch.cuda.Stream()]  # line's `two_streams` block, never its `value`
+        for s_ in two:
+            s_.wait_stream(torch.cuda.current_stream())
     t0 = time.perf_counter()
     for i in range(args.steps):
         if use_graph and not eager_small:
             graph.replay()
         elif eager_small:
             step()
+        elif two is not None:
+            with torch.cuda.stream(two[i & 1]):
+                step(i)
         else:
             step(i)
     if pipe is not None:
@@ -1023,6 +1031,11 @@ def configs_block(args, device, stats, rdist, dist, torch):
                          "traffic_from_profile": rb["traffic_from_profile"], "launch": res["launch"],
                          "stats": {"VaR": res["stats"][0], "CVaR": res["stats"][1], "frac_satisfied": res["stats"][2]}}
             if name == "C5":
+                try:   # (see the line's `two_streams` block: consecutive independent steps on alternating streams)
+                    r2 = timed_region(work, a, 1, 0, device, stats, rdist, dist, torch, probe_clock=False, two_streams=True)
+                    out[name]["two_streams_ms_per_step"] = 1e3 * r2["elapsed"] / K
+                except Exception as e:                     # noqa: BLE001
+                    out[name]["two_streams_ms_per_step"] = repr(e)
                 try:
                     out[name]["rank_local"] = c5_rank_local_block(work, a, device, stats, rdist, torch)
                 except Exception as e:                     # noqa: BLE001
@@ -1091,6 +1104,20 @@ def main():
         work = WORKLOADS[args.workload](args, device, seed=1000 * rank + 7)
         res = timed_region(work, args, world, rank, device, stats, rdist, dist, torch)
         res["work"], res["variant"] = work, var
+        if world == 1 and var == variants[0] and args.config == "metric" and is_drone_lin and not args.no_configs:
+            try:   # the same K steps with consecutive steps on two alternating streams (an extra block, outside `value`)
+                r2 = timed_region(work, args, world, rank, device, stats, rdist, dist, torch, probe_clock=False, two_streams=True)
+                res["two_streams"] = {
+                    "ms_per_step": 1e3 * r2["elapsed"] / args.steps, "value": work.M * work.S * args.steps / r2["elapsed"],
+                    "unit": "samples*steps/s",
+                    "what": "the metric configuration's K steps with consecutive steps issued on two alternating streams: the "
+                            "steps of this benchmark are independent of one another, so the drain of one linearize launch and "
+                            "its statistics overlap the ramp of the next (per-stream tile queues).  NOT the line's `value` "
+                            "(one stream, no overlap between steps): an SCP's consecutive linearizations depend on each "
+                            "other through the host's QP; a Monte-Carlo study over independent batches or control sequences "
+                            "can run this way.  Per-launch event times are meaningless here (two kernels share the chip)"}
+            except Exception as e:                           # noqa: BLE001
+                res["two_streams"] = {"error": repr(e)}
         results.append(res)
         if var != variants[-1]:
             del work.outs, work.records                  # free the 3 GB output slots before the next variant
@@ -1138,6 +1165,8 @@ def main():
                        "how": "shader-cycle counter against the 100 MHz counter, one wave on a second stream while the hot "
                               "kernel runs (rato_device_clock_probe); diagnostic, outside the timed region"},
         }
+        if head.get("two_streams"):
+            line["two_streams"] = head["two_streams"]
         for res in results[1:]:                           # the other output representation, same run, same samples
             w = res["work"]
             line["roofline_" + res["variant"]] = roofline_block(w, res["kern_ms"], args.workload, args.mode, M, S,
