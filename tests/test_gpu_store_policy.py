@@ -93,3 +93,37 @@ def test_driving_on_both_sides_of_the_policy_edges(M, streaming):
     for sl in (slice(0, 2), slice(-3, -1)):
         assert torch.equal(r["G"][sl], r2["G"][sl])
     assert torch.isfinite(r["G"][-2]).all()
+
+
+@pytest.mark.parametrize("factored", [False, True])
+def test_linearizations_on_two_alternating_streams_equal_the_one_stream_result(factored):
+    """Consecutive linearize launches issued on two alternating streams (bench.py's `two_streams` block; also what
+    dist.PipelinedSteps relies on) overlap on the chip: every stream has its own tile queue and the caller its own
+    output slot per stream, so both slots must hold, bit for bit, what one launch on one stream writes."""
+    import torch
+    from riskaversetrajopt_amd import drone_risk, drone_utils
+    M, S = 100000, 50
+    dW, mass, Q = drone_utils.sample_uncertain_parameters_device(M, S, seed=7)
+    d = drone_risk.Model.from_device(S, dW, mass, Q, 'saa', 0.1, M=M)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    ref = d.linearize_device(us, factored=factored)
+    torch.cuda.synchronize()
+    from riskaversetrajopt_amd.drone_risk import untile
+    keys = [k for k in ("G", "g_up", "Z", "W", "part") if isinstance(ref.get(k), torch.Tensor)]
+    valid = lambda k, r: untile(r[k], M) if k == "G" else (r[k][..., :M] if k == "W" else r[k])   # (not the padding lanes)
+    want = {k: valid(k, ref).clone() for k in keys}
+    outs = [d.linearize_device(us, factored=factored), d.linearize_device(us, factored=factored)]
+    torch.cuda.synchronize()
+    for o in outs:
+        for k in keys:
+            o[k].zero_()
+    two = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for i in range(12):
+        with torch.cuda.stream(two[i & 1]):
+            d.linearize_device(us, out=outs[i & 1], factored=factored)
+    torch.cuda.synchronize()
+    for o in outs:
+        for k in keys:
+            assert torch.equal(valid(k, o), want[k]), k
