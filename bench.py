@@ -1117,6 +1117,7 @@ def main():
                 res["two_streams"] = {
                     "ms_per_step": 1e3 * r2["elapsed"] / args.steps, "value": work.M * work.S * args.steps / r2["elapsed"],
                     "unit": "samples*steps/s",
+                    "algorithmic_GBps_over_the_whole_step": work.algorithmic_bytes() * args.steps / r2["elapsed"] / 1e9,
                     "what": "the metric configuration's K steps with consecutive steps issued on two alternating streams: the "
                             "steps of this benchmark are independent of one another, so the drain of one linearize launch and "
                             "its statistics overlap the ramp of the next (per-stream tile queues).  NOT the line's `value` "
