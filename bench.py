@@ -74,9 +74,9 @@ def parse():
                          "M <= 50,000 (BASELINE C2-C4) probe replayed against eager back-to-back steps and time the faster form")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=None,
                     help="run the exchange + risk statistics of step i on a side stream while the hot kernel of step "
-                         "i+1 runs (two output slots; dist.PipelinedSteps).  DEFAULT FOR N > 1: every rank runs the exact "
-                         "selection on all M_total gathered samples, which at C5 (1e6) is a third of the shard's kernel "
-                         "time when paid behind it.  Off by default at N = 1, where it gains nothing (DESIGN.md 5)")
+                         "i+1 runs (two output slots; dist.PipelinedSteps).  N > 1 without either flag: both forms are "
+                         "probed over 50 untimed steps and the faster one (slowest rank's clock) is timed.  Off by default "
+                         "at N = 1, where it gains nothing (DESIGN.md 5)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: kernel -> sums -> all-gather -> selection serially on one stream (A/B against the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -510,9 +510,15 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     eager_small, launch_probe = False, None
     use_graph = world == 1 and not args.overlap and (args.graph == "on" or (args.graph == "auto" and M <= 50000))
-    pipelined = args.overlap and not use_graph
-    # N > 1 (default) / --overlap: the exchange + statistics of step n beside the hot kernel of step n+1 (dist.PipelinedSteps)
-    pipe = rdist.PipelinedSteps(2, device) if pipelined else None
+    # --overlap: the exchange + statistics of step n beside the hot kernel of step n+1 (dist.PipelinedSteps).  N > 1
+    # default ("auto"): BOTH forms are probed over untimed steps after the warm-up and the faster one, by the slowest
+    # rank's clock, is timed -- beside a store-saturated kernel the selection over M_total samples runs several times
+    # slower and takes bandwidth from it, and which form wins differs from board to board (round 5: 178 serial / 191
+    # pipelined on the driver's board, 180 / 176 on another).
+    auto_form = args.overlap == "auto" and not use_graph
+    pipelined = bool(args.overlap) and not use_graph
+    pipe = rdist.PipelinedSteps(2, device, high_priority=bool(os.environ.get("RATO_PIPE_PRIORITY"))) if pipelined else None
+    form_probe = None
     counter = [0]
     in_launch = (world == 1 and not pipelined and hasattr(work, "stats_in_launch") and work.stats_in_launch()
                  and not os.environ.get("RATO_BENCH_NO_IN_LAUNCH"))
@@ -561,6 +567,31 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         step()
     if pipe is not None:
         pipe.drain()
+    if auto_form:
+        def probe_form(p, n=50):
+            nonlocal pipelined
+            pipelined = p
+            for _ in range(5):
+                step()
+            if p:
+                pipe.drain()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                step()
+            if p:
+                pipe.drain()
+            torch.cuda.synchronize()
+            t_ = torch.tensor([(time.perf_counter() - t0_) / n * 1e6], dtype=torch.float64,
+                              device=device if (dist.is_initialized() and dist.get_backend() == "nccl") else "cpu")
+            if dist.is_initialized():
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # the slowest rank's figure, identical on every rank:
+            return float(t_.item())                            # every rank takes the same decision
+        form_probe = {"serial_us": probe_form(False), "pipelined_us": probe_form(True)}
+        pipelined = form_probe["pipelined_us"] < form_probe["serial_us"]
+        form_probe["timed"] = "pipelined" if pipelined else "serial"
     if use_graph:
         # eager pre-pass: per-launch kernel time with HIP events.  The launches are queued BEHIND a spin kernel long
         # enough for the host to issue all of them, so the events bracket back-to-back GPU work and the host's issue
@@ -662,7 +693,9 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
               "hipGraph replay of the whole step" + (" (the statistics ride in the kernel's own launch)" if in_launch else "")
               + ((" (probe: %.1f us per replayed step, %.1f eager)" % (launch_probe["replay_us"], launch_probe["eager_us"])) if launch_probe else "")) if use_graph else (
         "eager; exchange + VaR/CVaR of step n on a side stream beside the hot kernel of step n+1 (dist.PipelinedSteps)"
-        if pipelined else "eager, one stream, no overlap between steps")
+        if pipelined else "eager, one stream, no overlap between steps") + (
+        (" (probed over 50 untimed steps, slowest rank: %.1f us serial, %.1f us pipelined)" %
+         (form_probe["serial_us"], form_probe["pipelined_us"])) if form_probe else "")
     kern_src = ("HIP events around each launch of an eager pre-pass queued behind a spin kernel (back-to-back on the "
                 "GPU, host issue rate excluded), mean over K launches" if use_graph
                 else "HIP events around the launch, mean over the timed steps")
@@ -672,7 +705,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         dist.all_gather_object(every, float(kern_ms))
         kern_ranks = {"min": min(every), "max": max(every), "per_rank": every}
     return {"elapsed": elapsed, "kern_ms": kern_ms, "kern_src": kern_src, "stats": final_stats, "launch": launch,
-            "sclk_mhz": sclk, "comm_selfcheck": selfcheck, "kernel_ms_ranks": kern_ranks}
+            "sclk_mhz": sclk, "comm_selfcheck": selfcheck, "kernel_ms_ranks": kern_ranks, "form_probe": form_probe}
 
 
 def kkt_block(model, us_final, iters, first_cvar, where):
@@ -946,9 +979,16 @@ def c5_rank_local_block(work, args, device, stats, rdist, torch, world=8, K=100)
         pipe.step(lambda s: work.hot_kernel(slot=s), local_exchange)
     piped_us = timed(piped, K)
     pipe.drain()
+    pipe = rdist.PipelinedSteps(2, device, high_priority=True)       # A/B: the consumer on a high-priority stream
+    piped_hi_us = timed(piped, K)
+    pipe.drain()
+    serial2_us = timed(lambda: (work.hot_kernel(slot=0), local_exchange(0)), K)     # (again: drift between the legs)
+    serial_us = min(serial_us, serial2_us)
     return {"world": world, "M_total": world * M,
             "kernel_us": kernel_us, "unpack_records_us": unpack_us, "selection_M_total_us": select_us,
-            "step_serial_us": serial_us, "step_pipelined_us": piped_us,
+            "step_serial_us": serial_us, "step_pipelined_us": piped_us, "step_pipelined_high_priority_us": piped_hi_us,
+            "default_form": "serial" if serial_us <= piped_us else "pipelined",
+            "default_rule": "bench.py --gpus N (N > 1) probes both forms over 50 untimed steps and times the faster one",
             "what": "one GPU: shard kernel + rato_unpack_records(world records) + exact selection over M_total samples; "
                     "eager steps, wall-clock per step over %d steps; kernel / unpack / selection alone by HIP events, "
                     "back to back.  The wire time of the all-gather (4 MB in total over xGMI) is NOT in these numbers" % K}
@@ -997,6 +1037,8 @@ def c5_prediction_block(c5, args, device, stats, rdist, dist, torch):
     return {"one_gpu_M_1e6_step_us": one_gpu_us, "one_gpu_M_1e6_kernel_us": 1e3 * res["kern_ms"],
             "step_serial_us": rl["step_serial_us"], "step_pipelined_us": rl["step_pipelined_us"],
             "speedup_serial": one_gpu_us / rl["step_serial_us"], "speedup_pipelined": one_gpu_us / rl["step_pipelined_us"],
+            "speedup_default": one_gpu_us / min(rl["step_serial_us"], rl["step_pipelined_us"]),
+            "default_form": rl.get("default_form"),
             "target": ">= 6x at 8 GPUs (BASELINE.json north_star)", "wire": "unknown, not included: the all-gather of 8 x 0.5 MB "
             "records; pipelined it has a whole kernel time (%.0f us) to hide in" % rl["kernel_us"]}
 
@@ -1058,6 +1100,58 @@ def configs_block(args, device, stats, rdist, dist, torch):
     return out
 
 
+def ordered_line(line):
+    """The ONE JSON line, arranged for readers that keep only `config`, `roofline` and the tail of the line: the whole
+    metric (the throughput AND the SCP wall-clock, the two-stream figure, the 8-GPU prediction) is summarised inside
+    `config`; the long diagnostic blocks (`configs`, `scp` with its per-kernel table, ...) come FIRST and the contract's
+    keys LAST.  The blocks are also left in gpurun_out/bench_blocks.json when that directory can be written."""
+    cfg = line["config"]
+    scp = line.get("scp") or {}
+    if "cumulative_s" in scp:
+        cfg.update({"scp_cumulative_s": scp["cumulative_s"], "scp_iters": scp["iters"], "scp_cuts_total": scp["cuts_total"],
+                    "scp_cuts_max": scp["cuts_max"], "scp_L2_error_last": scp["L2_error_last"],
+                    "scp_define_median_s": scp["define_median_s"], "scp_solve_median_s": scp["solve_median_s"],
+                    "scp_split_s": scp["split_s"], "scp_oracle_round_trips": (scp.get("kernels") or {}).get("oracle_round_trips"),
+                    "scp_kkt": {k: (scp.get("kkt") or {}).get(k) for k in ("primal", "stationarity", "complementarity")},
+                    "scp_what": "drone_risk SCP at this M and S, reference protocol drone_times.py:509-550 (60 iterations "
+                                "from the initial guess), wall-clock seconds; = the line's scp.cumulative_s"})
+    if "cumulative_s" in (line.get("scp_driving") or {}):
+        cfg["scp_driving_cumulative_s"] = line["scp_driving"]["cumulative_s"]
+    if "ms_per_step" in (line.get("two_streams") or {}):
+        cfg["two_streams_ms_per_step"] = line["two_streams"]["ms_per_step"]
+    c5 = (line.get("configs") or {}).get("C5") or {}
+    p8 = c5.get("predicted_8gpu") or {}
+    if "speedup_serial" in p8:
+        cfg.update({"c5_predicted_speedup_serial": p8["speedup_serial"], "c5_predicted_speedup_pipelined": p8["speedup_pipelined"],
+                    "c5_predicted_speedup_default": p8.get("speedup_default"), "c5_default_form": p8.get("default_form")})
+    cfgs = line.get("configs") or {}
+    small = {k: {"ms_per_step": v.get("ms_per_step"), "kernel_ms": v.get("kernel_ms"), "frac": v.get("frac")}
+             for k, v in cfgs.items() if isinstance(v, dict) and "ms_per_step" in v}
+    if small:
+        cfg["configs_ms_per_step"] = small
+    rb = line.get("roofline_beyond_cache") or {}
+    if "frac" in rb:
+        cfg["roofline_beyond_cache_frac"] = rb["frac"]
+    if "cpu_baseline" in line:
+        cfg["gpu_over_cpu"] = line["cpu_baseline"]["gpu_over_cpu"]
+        cfg["cpu_baseline_cores"] = line["cpu_baseline"]["cores"]
+    last = ("stats", "device", "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "cpu_baseline", "roofline", "config")
+    blocks = {k: v for k, v in line.items() if k not in last}
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            with open(os.path.join(d, "bench_blocks.json"), "w") as f:
+                json.dump(blocks, f)
+    except OSError:
+        pass
+    out = dict(blocks)
+    for k in last:
+        if k in line:
+            out[k] = line[k]
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -1094,7 +1188,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if args.overlap is None:
-        args.overlap = world > 1
+        args.overlap = "auto" if world > 1 else False     # N > 1: probe serial against pipelined, time the faster
 
     is_drone_lin = args.workload == "drone" and args.mode == "linearize"
     variants = [None]
@@ -1165,6 +1259,7 @@ def main():
                        "comm_selfcheck": head["comm_selfcheck"],
                        "rccl_ranks": (head["comm_selfcheck"] or {}).get("rccl_ranks", 0),
                        "kernel_ms_ranks": head["kernel_ms_ranks"],
+                       "step_form_probe": head.get("form_probe"),
                        "launch": head["launch"]},
             "roofline": roofline_block(work, head["kern_ms"], args.workload, args.mode, M, S, jacobian,
                                        head["kern_src"]),
@@ -1227,7 +1322,7 @@ def main():
                 avail = len(os.sched_getaffinity(0))
             except AttributeError:
                 avail = os.cpu_count() or 1
-            cores = min(avail, 64) if threaded else 1
+            cores = 1
 
             def timed(fn, budget_s, max_reps):
                 fn()                                       # warm-up
@@ -1240,17 +1335,31 @@ def main():
                 return n * unit_steps * reps / t_cpu, reps, t_cpu
 
             if threaded:
-                v1, r1, t1 = timed(lambda: cpu_step(1), 6.0, 40)
-                vp, rp, tp = timed(lambda: cpu_step(cores), 12.0, 200)
+                # 1 thread, 64, half the cpus and EVERY cpu the process may run on (P = os.cpu_count()); the
+                # workers of the multi-thread legs are placed like OMP_PROC_BIND=spread (oracle/saa_oracle.c:
+                # rato_oracle_place_threads -- by hand: the variable is read when libgomp loads and would also pin this
+                # thread, which feeds the GPU).  `value` = the best of them, `cores` = the threads that gave it.
+                from oracle import c_oracle
+                v1, r1, t1 = timed(lambda: cpu_step(1), 5.0, 40)
+                legs = {}
+                for nt in sorted({min(avail, 64), max(avail // 2, 1), avail} - {1}):
+                    c_oracle.place_threads(nt, True)
+                    legs[nt] = timed(lambda: cpu_step(nt), 5.0, 200)
+                    c_oracle.place_threads(nt, False)
+                if not legs:
+                    legs[1] = (v1, r1, t1)
+                cores = max(legs, key=lambda k: legs[k][0])
+                vp, rp, tp = legs[cores]
                 cpu_val, extra = vp, (f"C oracle (oracle/saa_oracle.c, fp64, every sample's dense linearization formed "
-                                      f"in the reference's shapes and reduced on the fly, OpenMP over samples), M={n}: "
-                                      f"{cores} threads {vp:.3e} ({rp} reps, {tp:.1f} s); "
-                                      f"1 thread {v1:.3e} ({r1} reps, {t1:.1f} s)")
+                                      f"in the reference's shapes and reduced on the fly, OpenMP over samples, workers "
+                                      f"spread over the {avail} cpus of the affinity mask), M={n}: "
+                                      + "; ".join(f"{k} threads {v[0]:.3e} ({v[1]} reps, {v[2]:.1f} s)" for k, v in legs.items())
+                                      + f"; 1 thread {v1:.3e} ({r1} reps, {t1:.1f} s); value = the best leg ({cores} threads)")
                 numpy_1proc = None
                 if getattr(cpu_step, "numpy", None) is not None:      # the NumPy restatement, one process, in chunks
                     cpu_step.numpy(0)
                     done, t_np, k = 0, 0.0, 1
-                    while t_np < 6.0 and done < n:
+                    while t_np < 5.0 and done < n:
                         t1_ = time.perf_counter()
                         done += cpu_step.numpy(k)
                         t_np += time.perf_counter() - t1_
@@ -1263,12 +1372,14 @@ def main():
                 extra = f"NumPy fp64 oracle, M={n}, {reps} rep(s), {t_cpu:.1f} s"
             line["cpu_baseline"] = {
                 "value": cpu_val, "unit": line["unit"], "cores": cores, "kind": "port",
+                "cpus_available": avail,
+                "value_by_threads": ({str(k): v[0] for k, v in legs.items()} if threaded else None),
                 "value_1_thread": (v1 if threaded else cpu_val),
                 "value_numpy_1_process": (numpy_1proc if threaded else cpu_val),
                 "sample": extra + f"; restatement of the reference's path (its JAX/XLA-CPU path is not installable "
                                   f"here); host reports {os.cpu_count()} cpus",
                 "gpu_over_cpu": value / cpu_val}
-        print(json.dumps(line))
+        print(json.dumps(ordered_line(line)))
     rdist.destroy_comms()
     if dist.is_initialized():
         dist.destroy_process_group()

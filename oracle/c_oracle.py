@@ -22,6 +22,8 @@ def load(build=True):
         _lib.rato_oracle_drone_stream.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 8 + [C.c_int]
         _lib.rato_oracle_drone_stream.restype = None
         _lib.rato_oracle_max_threads.restype = C.c_int
+        _lib.rato_oracle_place_threads.argtypes = [C.c_int, C.c_int]
+        _lib.rato_oracle_place_threads.restype = C.c_int
         ip = C.POINTER(C.c_int)
         _lib.rato_oracle_drone_rowmax.argtypes = [C.c_int, C.c_int, C.c_double] + [dp] * 6 + [ip, C.c_int]
         _lib.rato_oracle_drone_rowmax.restype = None
@@ -35,6 +37,12 @@ def load(build=True):
         _lib.rato_oracle_car_tail_rows.argtypes = [C.c_int, C.c_int] + [dp] * 5 + [C.c_int, dp, ip, dp, dp, C.c_int]
         _lib.rato_oracle_car_tail_rows.restype = None
     return _lib
+
+
+def place_threads(nthreads, spread=True):
+    """OMP_PROC_BIND=spread by hand for the next calls with this ``nthreads`` (workers only; the calling thread is not
+    pinned); ``spread=False`` gives the workers the whole affinity mask back.  -> cpus in the process's mask."""
+    return int(load().rato_oracle_place_threads(int(nthreads), 1 if spread else 0))
 
 
 def _p(a):

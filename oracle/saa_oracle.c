@@ -15,7 +15,9 @@
  *   Z           (M)             max g - OSQP_TOL                 :656-662
  * Any output pointer may be NULL.
  */
+#define _GNU_SOURCE
 #include <math.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -38,6 +40,40 @@ int rato_oracle_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+/* The CPU baseline's thread placement (bench.py): OMP_PROC_BIND=spread by hand, because the environment variable is read
+ * when libgomp is loaded (long before bench.py knows the box) and would also pin the caller's own thread, which feeds
+ * the GPU.  spread != 0: worker t (t > 0) of an nthreads-wide team is pinned to the (t * n_allowed / nthreads)-th cpu of
+ * the process's affinity mask; spread == 0: every worker gets the whole mask back.  The calling thread is never touched.
+ * libgomp keeps its workers between parallel regions, so the placement holds for the calls that follow with the same
+ * nthreads.  -> number of cpus in the mask. */
+int rato_oracle_place_threads(int nthreads, int spread) {
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
+  int cpus[CPU_SETSIZE], n = 0;
+  for (int c = 0; c < CPU_SETSIZE; ++c)
+    if (CPU_ISSET(c, &allowed)) cpus[n++] = c;
+  if (n == 0) return -1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    if (t > 0) {
+      cpu_set_t one;
+      if (spread) {
+        CPU_ZERO(&one);
+        CPU_SET(cpus[(int)(((long)t * n) / nt) % n], &one);
+      } else {
+        one = allowed;
+      }
+      sched_setaffinity(0, sizeof(one), &one);
+    }
+  }
+#endif
+  return n;
 }
 
 /* One sample i.  ``slot`` is the index its dense outputs are written at: i itself (rato_oracle_drone: outputs of all M

@@ -204,6 +204,16 @@ int kept_cuts_launch(rato_cut_solver* s, int n_keep, void* stream) {
   return rato_sum_partials_f64(c.part_b, s->nblk, n_keep * s->nc, 1.0, c.sums_b_host, stream);
 }
 
+// A kept-cuts launch is still marked in flight (define / begin followed by another define / begin without the solve that
+// waits for it): let it finish before its pinned words are pre-set again -- a late write of the OLD launch would
+// otherwise satisfy the NEW wait with stale sums.  Clears the mark whatever happens.
+int settle_kept(rato_cut_solver* s, hipStream_t st) {
+  if (!s->kept_armed) return RATO_OK;
+  s->kept_armed = false;
+  const hipError_t e = hipStreamSynchronize(st);
+  return e == hipSuccess ? RATO_OK : RATO_EHIP - (int)e;
+}
+
 bool keep_ok(const rato_cut_solver* s, const int32_t* keep, int n_keep) {
   for (int k = 0; k < n_keep; ++k)
     if (keep[k] < 0 || keep[k] >= s->c.cap - 1) return false;
@@ -221,11 +231,15 @@ extern "C" int rato_cut_begin(rato_cut_solver* s, const double* u_lin, const int
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool with_cuts = n_keep > 0 && s->c.S >= 2;
   if (with_cuts && !keep_ok(s, keep, n_keep)) return RATO_EINVAL;
-  const int rc = stage_inputs(s, u_lin, nullptr, nullptr, keep, with_cuts ? n_keep : 0, st);
+  int rc = settle_kept(s, st);
   if (rc != RATO_OK) return rc;
-  s->kept_armed = with_cuts && rato::readback_poll_enabled();
-  if (s->kept_armed) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);
-  return kept_cuts_launch(s, with_cuts ? n_keep : 0, stream);
+  rc = stage_inputs(s, u_lin, nullptr, nullptr, keep, with_cuts ? n_keep : 0, st);
+  if (rc != RATO_OK) return rc;
+  const bool arm_kept = with_cuts && rato::readback_poll_enabled();
+  if (arm_kept) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);
+  rc = kept_cuts_launch(s, with_cuts ? n_keep : 0, stream);
+  s->kept_armed = arm_kept && rc == RATO_OK;   // armed words with nothing launched behind them are never waited for
+  return rc;
 }
 
 // The "define" half of a reduced SCP iteration of the DRONE as one call (table-free oracle: no linearization table is
@@ -253,10 +267,12 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
   // the sample sums land in pinned memory and are watched for (rato_common.h: readback_*); with the non-finite count
   // (a copy node behind them) the event below is waited for instead
   const bool watch = rato::readback_poll_enabled() && !bad_dev;
+  int rc = settle_kept(s, st);   // a kept-cuts launch nobody waited for must not write into words armed anew
+  if (rc != RATO_OK) return rc;
   if (watch) rato::readback_arm(sums_host, ncols);
-  s->kept_armed = with_cuts && rato::readback_poll_enabled();
-  if (s->kept_armed) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);
-  int rc = stage_inputs(s, us, us_host, us_dev, keep, with_cuts ? n_keep : 0, st);   // us, u_k (fp64) and the kept slots: one launch
+  const bool arm_kept = with_cuts && rato::readback_poll_enabled();
+  if (arm_kept) rato::readback_arm(s->c.sums_b_host, n_keep * s->nc);   // (kept_armed only once the launch is out)
+  rc = stage_inputs(s, us, us_host, us_dev, keep, with_cuts ? n_keep : 0, st);   // us, u_k (fp64) and the kept slots: one launch
   if (rc != RATO_OK) return rc;
   rc = rato_drone_linearize_generators(&s->drone, us_dev, s->c.s0, s->c.s1, s->c.s2, A22, nullptr, nullptr, Z, part,
                                            stream);
@@ -279,6 +295,7 @@ extern "C" int rato_cut_define_drone(rato_cut_solver* s, const double* us, float
     if (e != hipSuccess) return RATO_EHIP - (int)e;
   }
   if ((rc = kept_cuts_launch(s, with_cuts ? n_keep : 0, stream)) != RATO_OK) return rc;
+  s->kept_armed = arm_kept;
   e = watch ? rato::readback_wait(sums_host, ncols, st) : hipEventSynchronize(s->sums_ready);
   if (e != hipSuccess) return RATO_EHIP - (int)e;
   if (bad_host && *bad_host) return RATO_ENONFINITE;
@@ -338,6 +355,8 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
     s->kept_armed = false;
     hipError_t e = armed ? rato::readback_wait(c.sums_b_host, n_kept * nc, st) : hipStreamSynchronize(st);
     if (e != hipSuccess) return RATO_EHIP - (int)e;
+    // (not armed: the words were not watched -- a define that failed before its launch leaves them pre-set; never data)
+    if (!armed && rato::readback_pending(c.sums_b_host, n_kept * nc)) return RATO_EHIP - (int)hipErrorNotReady;
     oracle_s += seconds_since(t0);
     t0 = std::chrono::steady_clock::now();
     // cut k under the current linearization (delta form):  rows_k . (u - u_k) + c0_k - c_s s <= rhs0

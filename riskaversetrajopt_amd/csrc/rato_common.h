@@ -261,6 +261,12 @@ inline void readback_arm(double* host, int n) {
   volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(host);
   for (int i = 0; i < n; ++i) w[i] = READBACK_PENDING;
 }
+inline bool readback_pending(const double* host, int n) {   // any word still the pre-set payload?
+  const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(host);
+  for (int i = 0; i < n; ++i)
+    if (w[i] == READBACK_PENDING) return true;
+  return false;
+}
 inline hipError_t readback_wait(const double* host, int n, hipStream_t st) {   // st: what to synchronise if the words stay away
   if (readback_poll_enabled()) {
     const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(host);
@@ -276,7 +282,12 @@ inline hipError_t readback_wait(const double* host, int n, hipStream_t st) {   /
       if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
     }
   }
-  return hipStreamSynchronize(st);
+  // the words stayed away (or polling is off): ask the runtime for the end of the stream -- and then LOOK: a stream that
+  // reports success while a word is still the pending payload means the writer never ran (an error path armed the
+  // words and launched nothing); that must not be read as data
+  const hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess || !readback_poll_enabled()) return e;
+  return readback_pending(host, n) ? hipErrorNotReady : hipSuccess;
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember, per device, the largest size a

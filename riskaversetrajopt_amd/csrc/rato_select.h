@@ -256,6 +256,9 @@ __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha,
   const int tid = threadIdx.x;
   const int n = (int)M;
 #ifdef RATO_RS_DIAG
+  // diagnostic stamps (100 MHz wall clock) behind the record: out[16 + k], k = 0 start, 1 keys loaded + range known,
+  // 6 rank key found, 7 tail terms accumulated, 8 record written.  Slots 2..5 (the three fixed passes of the round-4
+  // form) are NOT written by the range-normalised form: readers must not expect them.
   if (tid == 0) out[16 + 0] = (double)wall_clock64();
 #endif
   // every load of the thread in flight before anything else (Z comes from HBM: its producer's L2 was written back)
@@ -315,7 +318,7 @@ __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha,
       for (int u = 0; u < KEYS; ++u) {
         const int i = tid + u * NT;
         const unsigned rel = key[u] - lo;
-        if (i < n && (level == 0 || rel < width)) {
+        if (i < n && (level == 0 || (key[u] >= lo && rel < width))) {   // (>= lo: a key below lo wraps, and with a key range near 2^32 -- NaNs of both signs -- could pass)
           const unsigned bin = rel >> sh;
           if (bin != run_bin) {
             if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
@@ -346,7 +349,7 @@ __device__ void rs_small_body(const float* __restrict__ Z, long M, double alpha,
 #pragma unroll
       for (int u = 0; u < KEYS; ++u) {
         const int i = tid + u * NT;
-        if (i < n && key[u] - lo < width) cand[atomicAdd(&h[B1 - 2], 1u)] = key[u];
+        if (i < n && key[u] >= lo && key[u] - lo < width) cand[atomicAdd(&h[B1 - 2], 1u)] = key[u];
       }
       __syncthreads();
       if (tid < (int)c) {        // the candidate with  #{< x} <= krem < #{<= x}  (equal keys all qualify, and agree)

@@ -403,14 +403,17 @@ class CvarCutSolver:
         """the rato_cut_solver for the current samples (rebuilt when they, or the parameters, change)"""
         kind, p, *samples = self.rollout
         nat = self._native
-        # (the same parameter object and sample tensors as last time: the handle stands; a caller that keeps one params
-        #  struct per Model -- solve_reduced does -- never reaches the byte comparison below)
+        # (the same parameter object and sample tensors as last time: the handle stands if the struct's BYTES are also
+        #  what the native solver copied -- it holds the parameters by value, so an in-place edit of the struct (dt, beta,
+        #  S ... of the Model behind it) must rebuild it; ~1 us for the 200 bytes)
+        knobs = (bool(self.recycle), self.keep_recent, self.keep_idle, self.keep_max)
+        pbytes = bytes(p)
         if nat is not None and len(nat) > 3 and nat[3][0] is p and len(nat[3][1]) == len(samples) and \
-                all(a is b for a, b in zip(nat[3][1], samples)) and nat[3][2] == (bool(self.recycle), self.keep_recent, self.keep_idle):
+                all(a is b for a, b in zip(nat[3][1], samples)) and nat[3][2] == knobs and nat[3][3] == pbytes:
             return nat[1]
-        key = (kind, bytes(p), bool(self.recycle), self.keep_recent, self.keep_idle, self.keep_max) + tuple(a.data_ptr() for a in samples)
+        key = (kind, pbytes) + knobs + tuple(a.data_ptr() for a in samples)
         if nat is not None and nat[0] == key:
-            self._native = (nat[0], nat[1], nat[2], (p, samples, (bool(self.recycle), self.keep_recent, self.keep_idle)))
+            self._native = (nat[0], nat[1], nat[2], (p, samples, knobs, pbytes))
             return nat[1]
         self._native_destroy()
         C = _lib.C
@@ -445,7 +448,7 @@ class CvarCutSolver:
         res.bound_var, res.bound_sign = out["bound_var"].ctypes.data, out["bound_sign"].ctypes.data
         res.bound_lambda, res.bound_capacity = out["bound_lambda"].ctypes.data, out["bound_var"].size
         out["res"] = res
-        self._native = (key, h, out, (p, samples, (bool(self.recycle), self.keep_recent, self.keep_idle)))
+        self._native = (key, h, out, (p, samples, knobs, pbytes))
         return h
 
     def _native_destroy(self):

@@ -365,6 +365,20 @@ def broadcast_from_rank0(arr, device, group=None):
 
 
 # ---- the N > 1 step as a two-slot software pipeline ---------------------------------------------------------------------
+def _record_stream(obj, stream, _depth=0):
+    """Mark every CUDA tensor reachable from ``obj`` (dict / list / tuple nesting) as in use on ``stream``."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif _depth < 4:
+        if isinstance(obj, dict):
+            for v in obj.values():
+                _record_stream(v, stream, _depth + 1)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                _record_stream(v, stream, _depth + 1)
+
+
 class PipelinedSteps:
     """[hot kernel of step n + 1]  beside  [exchange + statistics of step n].
 
@@ -377,19 +391,30 @@ class PipelinedSteps:
     the last consumer and waits for both streams: results are complete, and identical to the serial order bit for bit
     (same kernels on the same buffers; tests/test_dist_gloo.py, tests/test_gpu_dist.py).
 
+    Memory: ``produce`` should write into persistent per-slot buffers (bench.py does).  If it returns freshly allocated
+    tensors instead, the consumer reads them on the side stream after this object has dropped its last reference, and the
+    caching allocator would hand the block to the next main-stream allocation while the side stream still reads it: every
+    tensor reachable from what ``produce`` returned (dicts / lists / tuples are walked) is therefore marked as in use on
+    the side stream (``Tensor.record_stream``) before the consumer is issued.
+
     Host tensors / no GPU (the gloo tests of the logic): no streams, the same ISSUE order -- produce(n + 1), then
     consume(n)."""
 
-    def __init__(self, n_slots=2, device=None):
+    ISSUED_KEPT = 256                                     # the issue log is a diagnostic: bounded
+
+    def __init__(self, n_slots=2, device=None, high_priority=False):
+        import collections
         self.n_slots = int(n_slots)
         self.cuda = bool(device is not None and torch.device(device).type == "cuda")
         self.pending = None
         self.results = [None] * self.n_slots
-        self.issued = []                                  # ("produce" | "consume", step): the order work was issued in
+        # ("produce" | "consume", step): the order work was issued in (the last ISSUED_KEPT entries)
+        self.issued = collections.deque(maxlen=self.ISSUED_KEPT)
         self._step = 0
         if self.cuda:
             self.main = torch.cuda.current_stream(device)
-            self.side = torch.cuda.Stream(device)
+            # high_priority: the consumer's few workgroups are dispatched ahead of the producer's queue of tiles (A/B knob)
+            self.side = torch.cuda.Stream(device, priority=-1) if high_priority else torch.cuda.Stream(device)
             self.ev_done = [torch.cuda.Event() for _ in range(self.n_slots)]
             self.ev_free = [torch.cuda.Event() for _ in range(self.n_slots)]
 
@@ -414,6 +439,7 @@ class PipelinedSteps:
         slot, consume, out, n = self.pending
         self.pending = None
         if self.cuda:
+            _record_stream(out, self.side)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_done[slot])
                 self.results[slot] = consume(slot, out)

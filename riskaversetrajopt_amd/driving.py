@@ -186,7 +186,9 @@ class Model:
         Z = reuse("_Z", (M,))
         xs = self._empty(self.S + 1, n_x, M) if want_xs else None
         g = reuse("_g", (self.S, M)) if want_g else None
-        o["_Z"], o["_g"] = Z, g
+        o["_Z"] = Z
+        if g is not None:                                # (a call without g keeps the reusable g buffer of an earlier one)
+            o["_g"] = g
         p = self._params(M)
         if stats_request is not None:        # (workspace, record, alpha[, in_launch])
             stats.request_in_launch(p, *stats_request[:3], flags=(stats.STATS_IN_LAUNCH if (len(stats_request) > 3 and

@@ -203,7 +203,9 @@ class Model:
         Z = reuse("_Z", (ld,))
         xs = self._empty(self.S + 1, n_x, ld) if want_xs else None
         g = reuse("_g", (n_obs, self.S, ld)) if want_g else None
-        o["_Z"], o["_g"] = Z, g
+        o["_Z"] = Z
+        if g is not None:                                # (a call without g keeps the reusable g buffer of an earlier one)
+            o["_g"] = g
         p = self._params(M, ld)
         if stats_request is not None:        # (workspace, record, alpha[, in_launch])
             stats.request_in_launch(p, *stats_request[:3], flags=(stats.STATS_IN_LAUNCH if (len(stats_request) > 3 and

@@ -211,7 +211,7 @@ def _pipeline_worker(rank, world, port, M_local, K, tmpdir):
     assert len(got) == K - 1                              # the last step's consumer is still pending ...
     pipe.drain()
     assert len(got) == K                                  # ... until the pipeline is drained
-    order = pipe.issued
+    order = list(pipe.issued)
     for n in range(K - 1):
         assert order.index(("produce", n + 1)) < order.index(("consume", n))     # the overlap: next producer first
         assert order.index(("consume", n)) < (order.index(("produce", n + 2)) if n + 2 < K else len(order))   # slot reuse

@@ -33,6 +33,13 @@ def test_default_blocks_at_a_small_size():
     assert "error" not in kkt, kkt
     assert max(kkt["primal"], kkt["stationarity"], kkt["complementarity"]) < 1e-7, kkt
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    cb = d["cpu_baseline"]                              # timed at 1 / 64 / half / all threads; the best leg is the value
+    assert cb["cores"] >= 1 and cb["value"] == max(cb["value_by_threads"].values()) and cb["cpus_available"] >= cb["cores"]
+    # the whole metric inside `config` (what the driver's record keeps): the SCP wall-clock next to the throughput
+    cfg = d["config"]
+    assert cfg["scp_cumulative_s"] == d["scp"]["cumulative_s"] and cfg["scp_iters"] == 3
+    assert cfg["scp_cuts_total"] == d["scp"]["cuts_total"] and cfg["gpu_over_cpu"] == cb["gpu_over_cpu"]
+    assert list(d)[-1] == "config" and list(d)[-2] == "roofline"      # the contract's keys close the line
     assert d["device"]["sclk_mhz_beside_hot_kernel"] > 500
 
 
@@ -60,6 +67,10 @@ def test_two_ranks_validate_their_exchange_before_timing():
     assert sc["ok"] and sc["bitwise_vs_torch_all_gather"] and sc["identical_on_every_rank"] and sc["world"] == 2
     assert cfg["rccl_ranks"] == 0 and "gloo" in cfg["transport"]          # two ranks on one device: RCCL refuses that
     assert len(cfg["kernel_ms_ranks"]["per_rank"]) == 2 and cfg["kernel_ms_ranks"]["min"] > 0
+    # N > 1 without --overlap / --no-overlap: both step forms probed (slowest rank's clock), the faster one timed
+    fp = cfg["step_form_probe"]
+    assert fp["serial_us"] > 0 and fp["pipelined_us"] > 0
+    assert fp["timed"] == ("pipelined" if fp["pipelined_us"] < fp["serial_us"] else "serial")
     # --strict-comm: a run whose exchange is not the library's RCCL communicator on every rank must not report a number
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--M", "3000", "--S", "20",
                           "--steps", "3", "--warmup", "1", "--jacobian", "products", "--strict-comm"], capture_output=True,
