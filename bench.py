@@ -979,14 +979,11 @@ def c5_rank_local_block(work, args, device, stats, rdist, torch, world=8, K=100)
         pipe.step(lambda s: work.hot_kernel(slot=s), local_exchange)
     piped_us = timed(piped, K)
     pipe.drain()
-    pipe = rdist.PipelinedSteps(2, device, high_priority=True)       # A/B: the consumer on a high-priority stream
-    piped_hi_us = timed(piped, K)
-    pipe.drain()
     serial2_us = timed(lambda: (work.hot_kernel(slot=0), local_exchange(0)), K)     # (again: drift between the legs)
     serial_us = min(serial_us, serial2_us)
     return {"world": world, "M_total": world * M,
             "kernel_us": kernel_us, "unpack_records_us": unpack_us, "selection_M_total_us": select_us,
-            "step_serial_us": serial_us, "step_pipelined_us": piped_us, "step_pipelined_high_priority_us": piped_hi_us,
+            "step_serial_us": serial_us, "step_pipelined_us": piped_us,
             "default_form": "serial" if serial_us <= piped_us else "pipelined",
             "default_rule": "bench.py --gpus N (N > 1) probes both forms over 50 untimed steps and times the faster one",
             "what": "one GPU: shard kernel + rato_unpack_records(world records) + exact selection over M_total samples; "

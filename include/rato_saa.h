@@ -375,6 +375,30 @@ int rato_hopper_slip_host_inputs(int32_t M, int32_t C, const float* px_host, con
                                  const float* lam, float* Z, float* h, float* dh_dfz, float* dh_dpx,
                                  float* part_hess, void* stream);
 
+/* rato_hopper_slip / rato_hopper_slip_host_inputs (host_inputs != 0) with THREE per-block sums per contact,
+ *   part_hess3 [nblocks][C][3] = lam*d2h/(dpx dfz), lam*d2h/dpx^2, lam*dh/dpx
+ * -- everything ``hessian(lambda . g)`` of the reference (hopper.py:575-580) needs from the samples: with the chain factors
+ * J_c, H_c of the end-effector map p = x0 + x3 sin x2 (:166-171) the block of contact c on (x0, x2, x3) is
+ * D2_c J_c J_c' + D0_c H_c and its mixed entries with fz are D1_c J_c (Model.slip_hessian). */
+int rato_hopper_slip_hessian(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,
+                             int32_t host_inputs, const float* a, const float* theta, const float* tau,
+                             const float* lam, float* Z, float* h, float* dh_dfz, float* dh_dpx, float* part_hess3,
+                             void* stream);
+
+/* ``jacrev(slip_risk_constraints)`` (hopper.py:569 on the rows of :300-367) in the reference's own layout: the CSC VALUE
+ * array, written on the device from dh_dfz / dh_dpx [C][M] of the calls above.  Rows ('saa', saa != 0; :351-366):
+ * 0 = (M alpha) t + sum y; 1 + i = -y_i; 1 + M + i C + c = h_ic - t - y_i - slack; one trailing zero row; ('baseline',
+ * :339-348: i C + c = h_ic - slack).  Columns in Z order (:105-132).  Values, columns ascending and rows ascending
+ * inside a column:  [c][x0, x2, x3][i] dh_dpx * chain[c][k];  [c][fx, fz][i] 1, dh_dfz;  saa: [i][1, -1, C x -1];
+ * slack: M C x -1;  saa: t_risk: M alpha, M C x -1.  rato_hopper_jacobian_nnz values in all (8 C M + 2 M + 1 / 6 C M).
+ *   chain_host [C][3] host floats (C <= RATO_HOPPER_MAX_HOST_CONTACTS: kernel arguments) and / or chain_dev (device);
+ *   write_constants = 0 skips the constant part (a buffer written once keeps it).
+ * Exact zeros (sin x2 = 0) are written as zeros; the reference's csc_matrix(dense) drops them (Model.slip_jacobian does). */
+int64_t rato_hopper_jacobian_nnz(int32_t M, int32_t C, int32_t saa);
+int rato_hopper_emit_jacobian_values(int32_t M, int32_t C, int32_t saa, double alpha, const float* dh_dfz,
+                                     const float* dh_dpx, const float* chain_host, const float* chain_dev,
+                                     int32_t write_constants, float* out, void* stream);
+
 /* --------------------------------------------------------------- assembly */
 
 /*

@@ -150,7 +150,82 @@ class Model:
         D2 = -forces[:, 1] * np.sum(lam * d2mu, axis=0)
         return D1, D2
 
+    # -- the reference's own matrices: jacrev(g) / hessian(lambda.g) restricted to the slip rows ---------------------
+    def slip_jacobian(self, Z):
+        """``jacrev(slip_risk_constraints)(Z)`` (hopper.py:569 on the rows of :300-367) as a scipy CSC matrix with the
+        reference's rows (1 + M + i C + c, 'saa'; i C + c, 'baseline') and columns (Z order: xs [t][8], us [t][4], y, slack,
+        t_risk); exact zeros dropped, as ``csc_matrix(dense)`` drops them."""
+        import scipy.sparse as sp
+        Z = np.asarray(Z, dtype=np.float64)
+        M, S = self.M, self.S
+        px, forces = self.contact_inputs(Z)
+        C = px.shape[0]
+        _, dfz, dpx = self.slip_partials(px, forces)
+        Jee, _ = self.contact_chain(Z)
+        steps = self.contact_steps()
+        nX, nU = (S + 1) * n_x, S * n_u
+        saa = self.method != 'baseline'
+        r0 = 1 + M if saa else 0
+        rows = (r0 + np.arange(M)[:, None] * C + np.arange(C)[None, :])              # (M,C)
+        I, Jc, V = [], [], []
+
+        def put(r, c, v):
+            r, c, v = np.broadcast_arrays(r, c, v)
+            I.append(r.reshape(-1)), Jc.append(c.reshape(-1)), V.append(np.asarray(v, dtype=np.float64).reshape(-1))
+        for k, xk in enumerate((0, 2, 3)):                                            # d/d(x0, x2, x3) of step t_c
+            put(rows, (steps * n_x + xk)[None, :], dpx * Jee[None, :, k])
+        put(rows, (nX + steps * n_u + 2)[None, :], 1.0)                               # d/dfx
+        put(rows, (nX + steps * n_u + 3)[None, :], dfz)                               # d/dfz = -mu
+        put(rows, self.num_vars - 2, -1.0)                                            # slack (:347, :366)
+        if saa:
+            put(rows, (nX + nU + np.arange(M))[:, None], -1.0)                        # -y_i (:366)
+            put(rows, self.num_vars - 1, -1.0)                                        # -t_risk
+            put(0, nX + nU + np.arange(M), 1.0)                                       # row 0 (:354)
+            put(0, self.num_vars - 1, M * self.alpha)
+            put(1 + np.arange(M), nX + nU + np.arange(M), -1.0)                       # -y_i <= 0 (:357)
+        n_rows = (1 + M + M * C + 1) if saa else M * C
+        A = sp.coo_matrix((np.concatenate(V), (np.concatenate(I), np.concatenate(Jc))),
+                          shape=(n_rows, self.num_vars)).tocsc()
+        A.eliminate_zeros()
+        A.sort_indices()
+        return A
+
+    def slip_hessian(self, Z, lam):
+        """``hessian(lambda . slip_risk_constraints)(Z)`` (hopper.py:575-580; lam (M,C) on the per-sample rows: every other
+        row is linear) as a scipy CSC (num_vars x num_vars): per contact the 3 x 3 block on (x0, x2, x3) of its step and
+        the mixed entries with fz."""
+        import scipy.sparse as sp
+        Z = np.asarray(Z, dtype=np.float64)
+        px, forces = self.contact_inputs(Z)
+        _, _, dpx = self.slip_partials(px, forces)
+        D1, D2 = self.slip_hessian_sums(px, forces, lam)
+        D0 = np.sum(lam * dpx, axis=0)
+        return hessian_from_sums(self, Z, D0, D1, D2)
+
     # -- Monte-Carlo validation: hopper.py:901-925 ---------------------------
     def no_slip_constraints_verification(self, px, forces):
         Z = self.no_slip_values(px, forces).max(axis=1)
         return Z <= 1e-6, Z
+
+
+def hessian_from_sums(model, Z, D0, D1, D2):
+    """The Lagrangian-Hessian blocks from the three per-contact sample sums D0_c = sum_i lam_ic dh_ic/dpx,
+    D1_c = sum_i lam_ic d2h/(dpx dfz), D2_c = sum_i lam_ic d2h/dpx2 and the chain factors of p = x0 + x3 sin x2."""
+    import scipy.sparse as sp
+    S = model.S
+    Jee, Hee = model.contact_chain(Z)
+    steps = model.contact_steps()
+    nX = (S + 1) * n_x
+    H = sp.lil_matrix((model.num_vars, model.num_vars))
+    for c, t in enumerate(steps):
+        xi = [t * n_x + 0, t * n_x + 2, t * n_x + 3]
+        blk = D2[c] * np.outer(Jee[c], Jee[c]) + D0[c] * Hee[c]
+        fz = nX + t * n_u + 3
+        for a in range(3):
+            for b in range(3):
+                H[xi[a], xi[b]] = blk[a, b]
+            H[xi[a], fz] = H[fz, xi[a]] = D1[c] * Jee[c, a]
+    H = H.tocsc()
+    H.eliminate_zeros()
+    H.sort_indices()
+    return H

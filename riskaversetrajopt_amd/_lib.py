@@ -110,6 +110,10 @@ SIGNATURES = {
     "rato_hopper_nblocks": (C.c_int, [C.c_int32]),
     "rato_hopper_slip": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
     "rato_hopper_slip_host_inputs": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 12 + [c_stream]),
+    "rato_hopper_slip_hessian": (C.c_int, [C.c_int32, C.c_int32] + [c_float_p] * 3 + [C.c_int32] + [c_float_p] * 9 + [c_stream]),
+    "rato_hopper_jacobian_nnz": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "rato_hopper_emit_jacobian_values": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double] + [c_float_p] * 4 +
+                                         [C.c_int32, c_float_p, c_stream]),
     "rato_emit_csc_values": (C.c_int, [c_float_p, c_float_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_float, c_float_p, c_stream]),
     "rato_saa_rowmax": (C.c_int, [c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,

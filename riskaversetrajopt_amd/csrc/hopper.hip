@@ -50,7 +50,9 @@ struct HopperContacts {
 // Everything a sample needs meets inside ONE workgroup: no atomics on Z, nothing to initialise before the launch
 // (round 2 until here: contact groups on blockIdx.y folded with atomic max into a Z pre-filled with -inf -- one more
 // node in every step).
-template <bool DERIV, bool BYVAL>
+// HC = 2: part_hess holds (D1, D2) per contact; HC = 3 (rato_hopper_slip_hessian): also D0 = sum lam dh/dpx, the factor
+// of the end-effector map's own curvature in the reference's Lagrangian Hessian (hopper.py:577-580).
+template <bool DERIV, bool BYVAL, int HC = 2>
 __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     int M_, int C, int nw_log2, const float* __restrict__ px, const float* __restrict__ fx,
     const float* __restrict__ fz, const HopperContacts hc, const float* __restrict__ a,
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     rtau[k] = ta * INV_2PI;
   }
   float zmax = -INFINITY;
-  extern __shared__ float lds[];        // [WAVES][64] per-wave maxima | [SW][C][2] per-wave Hessian sums
+  extern __shared__ float lds[];        // [WAVES][64] per-wave maxima | [SW][C][HC] per-wave Hessian sums
   float* zred = lds;
   float* hess_lds = lds + WAVES * RATO_WAVE;
   const bool want_hess = DERIV && part_hess;
@@ -134,9 +136,12 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
     if (want_hess) {  // wave-uniform; contact c belongs to exactly one contact-wave of each sample-wave
       const float d1 = rato::wave_sum_dpp(l * (s1.x + s1.y));        // lam * d2h/(dpx dfz) = -lam mu'
       const float d2 = rato::wave_sum_dpp(l * (s2.x + s2.y) * f_z);  // lam * d2h/dpx^2   = -lam mu'' fz
+      float d0 = 0.0f;
+      if (HC == 3) d0 = rato::wave_sum_dpp(l * (s1.x + s1.y) * f_z);   // lam * dh/dpx         = -lam mu' fz
       if (lane == 0) {
-        hess_lds[(sw * C + c) * 2 + 0] = d1;
-        hess_lds[(sw * C + c) * 2 + 1] = d2;
+        hess_lds[(sw * C + c) * HC + 0] = d1;
+        hess_lds[(sw * C + c) * HC + 1] = d2;
+        if (HC == 3) hess_lds[(sw * C + c) * HC + 2] = d0;
       }
     }
   }
@@ -144,10 +149,10 @@ __global__ __launch_bounds__(RATO_BLOCK, DERIV ? 3 : 4) void hopper_slip_kernel(
   if (fold_z) zred[wave * RATO_WAVE + lane] = zmax;
   if (want_hess || fold_z) __syncthreads();
   if (want_hess) {
-    for (int i = threadIdx.x; i < C * 2; i += RATO_BLOCK) {
+    for (int i = threadIdx.x; i < C * HC; i += RATO_BLOCK) {
       float acc = 0.0f;
-      for (int w = 0; w < SW; ++w) acc += hess_lds[w * C * 2 + i];   // fixed order
-      part_hess[(size_t)blockIdx.x * C * 2 + i] = acc;
+      for (int w = 0; w < SW; ++w) acc += hess_lds[w * C * HC + i];   // fixed order
+      part_hess[(size_t)blockIdx.x * C * HC + i] = acc;
     }
   }
   if (Z && valid && cw == 0) {
@@ -178,17 +183,18 @@ extern "C" int rato_hopper_nblocks(int32_t M) { return M > 0 ? hopper_blocks(M) 
 namespace {
 int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, const float* fz, bool host_inputs,
                      const float* a, const float* theta, const float* tau, const float* lam, float* Z, float* h,
-                     float* dh_dfz, float* dh_dpx, float* part_hess, void* stream) {
+                     float* dh_dfz, float* dh_dpx, float* part_hess, void* stream, int hc = 2) {
   RATO_CLEAR_ERROR();
   if (M <= 0 || C <= 0 || !px || !fx || !fz || !a || !theta || !tau) return RATO_EINVAL;
   if (part_hess && !lam) return RATO_EINVAL;
+  if (hc == 3 && !part_hess) return RATO_EINVAL;
   if (host_inputs && C > RATO_HOPPER_MAX_HOST_CONTACTS) return RATO_EINVAL;
   hipStream_t st = rato::as_stream(stream);
   const int nw_log2 = hopper_nw_log2(M);
   dim3 grid(hopper_blocks(M)), block(RATO_BLOCK);
   const bool deriv = dh_dfz || dh_dpx || part_hess;
   const int SW = (RATO_BLOCK / RATO_WAVE) >> nw_log2;
-  const size_t lds = (size_t)(RATO_BLOCK + (part_hess ? SW * C * 2 : 0)) * sizeof(float);
+  const size_t lds = (size_t)(RATO_BLOCK + (part_hess ? SW * C * hc : 0)) * sizeof(float);
   // the Hessian sums keep 2 C floats per sample-wave in LDS: C <= 4064 (two sample-waves) / 2032 (four) contacts; the
   // reference's hopper has 2 S / 3 contacts (hopper.py:306-311).  Beyond the 64 KB default the kernels are raised (per
   // device) up to the 160 KB of a CU; past that the call is refused instead of failing inside the launch.
@@ -201,21 +207,34 @@ int hopper_slip_impl(int32_t M, int32_t C, const float* px, const float* fx, con
       if (err == hipSuccess)
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(hopper_slip_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RATO_HOPPER_LDS_MAX);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(hopper_slip_kernel<true, true, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)RATO_HOPPER_LDS_MAX);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(hopper_slip_kernel<true, false, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)RATO_HOPPER_LDS_MAX);
       return err;
     });
     if (e != hipSuccess) return RATO_EHIP - (int)e;
   }
-  HopperContacts hc;
+  HopperContacts hc_args;
   if (host_inputs) {
-    ::memcpy(hc.px, px, sizeof(float) * C);
-    ::memcpy(hc.fx, fx, sizeof(float) * C);
-    ::memcpy(hc.fz, fz, sizeof(float) * C);
+    ::memcpy(hc_args.px, px, sizeof(float) * C);
+    ::memcpy(hc_args.fx, fx, sizeof(float) * C);
+    ::memcpy(hc_args.fz, fz, sizeof(float) * C);
     px = fx = fz = nullptr;
   }
 #define RATO_HOPPER_LAUNCH(D, B)                                                                                  \
-  hipLaunchKernelGGL((hopper_slip_kernel<D, B>), grid, block, lds, st, M, C, nw_log2, px, fx, fz, hc, a, theta, tau, \
+  hipLaunchKernelGGL((hopper_slip_kernel<D, B>), grid, block, lds, st, M, C, nw_log2, px, fx, fz, hc_args, a, theta, tau, \
                      lam, Z, h, dh_dfz, dh_dpx, part_hess)
-  if (deriv) {
+  if (hc == 3) {
+    if (host_inputs)
+      hipLaunchKernelGGL((hopper_slip_kernel<true, true, 3>), grid, block, lds, st, M, C, nw_log2, px, fx, fz, hc_args, a,
+                         theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess);
+    else
+      hipLaunchKernelGGL((hopper_slip_kernel<true, false, 3>), grid, block, lds, st, M, C, nw_log2, px, fx, fz, hc_args, a,
+                         theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess);
+  } else if (deriv) {
     if (host_inputs) RATO_HOPPER_LAUNCH(true, true); else RATO_HOPPER_LAUNCH(true, false);
   } else {
     if (host_inputs) RATO_HOPPER_LAUNCH(false, true); else RATO_HOPPER_LAUNCH(false, false);
@@ -239,4 +258,103 @@ extern "C" int rato_hopper_slip_host_inputs(int32_t M, int32_t C, const float* p
                                             float* dh_dpx, float* part_hess, void* stream) {
   return hopper_slip_impl(M, C, px_host, fx_host, fz_host, true, a, theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess,
                           stream);
+}
+
+// The same call with part_hess [nblocks][C][3] = per-block sums of (lam d2h/(dpx dfz), lam d2h/dpx^2, lam dh/dpx): everything
+// hessian(lambda . g) of the reference (hopper.py:575-580) needs from the samples.  host_inputs != 0: px / fx / fz are host
+// arrays of C <= RATO_HOPPER_MAX_HOST_CONTACTS values (kernel arguments); 0: device arrays.
+extern "C" int rato_hopper_slip_hessian(int32_t M, int32_t C, const float* px, const float* fx, const float* fz,
+                                        int32_t host_inputs, const float* a, const float* theta, const float* tau,
+                                        const float* lam, float* Z, float* h, float* dh_dfz, float* dh_dpx,
+                                        float* part_hess3, void* stream) {
+  return hopper_slip_impl(M, C, px, fx, fz, host_inputs != 0, a, theta, tau, lam, Z, h, dh_dfz, dh_dpx, part_hess3, stream, 3);
+}
+
+// ---- jacrev(slip_risk_constraints) in the reference's layout: the CSC value array --------------------------------------
+// Rows (hopper.py:351-366, 'saa'): 0 = (M alpha) t + sum y;  1 + i = -y_i;  1 + M + i C + c = h_ic - t - y_i - slack;  last: 0.
+// ('baseline', :339-348: rows i C + c = h_ic - slack.)  Columns in Z order (:105-132): xs [t][8], us [t][4], y_i, slack, t.
+// With the entries of a column sorted by row, the value array is, in this order:
+//   [c][k = x0, x2, x3][i]   dh_ic/dpx * chain[c][k]            3 C M   (chain = d(x0 + x3 sin x2)/d(x0, x2, x3) at step t_c)
+//   [c][fx, fz][i]           1, dh_ic/dfz = -mu_i(p_c)            2 C M
+//   saa: [i][1, -1, C x -1]  the y_i columns                      M (2 + C)
+//   slack: [i][c] -1                                              M C
+//   saa: t_risk: M alpha, then [i][c] -1                          1 + M C
+// Blocks [0, data_blocks) write the data-dependent part (lane = sample: coalesced reads of dh_dpx / dh_dfz [C][M] and
+// coalesced writes); the blocks behind them fill the constant part linearly (skipped with write_constants = 0: the
+// constants of a buffer written once do not change).  Exact zeros (sin x2 = 0) are written as zeros: the facade drops them.
+namespace {
+struct HopperChain {
+  float j[RATO_HOPPER_MAX_HOST_CONTACTS][3];
+};
+
+template <bool BYVAL>
+__global__ __launch_bounds__(RATO_BLOCK) void hopper_emit_jacobian_kernel(int M_, int C, int saa, float M_alpha,
+                                                                           const float* __restrict__ dh_dfz,
+                                                                           const float* __restrict__ dh_dpx,
+                                                                           const HopperChain chain,
+                                                                           const float* __restrict__ chain_dev,
+                                                                           int data_blocks, float* __restrict__ out) {
+  const size_t M = (size_t)M_;
+  const int chunks = (M_ + RATO_BLOCK - 1) / RATO_BLOCK;
+  if ((int)blockIdx.x < data_blocks) {
+    const int c = blockIdx.x / chunks;
+    const size_t i = (size_t)(blockIdx.x - c * chunks) * RATO_BLOCK + threadIdx.x;
+    if (i >= M) return;
+    const float dpx = dh_dpx[(size_t)c * M + i], dfz = dh_dfz[(size_t)c * M + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float j = BYVAL ? chain.j[c][k] : chain_dev[c * 3 + k];
+      out[((size_t)c * 3 + k) * M + i] = dpx * j;
+    }
+    float* u = out + (size_t)3 * C * M + (size_t)c * 2 * M;
+    u[i] = 1.0f;
+    u[M + i] = dfz;
+    return;
+  }
+  // constant part: [y columns | slack column | t column], one value per thread and step
+  const size_t n_y = saa ? M * (size_t)(2 + C) : 0, n_s = M * (size_t)C, n_t = saa ? 1 + M * (size_t)C : 0;
+  const size_t total = n_y + n_s + n_t;
+  float* o = out + (size_t)5 * C * M;
+  const size_t stride = (size_t)(gridDim.x - data_blocks) * RATO_BLOCK;
+  for (size_t q = (size_t)(blockIdx.x - data_blocks) * RATO_BLOCK + threadIdx.x; q < total; q += stride) {
+    float v = -1.0f;
+    if (q < n_y) {
+      if (q % (size_t)(2 + C) == 0) v = 1.0f;
+    } else if (q == n_y + n_s) {
+      v = M_alpha;
+    }
+    o[q] = v;
+  }
+}
+}  // namespace
+
+extern "C" int64_t rato_hopper_jacobian_nnz(int32_t M, int32_t C, int32_t saa) {
+  if (M <= 0 || C <= 0) return RATO_EINVAL;
+  return saa ? (int64_t)8 * C * M + (int64_t)2 * M + 1 : (int64_t)6 * C * M;
+}
+
+extern "C" int rato_hopper_emit_jacobian_values(int32_t M, int32_t C, int32_t saa, double alpha, const float* dh_dfz,
+                                                const float* dh_dpx, const float* chain_host, const float* chain_dev,
+                                                int32_t write_constants, float* out, void* stream) {
+  RATO_CLEAR_ERROR();
+  if (M <= 0 || C <= 0 || !dh_dfz || !dh_dpx || !out || (!chain_host && !chain_dev)) return RATO_EINVAL;
+  const bool byval = chain_host && C <= RATO_HOPPER_MAX_HOST_CONTACTS;
+  if (!byval && !chain_dev) return RATO_EINVAL;
+  HopperChain ch;
+  if (byval) ::memcpy(ch.j, chain_host, sizeof(float) * 3 * (size_t)C);
+  const int chunks = (M + RATO_BLOCK - 1) / RATO_BLOCK;
+  const long data_blocks = (long)C * chunks;
+  const int const_blocks = write_constants ? 512 : 0;
+  if (data_blocks + const_blocks > 0x7fffffffL) return RATO_EINVAL;
+  dim3 grid((unsigned)(data_blocks + const_blocks)), block(RATO_BLOCK);
+  hipStream_t st = rato::as_stream(stream);
+  const float Ma = (float)((double)M * alpha);
+  if (byval)
+    hipLaunchKernelGGL((hopper_emit_jacobian_kernel<true>), grid, block, 0, st, M, C, saa ? 1 : 0, Ma, dh_dfz, dh_dpx, ch,
+                       chain_dev, (int)data_blocks, out);
+  else
+    hipLaunchKernelGGL((hopper_emit_jacobian_kernel<false>), grid, block, 0, st, M, C, saa ? 1 : 0, Ma, dh_dfz, dh_dpx, ch,
+                       chain_dev, (int)data_blocks, out);
+  RATO_LAUNCH_CHECK();
+  return RATO_OK;
 }

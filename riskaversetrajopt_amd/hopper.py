@@ -215,6 +215,126 @@ class Model:
                                 want_deriv=True)["hess"].cpu().numpy()
         return hess[:, 0], hess[:, 1]
 
+    # ---- the reference's own matrices (hopper.py:569, :575-580) ---------------
+    def contact_steps(self):
+        return np.concatenate([np.arange(0, self.time_jump), np.arange(self.time_land, self.S)])
+
+    def _jacobian_pattern(self, Cn):
+        """(indices, indptr) of ``jacrev(slip_risk_constraints)`` with EVERY structural entry present, in the value order
+        of rato_hopper_emit_jacobian_values (include/rato_saa.h); built once per (M, C, method)."""
+        key = (self._a.shape[1], Cn, self.method)
+        pat = getattr(self, "_jac_pattern", None)
+        if pat is not None and pat[0] == key:
+            return pat[1], pat[2]
+        M, S = key[0], self.S
+        saa = self.method != 'baseline'
+        nX, nU = (S + 1) * n_x, S * n_u
+        steps = self.contact_steps()
+        r0 = 1 + M if saa else 0
+        rows_c = r0 + np.arange(M, dtype=np.int64)[None, :] * Cn + np.arange(Cn, dtype=np.int64)[:, None]     # (C, M)
+        counts = np.zeros(self.num_vars, dtype=np.int64)
+        for k in (0, 2, 3):
+            counts[steps * n_x + k] = M
+        counts[nX + steps * n_u + 2] = M
+        counts[nX + steps * n_u + 3] = M
+        parts = [np.repeat(rows_c[:, None, :], 3, axis=1).reshape(-1), np.repeat(rows_c[:, None, :], 2, axis=1).reshape(-1)]
+        rows_i = r0 + np.arange(M, dtype=np.int64)[:, None] * Cn + np.arange(Cn, dtype=np.int64)[None, :]     # (M, C)
+        if saa:
+            ycols = np.concatenate([np.zeros((M, 1), dtype=np.int64), 1 + np.arange(M, dtype=np.int64)[:, None], rows_i], axis=1)
+            parts.append(ycols.reshape(-1))
+            counts[nX + nU:nX + nU + M] = 2 + Cn
+        parts.append(rows_i.reshape(-1))
+        counts[self.num_vars - 2] = M * Cn
+        if saa:
+            parts.append(np.concatenate([[0], rows_i.reshape(-1)]))
+            counts[self.num_vars - 1] = 1 + M * Cn
+        indices = np.concatenate(parts).astype(np.int32)
+        indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        assert indices.size == int(self._lib.rato_hopper_jacobian_nnz(M, Cn, int(saa))) == indptr[-1]
+        self._jac_pattern = (key, indices, indptr)
+        return indices, indptr
+
+    def slip_jacobian_device(self, Z, out=None):
+        """-> (values [nnz] fp32 device tensor, indices, indptr, shape): ``jacrev(slip_risk_constraints)(Z)`` of the
+        reference (hopper.py:569 on the rows of :300-367), rows and columns in its order, as CSC with every structural entry
+        present; the values are written on the device (rato_hopper_emit_jacobian_values) from the slip kernel's partials and
+        the end-effector chain factors.  ``out``: the value tensor of an earlier call (its constant part is kept)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        px, forces = self.contact_inputs(Z)
+        Cn, M = px.shape[0], self._a.shape[1]
+        r = self.slip_device(px, forces, want_Z=False, want_h=False, want_deriv=True)
+        Jee, _ = self.contact_chain(Z)
+        chain = np.ascontiguousarray(Jee, dtype=np.float32)
+        saa = self.method != 'baseline'
+        nnz = int(self._lib.rato_hopper_jacobian_nnz(M, Cn, int(saa)))
+        fresh = out is None or out.numel() != nnz
+        vals = torch.empty(nnz, dtype=torch.float32, device=self.device) if fresh else out
+        chain_dev = None
+        if Cn > MAX_HOST_CONTACTS:
+            chain_dev = torch.as_tensor(chain, device=self.device)
+        _lib.check(self._lib.rato_hopper_emit_jacobian_values(
+            M, Cn, int(saa), float(self.alpha), _lib.ptr(r["dh_dfz"]), _lib.ptr(r["dh_dpx"]),
+            C.c_void_p(chain.ctypes.data), _lib.ptr(chain_dev), int(fresh), _lib.ptr(vals), _lib.current_stream()),
+            "rato_hopper_emit_jacobian_values")
+        indices, indptr = self._jacobian_pattern(Cn)
+        n_rows = (1 + M + M * Cn + 1) if saa else M * Cn
+        return vals, indices, indptr, (n_rows, self.num_vars)
+
+    def slip_jacobian(self, Z):
+        """The same matrix as a scipy CSC (fp64 values, exact zeros dropped as the reference's ``csc_matrix(dense)`` drops
+        them: the sparsity pattern is the reference's)."""
+        import scipy.sparse as sp
+        vals, indices, indptr, shape = self.slip_jacobian_device(Z)
+        A = sp.csc_matrix((vals.double().cpu().numpy(), indices, indptr), shape=shape)
+        A.eliminate_zeros()
+        A.sort_indices()
+        return A
+
+    slip_jacobian_rows = slip_jacobian
+
+    def slip_hessian(self, Z, lam):
+        """``hessian(lambda . slip_risk_constraints)(Z)`` (hopper.py:575-580; ``lam`` (M, C): the multipliers of the
+        per-sample rows -- every other row is linear) as a scipy CSC (num_vars x num_vars).  The three sample sums per contact
+        come from ONE launch (rato_hopper_slip_hessian); the 15 entries per contact are placed on the host."""
+        import scipy.sparse as sp
+        Z = np.asarray(Z, dtype=np.float64)
+        px, forces = self.contact_inputs(Z)
+        D = self.slip_hessian_sums3(px, forces, lam)
+        Jee, Hee = self.contact_chain(Z)
+        steps = self.contact_steps()
+        nX = (self.S + 1) * n_x
+        xi = steps[:, None] * n_x + np.array([0, 2, 3])[None, :]                                   # (C, 3)
+        blk = D[:, 1, None, None] * Jee[:, :, None] * Jee[:, None, :] + D[:, 2, None, None] * Hee    # (C, 3, 3)
+        mixed = D[:, 0, None] * Jee                                                                  # (C, 3)
+        fz = (nX + steps * n_u + 3)[:, None]
+        I = np.concatenate([np.repeat(xi, 3, axis=1).reshape(-1), xi.reshape(-1), np.repeat(fz, 3, axis=1).reshape(-1)])
+        J = np.concatenate([np.tile(xi, (1, 3)).reshape(-1), np.repeat(fz, 3, axis=1).reshape(-1), xi.reshape(-1)])
+        V = np.concatenate([blk.reshape(-1), mixed.reshape(-1), mixed.reshape(-1)])
+        H = sp.coo_matrix((V, (I, J)), shape=(self.num_vars, self.num_vars)).tocsc()
+        H.eliminate_zeros()
+        H.sort_indices()
+        return H
+
+    def slip_hessian_sums3(self, px, forces, lam):
+        """(C, 3): per contact the lambda-weighted sums over the samples of d2h/(dpx dfz), d2h/dpx^2 and dh/dpx."""
+        px = np.ascontiguousarray(px, dtype=np.float32)
+        forces = np.asarray(forces, dtype=np.float32)
+        Cn, M = px.shape[0], self._a.shape[1]
+        lamd = torch.as_tensor(np.ascontiguousarray(np.asarray(lam, dtype=np.float64).T), device=self.device).float().contiguous()
+        if tuple(lamd.shape) != (Cn, M):
+            raise ValueError(f"lam must be (M, C) = ({M},{Cn})")
+        part = torch.empty((self._lib.rato_hopper_nblocks(M), Cn, 3), dtype=torch.float32, device=self.device)
+        fx, fz = np.ascontiguousarray(forces[:, 0]), np.ascontiguousarray(forces[:, 1])
+        if Cn <= MAX_HOST_CONTACTS:
+            args, host = (C.c_void_p(px.ctypes.data), C.c_void_p(fx.ctypes.data), C.c_void_p(fz.ctypes.data)), 1
+        else:
+            dev = [torch.as_tensor(v, device=self.device) for v in (px, fx, fz)]
+            args, host = tuple(_lib.ptr(v) for v in dev), 0
+        _lib.check(self._lib.rato_hopper_slip_hessian(
+            M, Cn, *args, host, _lib.ptr(self._a), _lib.ptr(self._th), _lib.ptr(self._tau), _lib.ptr(lamd), None, None,
+            None, None, _lib.ptr(part), _lib.current_stream()), "rato_hopper_slip_hessian")
+        return stats.sum_partials(part).cpu().numpy().reshape(Cn, 3)
+
     # ---- Monte-Carlo validation (hopper.py:901-958) ------------------------
     def no_slip_constraints_verification(self, px, forces):
         Zh = self.slip_device(px, forces, want_h=False)["Z"].double().cpu().numpy()

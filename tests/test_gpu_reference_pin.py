@@ -5,6 +5,7 @@ fp64 reference -> fp32 device tolerances of tests/_tol.py."""
 import os
 
 import numpy as np
+import torch
 import pytest
 import scipy.sparse as sp
 
@@ -148,27 +149,43 @@ def test_hopper_vs_reference_execution(name):
     np.testing.assert_allclose(-dfz, f["mu"], rtol=0, atol=2e-6)                 # dh/dfz = -mu_i(px_c)
     ok, Zs = d.no_slip_constraints_verification(px, forces)
     np.testing.assert_allclose(Zs, f["Zs"], rtol=0, atol=2e-5)
-    # the reference's jac_g rows for the slip constraints, rebuilt from the device partials (hopper.py:569)
+    # the reference's jac_g for the slip rows (hopper.py:569) -- the WHOLE recorded matrix, every sample and contact: the
+    # facade assembles it in the reference's row / column order with the values written on the device
+    # (rato_hopper_emit_jacobian_values); same sparsity pattern entry for entry, values to the fp32 tolerance
     C = len(px)
-    Jee, Hee = d.contact_chain(Z)
+    Jref = sp.csc_matrix((f["J_data"], f["J_indices"], f["J_indptr"]), shape=tuple(f["J_shape"]))
+    Jref.sort_indices()
+    J = d.slip_jacobian(Z)
+    assert J.shape == Jref.shape and J.nnz == Jref.nnz
+    np.testing.assert_array_equal(J.indptr, Jref.indptr)
+    np.testing.assert_array_equal(J.indices, Jref.indices)
+    np.testing.assert_allclose(J.data, Jref.data, rtol=1e-4, atol=3e-5)
+    exact = np.isin(Jref.data, (1.0, -1.0, M * alpha))                       # the structural constants: exact
+    np.testing.assert_array_equal(J.data[exact], Jref.data[exact])
+    # structural form on the device: every entry present, nnz as the ABI states it; a second call reuses the value buffer
+    vals, indices, indptr, shape = d.slip_jacobian_device(Z)
+    assert vals.numel() == 8 * C * M + 2 * M + 1 == indptr[-1] and shape == tuple(Jref.shape)
+    vals2, *_ = d.slip_jacobian_device(Z, out=vals.clone())
+    assert torch.equal(vals, vals2)
+    # 'baseline' rows (:339-348): rows i C + c, zeroed fields (mu = mu_nom, no px dependence)
+    Jb = db.slip_jacobian(Z)
+    assert Jb.shape == (M * C, d.num_vars) and Jb.nnz == 3 * M * C     # fx, fz = -mu_nom, slack; dh/dpx = 0 dropped
     tj, tl = int(f["time_jump"]), int(f["time_land"])
     steps = np.concatenate([np.arange(0, tj), np.arange(tl, S)])
-    nX, nU = (S + 1) * 8, S * 4
-    Jref = sp.csc_matrix((f["J_data"], f["J_indices"], f["J_indptr"]), shape=tuple(f["J_shape"])).toarray()
-    for i in (0, M // 2, M - 1):
-        for c, t in enumerate(steps):
-            r = 1 + M + i * C + c
-            np.testing.assert_allclose(dfz[i, c], Jref[r, nX + t * 4 + 3], rtol=0, atol=2e-6)
-            np.testing.assert_allclose(dpx[i, c] * Jee[c], Jref[r, [t * 8 + 0, t * 8 + 2, t * 8 + 3]],
-                                       rtol=1e-4, atol=3e-5)
-    # lambda-weighted Hessian blocks (hopper.py:575-579)
-    Href = sp.csc_matrix((f["H_data"], f["H_indices"], f["H_indptr"]), shape=tuple(f["H_shape"])).toarray()
+    nX = (S + 1) * 8
+    np.testing.assert_allclose(Jb[np.arange(M * C), np.tile(nX + steps * 4 + 3, M)].A1, -0.10, rtol=0, atol=1e-7)
+    # lambda-weighted Hessian (hopper.py:575-580): the whole recorded matrix, pattern and values
+    Href = sp.csc_matrix((f["H_data"], f["H_indices"], f["H_indptr"]), shape=tuple(f["H_shape"]))
+    Href.sort_indices()
     lam = f["lam"]
+    H = d.slip_hessian(Z, lam)
+    assert H.shape == Href.shape
+    np.testing.assert_array_equal(H.indptr, Href.indptr)
+    np.testing.assert_array_equal(H.indices, Href.indices)
+    scale = np.abs(Href.data).max()
+    np.testing.assert_allclose(H.data, Href.data, rtol=1e-4, atol=2e-5 * scale)
+    # the two-sum entry point agrees with the three-sum one
     D1, D2 = d.slip_hessian_sums(px, forces, lam)
-    lam_dpx = np.sum(lam * dpx, axis=0)
-    scale = np.abs(Href).max()
-    for c, t in enumerate(steps):
-        xi = [t * 8 + 0, t * 8 + 2, t * 8 + 3]
-        blk = D2[c] * np.outer(Jee[c], Jee[c]) + lam_dpx[c] * Hee[c]
-        np.testing.assert_allclose(blk, Href[np.ix_(xi, xi)], rtol=1e-4, atol=2e-5 * scale)
-        np.testing.assert_allclose(D1[c] * Jee[c], Href[xi, nX + t * 4 + 3], rtol=1e-4, atol=2e-5 * scale)
+    D3 = d.slip_hessian_sums3(px, forces, lam)
+    np.testing.assert_allclose(D3[:, 0], D1, rtol=1e-6, atol=1e-7 * np.abs(D1).max())
+    np.testing.assert_allclose(D3[:, 1], D2, rtol=1e-6, atol=1e-7 * np.abs(D2).max())

@@ -219,6 +219,22 @@ def test_hopper_oracle_matches_reference_execution(name):
     Href = csc(f, "H").toarray()
     np.testing.assert_allclose(H, Href, rtol=1e-9, atol=1e-11 * np.abs(Href).max())
 
+    # the same two matrices from the oracle's own assemblers (what the device facade's Model.slip_jacobian /
+    # Model.slip_hessian are checked against): the reference's sparsity PATTERN, entry for entry, and its values
+    for A, ref, rtol in ((o.slip_jacobian(Z), csc(f, "J"), 1e-10), (o.slip_hessian(Z, lam), csc(f, "H"), 1e-9)):
+        ref = ref.tocsc()
+        ref.sort_indices()
+        assert A.shape == ref.shape
+        np.testing.assert_array_equal(A.indptr, ref.indptr)
+        np.testing.assert_array_equal(A.indices, ref.indices)
+        np.testing.assert_allclose(A.data, ref.data, rtol=rtol, atol=1e-11 * np.abs(ref.data).max())
+    # 'baseline' rows (hopper.py:339-348): rows i C + c, no y / t columns; against the saa matrix' own rows (zeroed fields)
+    Jb = ob.slip_jacobian(Z)
+    assert Jb.shape == (M * C, o.num_vars) and Jb[:, nX + nU:nX + nU + M].nnz == 0 and Jb[:, -1].nnz == 0
+    np.testing.assert_array_equal(Jb[:, -2].toarray().ravel(), -np.ones(M * C))
+    hb, dfzb, dpxb = ob.slip_partials(px, forces)
+    np.testing.assert_allclose(Jb[np.arange(M * C), np.tile(nX + steps * oh.n_u + 3, M)].A1, dfzb.ravel(), rtol=1e-14)
+
 
 # --------------------------------------------------- drone, Gaussian-linearization recursion (BASELINE config C1)
 def test_gaussian_recursion_matches_reference_execution():
