@@ -653,6 +653,25 @@ int rato_cut_solve(rato_cut_solver* s, const double* final_du, const double* fin
                    int32_t* keep, int32_t* keep_idle_count, int32_t* n_keep_io, int32_t kept_in_flight,
                    rato_cut_result* out, void* stream);
 
+/* The reduced SCP of the drone as ONE call (drone_risk.py:519-532 with the timing protocol of drone_times.py:509-550):
+ * `iters` iterations of [rato_cut_define_drone at the current controls -> equality rows from the sample sums ->
+ * rato_cut_solve], starting from us0 [S][3]; iteration k < first_cvar runs without the CVaR rows (:413-417).  Every
+ * iteration is timed from its first instruction to the moment its solution is on the host; the stream is synchronised
+ * once, inside the last iteration's clock.  us_hist [iters][S][3] and rec [iters] (host) receive every iteration's
+ * solution and record; the define's buffers are those of rato_cut_define_drone (no Z, no non-finite scan: check_finite
+ * tests the sample sums and the oracle's m values); keep / keep_idle_count / n_keep_io as for rato_cut_solve.  Returns the
+ * first non-OK status (RATO_ERANK / RATO_ESELECT: repeat with the per-iteration calls), *done = iterations completed. */
+typedef struct rato_scp_iter {
+  double define_s, solve_s, oracle_s, master_s; /* solve = oracle round trips + master; define = the rest of the iteration */
+  double t_risk, slack, phi;
+  int32_t cuts, status, recycled, reserved;
+} rato_scp_iter;
+size_t rato_scp_iter_bytes(void);
+int rato_scp_run_drone(rato_cut_solver* s, const double* us0, int32_t iters, int32_t first_cvar, double tol,
+                       int32_t max_cuts, double final_cut_above, int32_t check_finite, float* us_host, float* us_dev,
+                       float* A22, float* part, double* sums_host, int32_t* keep, int32_t* keep_idle_count,
+                       int32_t* n_keep_io, double* us_hist, rato_scp_iter* rec, int32_t* done, void* stream);
+
 /* ------------------------------------------------------------ device sampler */
 
 /*

@@ -57,6 +57,12 @@ class CutResult(C.Structure):
                 ("bound_lambda", C.c_void_p), ("bound_capacity", C.c_int32), ("n_bounds", C.c_int32)]
 
 
+class ScpIter(C.Structure):
+    """rato_scp_iter (include/rato_saa.h)"""
+    _fields_ = [(k, C.c_double) for k in ("define_s", "solve_s", "oracle_s", "master_s", "t_risk", "slack", "phi")] + \
+               [(k, C.c_int32) for k in ("cuts", "status", "recycled", "reserved")]
+
+
 # name -> (restype, argtypes); mirrors include/rato_saa.h one to one
 SIGNATURES = {
     "rato_abi_version": (C.c_int, []),
@@ -89,6 +95,9 @@ SIGNATURES = {
     "rato_cut_config_bytes": (C.c_size_t, []),
     "rato_cut_result_bytes": (C.c_size_t, []),
     "rato_cut_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
+    "rato_scp_iter_bytes": (C.c_size_t, []),
+    "rato_scp_run_drone": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_int32] +
+                           [C.c_void_p] * 11 + [c_stream]),
     "rato_cut_define_drone": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 5 + [C.c_int32, c_stream]),
     "rato_cut_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
                                  C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,

@@ -565,3 +565,83 @@ extern "C" int rato_cut_solve(rato_cut_solver* s, const double* final_du, const 
   }
   return RATO_OK;
 }
+
+
+// The reduced SCP of the drone as ONE call: `iters` iterations of [rato_cut_define_drone at the current controls -> the
+// equality rows from the sample sums -> rato_cut_solve], the reference's fixed-count protocol (drone_risk.py:519-532,
+// drone_times.py:509-550) with its per-iteration wall clocks taken here.  Each iteration is timed from its first
+// instruction to the moment its solution is on the host (the last oracle round trip has been read back: the device has
+// nothing of this iteration left to do); the stream is synchronised ONCE, after the last iteration, inside that
+// iteration's clock.  scp.run_drone_reduced's Python loop (one define + one solve call per iteration, a device
+// synchronisation on both sides of each) stays as the checker: same iterates bit for bit (tests/test_gpu_scp.py).
+//   us0 [S][3]: the initial guess;  first_cvar: the first iteration with the CVaR rows (2: drone_risk.py:413-417);
+//   us_hist [iters][S][3] (host): the solution of every iteration;  rec [iters];
+//   the define's buffers as for rato_cut_define_drone;  keep / keep_idle_count / n_keep_io: in and out as for rato_cut_solve.
+// Returns the first non-OK status of a define / solve (RATO_ERANK, RATO_ESELECT: repeat with the per-iteration calls,
+// whose Python loop recovers), *done = iterations completed.
+extern "C" int rato_scp_run_drone(rato_cut_solver* s, const double* us0, int32_t iters, int32_t first_cvar, double tol,
+                                  int32_t max_cuts, double final_cut_above, int32_t check_finite, float* us_host,
+                                  float* us_dev, float* A22, float* part, double* sums_host, int32_t* keep,
+                                  int32_t* keep_idle_count, int32_t* n_keep_io, double* us_hist, rato_scp_iter* rec,
+                                  int32_t* done, void* stream) {
+  if (!s || s->c.system != 0 || !us0 || iters < 0 || !us_host || !us_dev || !A22 || !part || !sums_host || !keep ||
+      !keep_idle_count || !n_keep_io || !us_hist || !rec || !done)
+    return RATO_EINVAL;
+  const int S = s->c.S, nU = s->nU, n_c = 6;
+  const double M = (double)s->c.M, inv_M = 1.0 / M;
+  std::vector<double> us(us0, us0 + nU), final_du((size_t)n_c * nU), final_rhs(n_c), sol(nU);
+  std::vector<int32_t> cut_slot(s->c.cap + 8);
+  std::vector<double> cut_lambda(s->c.cap + 8);
+  *done = 0;
+  for (int it = 0; it < iters; ++it) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool cvar = it >= first_cvar;
+    const int K = (cvar && s->c.recycle && S >= 2) ? *n_keep_io : 0;
+    int rc = rato_cut_define_drone(s, us.data(), us_host, us_dev, A22, nullptr, 0, part, sums_host, nullptr, nullptr, keep, K,
+                                   stream);
+    if (rc != RATO_OK) return rc;
+    if (check_finite)
+      for (int i = 0; i < 6 * S + 6; ++i)
+        if (!std::isfinite(sums_host[i])) return RATO_ENONFINITE;
+    // the equality rows: mean of the final-state Jacobian (axis a: row a = position, row 3 + a = velocity; the axes decouple)
+    // and of its right-hand side (drone_risk.py:271-273, :294-300)
+    std::fill(final_du.begin(), final_du.end(), 0.0);
+    for (int t = 0; t < S; ++t)
+      for (int a = 0; a < 3; ++a) {
+        final_du[(size_t)a * nU + t * 3 + a] = sums_host[t * 6 + a] * inv_M;
+        final_du[(size_t)(3 + a) * nU + t * 3 + a] = sums_host[t * 6 + 3 + a] * inv_M;
+      }
+    for (int r = 0; r < n_c; ++r) final_rhs[r] = sums_host[6 * S + r] / M;
+    rato_cut_result res = {};
+    res.us = sol.data();
+    res.cut_slot = cut_slot.data();
+    res.cut_lambda = cut_lambda.data();
+    res.cut_capacity = (int)cut_slot.size();
+    rc = rato_cut_solve(s, final_du.data(), final_rhs.data(), n_c, us.data(), cvar ? 1 : 0, tol, max_cuts, final_cut_above,
+                        check_finite, keep, keep_idle_count, n_keep_io, K > 0 ? 1 : 0, &res, stream);
+    if (rc != RATO_OK) return rc;
+    if (it == iters - 1) {   // the protocol's closing synchronisation, once: inside the last iteration's clock
+      const hipError_t e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return RATO_EHIP - (int)e;
+    }
+    const double total = seconds_since(t0);
+    rato_scp_iter& r = rec[it];
+    r.oracle_s = res.oracle_s;
+    r.master_s = res.master_s;
+    r.solve_s = res.oracle_s + res.master_s;
+    r.define_s = total - r.solve_s;
+    r.t_risk = res.t_risk;
+    r.slack = res.slack;
+    r.phi = res.phi;
+    r.cuts = res.cuts;
+    r.status = res.status;
+    r.recycled = res.recycled;
+    r.reserved = 0;
+    memcpy(us_hist + (size_t)it * nU, sol.data(), sizeof(double) * nU);
+    us = sol;
+    *done = it + 1;
+  }
+  return RATO_OK;
+}
+
+extern "C" size_t rato_scp_iter_bytes(void) { return sizeof(rato_scp_iter); }

@@ -900,7 +900,7 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 
 __host__ __device__ inline size_t rows_lds_floats(int S) {
   // A2 (2) + PP (2) + AZ (1) per (t, lane) | US float2[S] + uz[S] | queue head + rollout progress (+pad)
-  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 4;
+  return (size_t)S * ROWS_SAMPLES * 5 + (size_t)S * 3 + 4 + (RATO_DIAG == 4 ? 4 : 0);
 }
 
 // 1-D grid: workgroups [0, n_whole) own one whole tile each; after them every remaining tile is dealt out to `split`
@@ -965,6 +965,8 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   if (unit != bid && !tile_queue) __syncthreads();   // the previous tile's tables are dead (dynamic: synced below)
 #if RATO_DIAG == 4
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
+  // LDS word behind the queue state: the clock at which the first row WITH stores (task 1 of this part) was picked
+  unsigned long long* tl_first = reinterpret_cast<unsigned long long*>(head + 4);
 #endif
   const size_t m_raw = (size_t)tile * ROWS_SAMPLES + lane;
   const bool valid = m_raw < M;
@@ -1200,6 +1202,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     {
       const int t = task;
       wait_steps(t + 1);
+#if RATO_DIAG == 4
+      if (t >= 1 && t <= row_split && lane == 0) *tl_first = wall_clock64();   // (the first task with a store of this part)
+#endif
       const float2_t pp = PP[t * ROWS_SAMPLES + lane];
       float gj[NOBS], wx[NOBS], wy[NOBS];  // g, and -(Q+Q^T) d pre-multiplied by dt/m
 #pragma unroll
@@ -1274,9 +1279,21 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
   }
 #if RATO_DIAG == 4
   __syncthreads();   // all of the block's row tasks issued (stores may still be in flight)
+  const unsigned long long tl_issued = wall_clock64();
+  if (flags & 4) {   // RATO_DIAG_WAIT=1: also the clock at which every store of the unit has been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
+    // (row-split parts of one tile share the tile's record: the part that ends last wins -- the timeline tool runs with
+    //  whole tiles, RATO_DYN_TAIL_SPLIT=1, when it wants every unit)
     unsigned long long* tl = reinterpret_cast<unsigned long long*>(part + (size_t)tile * (6 * S + 6));
-    tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = tl_issued;
+    tl[4] = *tl_first;
+    tl[6] = wall_clock64();
+    tl[5] = (unsigned long long)bid | ((unsigned long long)(xcc & 0xf) << 32) | ((unsigned long long)part_id << 40);
   }
 #endif
   // ---- next tile
@@ -1681,7 +1698,7 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
 #define RATO_ROWS_LAUNCH(F, PH)                                                                                     \
   hipLaunchKernelGGL((drone_linearize_rows_kernel<F, PH>), dim3(grid_launch), dim3(ROWS_NW * RATO_WAVE), lds_launch, st, \
                      *p, n_whole, split, stride, n_tiles, queue, seed, noise_scale, us, dW, mass, Qsym, G, W, A22, g_up, \
-                     Z, part, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0))
+                     Z, part, tail, (noise_tiled ? 1 : 0) | (nt_stores ? 2 : 0) | ((RATO_DIAG == 4 && getenv("RATO_DIAG_WAIT")) ? 4 : 0))
     if (W) {
       if (dW) RATO_ROWS_LAUNCH(true, false); else RATO_ROWS_LAUNCH(true, true);
     } else {

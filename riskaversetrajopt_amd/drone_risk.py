@@ -834,16 +834,8 @@ class Model:
         """``solve_reduced`` for the benchmarked configuration (table-free oracle, one GPU) as TWO library calls:
         rato_cut_define_drone (controls up, generators-only linearization, sample sums into pinned memory, non-finite
         count, u_k and the kept cuts for the oracle, one synchronisation) and rato_cut_solve (the cutting-plane loop)."""
-        S, M, ld = self.S, cs.M, self._mass.numel()
-        b = getattr(self, "_native_define", None)
-        if b is None or b["key"] != (S, M, ld):
-            e = lambda *sh, dt=torch.float32: torch.empty(sh, dtype=dt, device=self.device)
-            b = {"key": (S, M, ld), "us_host": torch.zeros((S, n_u), dtype=torch.float32).pin_memory(), "us_dev": e(S, n_u),
-                 "A22": e(S, 3, ld), "Z": e(ld), "part": e((M + 255) // 256, 6 * S + 6),
-                 "sums_host": torch.zeros(6 * S + 6, dtype=torch.float64).pin_memory(),
-                 "bad_dev": e(1, dt=torch.int32), "bad_host": torch.zeros(1, dtype=torch.int32).pin_memory()}
-            b["sums_np"] = b["sums_host"].numpy()
-            self._native_define = b
+        S, M = self.S, cs.M
+        b = self._native_define_buffers(cs)
         us64 = np.ascontiguousarray(us_mat_p, dtype=np.float64)
         if us64.shape != (S, n_u):
             raise ValueError(f"us_mat must be ({S},{n_u}), got {us64.shape}")
@@ -868,6 +860,67 @@ class Model:
         info = cs._solve(None, None, 64, None, final_du, final_rhs, u_lin=us64, with_cvar=(scp_iter >= 2), tol=tol)
         info["final_du"], info["final_rhs"] = final_du, final_rhs
         return info["us"], info["t_risk"], info
+
+    def _native_define_buffers(self, cs):
+        S, M = self.S, cs.M
+        b = self._native_define_buffers(cs)
+        return b
+
+    def scp_run_native(self, us0, iters, first_cvar=2, tol=1e-9, max_cuts=400, final_cut_above=1e-11):
+        """The whole reduced SCP as ONE library call (rato_scp_run_drone: ``iters`` x [define, solve] with the per-iteration
+        clocks of the reference's protocol taken natively) -- for the configuration ``solve_reduced`` runs natively (table-free
+        oracle, one GPU).  -> dict(us_hist (iters, S, n_u), define_s, solve_s, oracle_s, cuts, t_risk, status) or None when the
+        configuration is not the native one / the native loop handed back (rank-deficient master, a selection that gave
+        up): the caller then runs the per-iteration loop."""
+        dW, mass, Qsym, _ = self._inputs(None)
+        if dW is None or getattr(self, "_world", 1) != 1 or self.S < 2:
+            return None
+        cs = self._reduced_cut_solver(int(self._inputs(None)[3]), mass.numel())
+        cs.implicit = None
+        rp = getattr(self, "_rollout_params", None)
+        if rp is None or rp[0] != (cs.M, mass.numel()):
+            rp = self._rollout_params = ((cs.M, mass.numel()), self._params(cs.M, mass.numel()))
+        cs.rollout = ("drone", rp[1], dW, mass, Qsym)
+        if not cs.native_loop_applies():
+            return None
+        S = self.S
+        b = self._native_define_buffers(cs)
+        us0 = np.ascontiguousarray(us0, dtype=np.float64)
+        if us0.shape != (S, n_u):
+            raise ValueError(f"us0 must be ({S},{n_u}), got {us0.shape}")
+        h = cs._native_solver()
+        out = cs._keep_arrays()
+        assert C.sizeof(_lib.ScpIter) == self._lib.rato_scp_iter_bytes()
+        rec = (_lib.ScpIter * max(iters, 1))()
+        us_hist = np.zeros((max(iters, 1), S, n_u))
+        done = C.c_int32(0)
+        cs.check_finite = bool(self.check_finite)
+        rc = self._lib.rato_scp_run_drone(
+            h, us0.ctypes.data, int(iters), int(first_cvar), float(tol), int(max_cuts), float(final_cut_above),
+            int(bool(self.check_finite)), b["us_host"].data_ptr(), b["us_dev"].data_ptr(), b["A22"].data_ptr(),
+            b["part"].data_ptr(), b["sums_host"].data_ptr(), out["keep"].ctypes.data, out["idle"].ctypes.data,
+            C.addressof(out["n_keep"]), us_hist.ctypes.data, C.addressof(rec), C.addressof(done), _lib.current_stream())
+        # the solver's Python-side state follows the native one (a later solve_reduced continues from here)
+        K = out["n_keep"].value
+        cs.keep = [int(v) for v in out["keep"][:K]]
+        cs.idle = {int(sl): int(c) for sl, c in zip(out["keep"][:K], out["idle"][:K])}
+        cs._relin_pending = None
+        n = done.value
+        if n:
+            cs.u_lin = (us_hist[n - 2] if n >= 2 else us0).reshape(-1).copy()      # the last linearization point
+        if rc in (_lib.RATO_ERANK, _lib.RATO_ESELECT):
+            _lib.synchronize()
+            return None
+        if rc == _lib.RATO_EINFEASIBLE:
+            raise cvar_cuts.dense_qp.InfeasibleError("master QP infeasible")
+        if rc == _lib.RATO_ENONFINITE:
+            raise _lib.RatoNonFiniteError("reduced SCP (native loop): non-finite sample sums / constraint values (RATO_ENONFINITE)")
+        _lib.check(rc, "rato_scp_run_drone")
+        recs = rec[:iters]
+        f = lambda k: np.array([getattr(r, k) for r in recs])
+        return {"us_hist": us_hist[:iters], "define_s": f("define_s"), "solve_s": f("solve_s"), "oracle_s": f("oracle_s"),
+                "master_s": f("master_s"), "cuts": f("cuts").astype(np.int64), "t_risk": f("t_risk"), "slack": f("slack"),
+                "status": f("status").astype(np.int64)}
 
     def certify_reduced(self, info):
         """Matrix-free KKT certificate of the last ``solve_reduced`` (its ``info``; an iteration with the CVaR rows,

@@ -285,7 +285,10 @@ class Model:
         them: the sparsity pattern is the reference's)."""
         import scipy.sparse as sp
         vals, indices, indptr, shape = self.slip_jacobian_device(Z)
-        A = sp.csc_matrix((vals.double().cpu().numpy(), indices, indptr), shape=shape)
+        data = vals.double().cpu().numpy()
+        if self.method != 'baseline':
+            data[indptr[-2]] = self._a.shape[1] * self.alpha       # row 0 of the t_risk column: M alpha in fp64 (a constant)
+        A = sp.csc_matrix((data, indices, indptr), shape=shape)
         A.eliminate_zeros()
         A.sort_indices()
         return A

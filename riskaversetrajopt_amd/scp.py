@@ -63,16 +63,34 @@ def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False, check_
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
 
 
-def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=True):
+def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=True, native_loop=None):
     """The SCP loop (drone_risk.py:519-532; also used for driving, driving.py:486-513) with every subproblem solved through
     ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
-    "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop."""
+    "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop.
+    ``native_loop`` (default: whenever the Model offers it -- the drone, one GPU, table-free oracle): the whole loop as ONE
+    library call with the per-iteration clocks taken natively (``Model.scp_run_native`` -> rato_scp_run_drone); False: the
+    per-iteration Python loop below, which is also the checker of the native one (same iterates bit for bit) and what the
+    native call hands back to when it meets a case only the Python loop recovers."""
     _finite_guard(model, check_finite)
     if hasattr(model, "_lib"):                 # a device Model: its master QP must be the native one (no silent NumPy leg)
         from . import dense_qp
         dense_qp.require_native()
     us_prev = model.initial_guess_us_mat()
-    define_s, solve_s, err, cuts, oracle_s = [], [], [], [], []
+    if native_loop is not False and not verbose and hasattr(model, "scp_run_native"):
+        _sync()
+        r = model.scp_run_native(us_prev, num_scp_iters_max)
+        if r is not None:
+            hist = r["us_hist"]
+            prev = [np.asarray(us_prev, dtype=np.float64)] + list(hist[:-1])
+            err = np.array([L2_error_us(u, p) for u, p in zip(hist, prev)])
+            return {"us": hist[-1], "t_risk": float(r["t_risk"][-1]), "define_s": r["define_s"], "solve_s": r["solve_s"],
+                    "cumulative_s": np.cumsum(r["define_s"] + r["solve_s"]), "L2_error": err, "cuts": r["cuts"],
+                    "oracle_s": r["oracle_s"], "us_hist": hist, "loop": "native (rato_scp_run_drone)"}
+        if native_loop is True:
+            raise RuntimeError("run_drone_reduced(native_loop=True): the native SCP loop does not apply to this Model / "
+                               "handed back")
+        model._cut_solver = None                # (a handed-back run starts over with the per-iteration loop)
+    define_s, solve_s, err, cuts, oracle_s, hist = [], [], [], [], [], []
     t_risk = None
     for scp_iter in range(num_scp_iters_max):
         _sync()
@@ -85,6 +103,7 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
         oracle_s.append(info["oracle_s"])
         cuts.append(info["cuts"])
         err.append(L2_error_us(us, us_prev))
+        hist.append(np.array(us, dtype=np.float64))
         us_prev = us
         if verbose:
             print(f"scp {scp_iter:3d}  define {define_s[-1]:.4f}s  solve {solve_s[-1]:.4f}s "
@@ -92,7 +111,8 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
     define_s, solve_s = np.array(define_s), np.array(solve_s)
     return {"us": us_prev, "t_risk": t_risk, "define_s": define_s, "solve_s": solve_s,
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err), "cuts": np.array(cuts),
-            "oracle_s": np.array(oracle_s)}
+            "oracle_s": np.array(oracle_s), "us_hist": np.array(hist),
+            "loop": "python (one define + one solve call per iteration)"}
 
 
 def run_driving(model, num_scp_iters_max=15, verbose=False, check_finite=True):

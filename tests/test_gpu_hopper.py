@@ -147,6 +147,25 @@ def test_full_size_C4_properties():
     tol.report("C4 D1 / D2 max |ref|", float(max(np.abs(D1_o).max(), np.abs(D2_o).max())), 0.0)
     np.testing.assert_allclose(D1, D1_o, rtol=2e-5, atol=D1_ATOL_C4)
     np.testing.assert_allclose(D2, D2_o, rtol=2e-5, atol=D2_ATOL_C4)
+    # the reference's matrices at full size (Model.slip_jacobian / slip_hessian; 16 M structural entries written on the
+    # device in CSC order): pattern identical to the oracle's assembler, values to the tolerances of the partials above
+    J, J_o = d.slip_jacobian(Z), o.slip_jacobian(Z)
+    assert J.shape == J_o.shape == (1 + M + M * 40 + 1, o.num_vars)
+    np.testing.assert_array_equal(J.indptr, J_o.indptr)
+    np.testing.assert_array_equal(J.indices, J_o.indices)
+    np.testing.assert_allclose(J.data, J_o.data, rtol=1e-4, atol=3e-5)
+    vals, indices, indptr, _ = d.slip_jacobian_device(Z)
+    C = 40
+    x = vals[:3 * C * M].view(C, 3, M)                     # [c][x0, x2, x3][i] = dh_dpx * chain: an fp32 product, exact
+    Jee = torch.as_tensor(d.contact_chain(Z)[0], dtype=torch.float32, device=vals.device)
+    assert torch.equal(x, r["dh_dpx"][:, None, :] * Jee[:, :, None])
+    u = vals[3 * C * M:5 * C * M].view(C, 2, M)
+    assert bool((u[:, 0] == 1.0).all()) and torch.equal(u[:, 1], r["dh_dfz"])
+    assert bool((vals[5 * C * M:].abs() == 1.0).sum() == vals.numel() - 5 * C * M - 1)          # constants: +-1 and M alpha
+    H, H_o = d.slip_hessian(Z, lam), o.slip_hessian(Z, lam)
+    np.testing.assert_array_equal(H.indptr, H_o.indptr)
+    np.testing.assert_array_equal(H.indices, H_o.indices)
+    np.testing.assert_allclose(H.data, H_o.data, rtol=1e-4, atol=2e-5 * np.abs(H_o.data).max())
 
 
 @pytest.mark.parametrize("M", [300, 50000])

@@ -976,3 +976,27 @@ def test_reduced_subproblems_with_controls_pinned_at_their_bounds(system, bound)
         us = uh
     print(system, "controls pinned at the bound:", pinned)
     assert pinned >= 3
+
+
+@pytest.mark.parametrize("M,S,alpha,method,iters", [(3001, 30, 0.1, "saa", 14), (13000, 50, 0.05, "saa", 9),
+                                                    (64, 20, 0.2, "baseline", 8)])
+def test_native_scp_loop_equals_the_per_iteration_loop_bitwise(M, S, alpha, method, iters):
+    """rato_scp_run_drone (the whole reduced SCP as ONE library call, what bench.py's SCP block times) against
+    scp.run_drone_reduced's Python loop (one rato_cut_define_drone + one rato_cut_solve per iteration, a device
+    synchronisation on both sides of each): the same iterates bit for bit, iteration by iteration, the same cut counts and
+    t_risk, the same kept cuts at the end -- and a solve_reduced that follows continues identically on both."""
+    from riskaversetrajopt_amd import scp
+    a, b = _drone(M, S, alpha=alpha, method=method, seed=4)[1], _drone(M, S, alpha=alpha, method=method, seed=4)[1]
+    ra = scp.run_drone_reduced(a, num_scp_iters_max=iters)
+    rb = scp.run_drone_reduced(b, num_scp_iters_max=iters, native_loop=False)
+    assert ra["loop"].startswith("native") and rb["loop"].startswith("python")
+    assert ra["us_hist"].shape == rb["us_hist"].shape == (iters, S, 3)
+    for k in range(iters):
+        assert np.array_equal(ra["us_hist"][k], rb["us_hist"][k]), (k, np.abs(ra["us_hist"][k] - rb["us_hist"][k]).max())
+    assert np.array_equal(ra["cuts"], rb["cuts"]) and np.array_equal(ra["L2_error"], rb["L2_error"])
+    assert ra["t_risk"] == rb["t_risk"] and np.array_equal(ra["us"], rb["us"])
+    assert a._cut_solver.keep == b._cut_solver.keep and a._cut_solver.idle == b._cut_solver.idle
+    assert (ra["define_s"] > 0).all() and (ra["solve_s"] > 0).all() and np.all(np.diff(ra["cumulative_s"]) > 0)
+    ua, ta, ia = a.solve_reduced(ra["us"], iters)
+    ub, tb, ib = b.solve_reduced(rb["us"], iters)
+    assert np.array_equal(ua, ub) and ta == tb and ia["cuts"] == ib["cuts"]
