@@ -169,6 +169,35 @@ __device__ __forceinline__ void ped_step(const rato_car_params& P, const PedCons
   px = pxn; py = pyn; vx = vxn; vy = vyn;
 }
 
+// The pedestrian step and the distance row with every rounding spelled out (see step_axis_exact in drone.hip): what
+// car_eval_kernel AND car_eval_tiles_kernel call, so that their Z / g / trajectories agree to the bit by construction.
+// (-ffp-contract=fast lets the BACK END fuse any multiply into a following add whatever the pragma says: a product that
+//  must stay a product goes through an empty asm statement, which hides where it came from)
+__device__ __forceinline__ float unfused(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ void ped_step_exact(const rato_car_params& P, const PedConsts& c, float ex, float ey, float xi0,
+                                               float xi1, float& px, float& py, float& vx, float& vy) {
+#pragma clang fp contract(off)
+  const float dx = ex - px, dy = ey - py;
+  const float r2 = unfused(dx * dx) + unfused(dy * dy);
+  const float rinv = __builtin_amdgcn_rsqf(r2);
+  const float common = c.w_s * (P.speed_ped_des - vy);
+  const float F0 = __builtin_fmaf(-c.w_r, dx * rinv, common), F1 = __builtin_fmaf(-c.w_r, dy * rinv, common);
+  const float pxn = __builtin_fmaf(P.dt, vx, px), pyn = __builtin_fmaf(P.dt, vy, py);
+  vx = __builtin_fmaf(c.cn, xi0, __builtin_fmaf(P.dt, F0, vx));
+  vy = __builtin_fmaf(c.cn, xi1, __builtin_fmaf(P.dt, F1, vy));
+  px = pxn;
+  py = pyn;
+}
+__device__ __forceinline__ float separation_row_exact(const rato_car_params& P, float ex, float ey, float px, float py) {
+#pragma clang fp contract(off)
+  const float dx = ex - px, dy = ey - py;
+  const float d2 = unfused(dx * dx) + unfused(dy * dy);
+  return -__builtin_fmaf(d2, __builtin_amdgcn_rsqf(d2), -P.d_min);
+}
+
 // PHILOX: regenerate the two pedestrian noise components of step t in the kernel (philox.h; bit-identical to
 // rato_car_sample's dW) instead of reading 8 B per sample-step.
 template <bool PHILOX>
@@ -209,11 +238,8 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
       nx0 = dW[(size_t)(tn * 2 + 0) * M + m];
       nx1 = dW[(size_t)(tn * 2 + 1) * M + m];
     }
-    float n0, n1, rinv;
-    ped_step(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy, n0, n1, rinv);
-    const float dx = ego[(t + 1) * 4 + 0] - px, dy = ego[(t + 1) * 4 + 1] - py;
-    const float d2 = dx * dx + dy * dy;
-    const float gt = -(d2 * __builtin_amdgcn_rsqf(d2) - P.d_min);  // -(||p_e - p_p|| - d_min): driving.py:223-230,269
+    ped_step_exact(P, c, ego[t * 4 + 0], ego[t * 4 + 1], xi0, xi1, px, py, vx, vy);
+    const float gt = separation_row_exact(P, ego[(t + 1) * 4 + 0], ego[(t + 1) * 4 + 1], px, py);   // -(||p_e - p_p|| - d_min): driving.py:223-230,269
     zmax = fmaxf(zmax, gt);
     if (g) g[(size_t)t * M + m] = gt;
     if (xs) {
@@ -228,36 +254,6 @@ __global__ __launch_bounds__(RATO_BLOCK) void car_eval_kernel(
     }
   }
   if (Z) Z[m] = zmax - P.tol;
-}
-
-// ped_step and the distance row with every rounding spelled out: the contraction pattern the compiler chooses for them in
-// car_eval_kernel (read off its ISA; see step_axis_exact in drone.hip for why) -- for a kernel that has to reproduce
-// car_eval_kernel to the bit.
-// (-ffp-contract=fast lets the BACK END fuse any multiply into a following add whatever the pragma says: a product that
-//  must stay a product goes through an empty asm statement, which hides where it came from)
-__device__ __forceinline__ float unfused(float x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-__device__ __forceinline__ void ped_step_exact(const rato_car_params& P, const PedConsts& c, float ex, float ey, float xi0,
-                                               float xi1, float& px, float& py, float& vx, float& vy) {
-#pragma clang fp contract(off)
-  const float dx = ex - px, dy = ey - py;
-  const float r2 = unfused(dx * dx) + unfused(dy * dy);
-  const float rinv = __builtin_amdgcn_rsqf(r2);
-  const float common = c.w_s * (P.speed_ped_des - vy);
-  const float F0 = __builtin_fmaf(-c.w_r, dx * rinv, common), F1 = __builtin_fmaf(-c.w_r, dy * rinv, common);
-  const float pxn = __builtin_fmaf(P.dt, vx, px), pyn = __builtin_fmaf(P.dt, vy, py);
-  vx = __builtin_fmaf(c.cn, xi0, __builtin_fmaf(P.dt, F0, vx));
-  vy = __builtin_fmaf(c.cn, xi1, __builtin_fmaf(P.dt, F1, vy));
-  px = pxn;
-  py = pyn;
-}
-__device__ __forceinline__ float separation_row_exact(const rato_car_params& P, float ex, float ey, float px, float py) {
-#pragma clang fp contract(off)
-  const float dx = ex - px, dy = ey - py;
-  const float d2 = unfused(dx * dx) + unfused(dy * dy);
-  return -__builtin_fmaf(d2, __builtin_amdgcn_rsqf(d2), -P.d_min);
 }
 
 // The Monte-Carlo form for small batches (driving.py:618-740: M = 1e4), for calls that want Z (and g) but no

@@ -47,21 +47,31 @@ __device__ __forceinline__ SampleConsts load_consts(const rato_drone_params& P, 
   return c;
 }
 
-// One Euler–Maruyama step of one axis (drone_risk.py:122-131,148-153).
-__device__ __forceinline__ void step_axis(const rato_drone_params& P, const SampleConsts& c, float u, float xi,
-                                          float& p, float& v) {
-  const float acc = (u - (P.kp * p + P.kd * v)) * c.inv_m - P.drag * fabsf(v) * v * c.inv_m;
-  const float pn = p + P.dt * v;
-  const float vn = v + P.dt * acc + c.cn * xi;
+// One Euler-Maruyama step of one axis (drone_risk.py:122-131,148-153) and the obstacle row g_j = 1 - (p - o_j)' Q_j (p - o_j)
+// (:169-196), with every rounding spelled out (contraction off: only the written fmas fuse).
+// -ffp-contract=fast leaves the contraction pattern to the optimiser, and the same source compiled into ANOTHER kernel came
+// out one rounding different (1e-7 relative, round 5).  Every kernel that reports Z / g / trajectories of the plain rollout
+// -- drone_eval_kernel (trajectories, Philox) and drone_eval_tiles_kernel -- calls THESE, so that they agree to the bit by
+// construction and not by what a compiler version happens to fuse.
+__device__ __forceinline__ void step_axis_exact(const rato_drone_params& P, const SampleConsts& c, float u, float xi,
+                                                float& p, float& v) {
+#pragma clang fp contract(off)
+  const float kv = P.kd * v;
+  const float pn = __builtin_fmaf(P.dt, v, p);
+  const float s = __builtin_fmaf(P.kp, p, kv);
+  const float dq = v * (P.drag * fabsf(v));
+  const float w = c.inv_m * dq;
+  const float acc = __builtin_fmaf(c.inv_m, u - s, -w);
+  v = __builtin_fmaf(c.cn, xi, __builtin_fmaf(P.dt, acc, v));
   p = pn;
-  v = vn;
 }
-
-// g_j at the horizontal position (px, py): 1 - (p - o_j)' Q_j (p - o_j)  (drone_risk.py:169-196); ONE expression for
-// every kernel that reports constraint values, so that they agree to the bit
-__device__ __forceinline__ float obstacle_value(const rato_drone_params& P, const SampleConsts& c, int j, float px, float py) {
+__device__ __forceinline__ float obstacle_value_exact(const rato_drone_params& P, const SampleConsts& c, int j, float px, float py) {
+#pragma clang fp contract(off)
   const float dx = px - P.obs_xy[j][0], dy = py - P.obs_xy[j][1];
-  return 1.0f - (c.q00[j] * dx * dx + c.qs[j] * dx * dy + c.q11[j] * dy * dy);
+  float a = dy * (c.qs[j] * dx);
+  a = __builtin_fmaf(dx, c.q00[j] * dx, a);
+  a = __builtin_fmaf(dy, c.q11[j] * dy, a);
+  return 1.0f - a;
 }
 
 // PHILOX: the noise of step t is REGENERATED in the kernel (Philox4x32-10 at counter (m, t), philox.h) instead of
@@ -111,7 +121,7 @@ __device__ __forceinline__ void drone_eval_block(
       for (int a = 0; a < 3; ++a) nxt[a] = dW[(size_t)(tn * 3 + a) * ld + m];
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) step_axis(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
+    for (int a = 0; a < 3; ++a) step_axis_exact(P, c, us[t * 3 + a], xi[a], p[a], v[a]);
     if (xs) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -121,7 +131,7 @@ __device__ __forceinline__ void drone_eval_block(
     }
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) {
-      const float gj = obstacle_value(P, c, j, p[0], p[1]);
+      const float gj = obstacle_value_exact(P, c, j, p[0], p[1]);
       zmax = fmaxf(zmax, gj);
       if (g) g[((size_t)j * S + t) * ld + m] = gj;
     }
@@ -161,32 +171,6 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_eval_kernel(
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-}
-
-// step_axis / obstacle_value with every rounding spelled out, for a horizontal axis -- the contraction pattern the compiler
-// chooses for them inside drone_eval_kernel (it fuses the two horizontal axes into packed fp32 operations there;
-// read off its ISA: profiles/EXPERIMENTS.md, round 5).  -ffp-contract=fast leaves the pattern to the optimiser, and the
-// same source compiled into ANOTHER kernel came out one rounding different (1e-7 relative); a kernel that has to
-// reproduce drone_eval_kernel to the bit calls these (contraction off: only the written fmas fuse).
-__device__ __forceinline__ void step_axis_exact(const rato_drone_params& P, const SampleConsts& c, float u, float xi,
-                                                float& p, float& v) {
-#pragma clang fp contract(off)
-  const float kv = P.kd * v;
-  const float pn = __builtin_fmaf(P.dt, v, p);
-  const float s = __builtin_fmaf(P.kp, p, kv);
-  const float dq = v * (P.drag * fabsf(v));
-  const float w = c.inv_m * dq;
-  const float acc = __builtin_fmaf(c.inv_m, u - s, -w);
-  v = __builtin_fmaf(c.cn, xi, __builtin_fmaf(P.dt, acc, v));
-  p = pn;
-}
-__device__ __forceinline__ float obstacle_value_exact(const rato_drone_params& P, const SampleConsts& c, int j, float px, float py) {
-#pragma clang fp contract(off)
-  const float dx = px - P.obs_xy[j][0], dy = py - P.obs_xy[j][1];
-  float a = dy * (c.qs[j] * dx);
-  a = __builtin_fmaf(dx, c.q00[j] * dx, a);
-  a = __builtin_fmaf(dy, c.q11[j] * dy, a);
-  return 1.0f - a;
 }
 
 // Monte-Carlo validation batches (drone_risk.py:643-725: M = 1e4) are LATENCY bound: drone_eval_kernel at C2 runs 40

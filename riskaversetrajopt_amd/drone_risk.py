@@ -862,8 +862,17 @@ class Model:
         return info["us"], info["t_risk"], info
 
     def _native_define_buffers(self, cs):
-        S, M = self.S, cs.M
-        b = self._native_define_buffers(cs)
+        """the device / pinned buffers rato_cut_define_drone and rato_scp_run_drone work in (made once per shape)"""
+        S, M, ld = self.S, cs.M, self._mass.numel()
+        b = getattr(self, "_native_define", None)
+        if b is None or b["key"] != (S, M, ld):
+            e = lambda *sh, dt=torch.float32: torch.empty(sh, dtype=dt, device=self.device)
+            b = {"key": (S, M, ld), "us_host": torch.zeros((S, n_u), dtype=torch.float32).pin_memory(), "us_dev": e(S, n_u),
+                 "A22": e(S, 3, ld), "Z": e(ld), "part": e((M + 255) // 256, 6 * S + 6),
+                 "sums_host": torch.zeros(6 * S + 6, dtype=torch.float64).pin_memory(),
+                 "bad_dev": e(1, dt=torch.int32), "bad_host": torch.zeros(1, dtype=torch.int32).pin_memory()}
+            b["sums_np"] = b["sums_host"].numpy()
+            self._native_define = b
         return b
 
     def scp_run_native(self, us0, iters, first_cvar=2, tol=1e-9, max_cuts=400, final_cut_above=1e-11):
