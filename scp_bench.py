@@ -46,8 +46,13 @@ def main():
             solve = model.solve_reduced
             model.solve_reduced = lambda us, it, **kw: solve(us, it, tol=args.tol, **kw)
         t_all = time.perf_counter()
-        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=(rank == 0))
+        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=False)   # (one GPU: rato_scp_run_drone)
+        if rank == 0:
+            for k in range(args.iters):
+                print(f"scp {k:3d}  define {out['define_s'][k]:.4f}s  solve {out['solve_s'][k]:.4f}s "
+                      f"({out['cuts'][k]} cuts, oracle {out['oracle_s'][k]:.4f}s)  L2 {out['L2_error'][k]:.3e}")
         line = {"system": "drone", "mode": "reduced (u, slack) problem, device CVaR cuts + host master QP",
+                "loop": out.get("loop"),
                 "M": args.M, "M_total": args.M * world, "n_gpus": world, "S": args.S, "alpha": args.alpha,
                 "iters": args.iters,
                 "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),
