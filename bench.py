@@ -836,9 +836,12 @@ def scp_block(work, args):
     kkt = kkt_block(model, out["us"], args.scp_iters, 2, "drone_risk.py:327-368")
     return {"system": "drone_risk", "M": work.M, "S": work.S, "alpha": args.alpha, "iters": args.scp_iters, "kkt": kkt,
             "kernels": kernels,
-            "cut_tolerance": 1e-9, "loop": "rato_cut_solve (native cutting-plane loop, one library call per subproblem)",
+            "cut_tolerance": 1e-9,
+            "loop": f"{out.get('loop', 'python')}; every subproblem: rato_cut_define_drone + rato_cut_solve (the cutting-plane loop native)",
             "protocol": "drone_times.py:509-550: fixed iteration count from the initial guess, per-iteration define / "
-                        "solve wall-clock, medians + cumulative; run after the timed throughput region",
+                        "solve wall-clock, medians + cumulative; run after the timed throughput region.  Native loop: an "
+                        "iteration's clock runs from its first instruction to the moment its solution is on the host, the "
+                        "stream is synchronised once inside the last iteration's clock",
             "subproblem": "reference QP reduced exactly to (u, slack): device CVaR cuts (Jacobian-free oracle) + host "
                           "master QP (3S+1 variables); non-finite check on every linearization",
             "define_median_s": float(np.median(out["define_s"])), "solve_median_s": float(np.median(out["solve_s"])),

@@ -92,9 +92,11 @@ extern "C" {
  * rato_car_params, rato_car_rowmax_rollout / rato_car_tail_rows_rollout, rato_cut_oracle_rollout, rato_nnls_warm, rato_master_*,
  * (9: rato_cut_solver_* / rato_cut_begin / rato_cut_solve -- the cutting-plane loop of a subproblem as one call;
  * params.stats_* -- the statistics of Z in extra workgroups of the row-parallel linearize launch itself)
- * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover).
+ * rato_copy_async, rato_stream_synchronize, rato_risk_stats_recover; 12: rato_hopper_slip_hessian,
+ * rato_hopper_jacobian_nnz / rato_hopper_emit_jacobian_values -- the hopper's jacrev / Lagrangian Hessian in the reference's
+ * layout; rato_scp_run_drone / rato_scp_iter -- the reduced SCP loop as one call).
  * The Python binding refuses a library that reports another version. */
-#define RATO_ABI_VERSION 11
+#define RATO_ABI_VERSION 12
 #define RATO_STATS_IN_LAUNCH 1   /* params.stats_flags */
 int rato_abi_version(void);
 

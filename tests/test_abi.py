@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_size_queries(lib):
     from riskaversetrajopt_amd import _lib
-    assert lib.rato_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.rato_abi_version() == _lib.ABI_VERSION == 12
     import ctypes as C
     cpt, spl, tile = C.c_int32(8), C.c_int32(1), C.c_int32(0)
     assert lib.rato_drone_linearize_plan(1000, 50, 1000, C.byref(cpt), C.byref(spl), C.byref(tile)) == 4
