@@ -32,6 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# diagnostic (EXPERIMENTS 6): time the K steps WITHOUT the HIP events around every launch -- what the events themselves cost;
+# the line then has no kernel time (`roofline` is NaN) and is not a valid bench line
+NO_EVENTS = bool(os.environ.get("RATO_BENCH_NO_EVENTS"))
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 B = 4                       # fp32
 
@@ -652,7 +655,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
             with torch.cuda.stream(two[i & 1]):
                 step()                                   # (no events: two kernels share the chip, their brackets mean nothing)
         else:
-            step(i)
+            step(None if NO_EVENTS else i)
     if pipe is not None:
         pipe.drain()                                     # the last step's exchange + statistics: inside the timed region
     torch.cuda.synchronize()
@@ -663,7 +666,7 @@ def timed_region(work, args, world, rank, device, stats, rdist, dist, torch, pro
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = kern_ms_eager if use_graph else (float("nan") if two is not None else
+    kern_ms = kern_ms_eager if use_graph else (float("nan") if (two is not None or NO_EVENTS) else
                                                float(np.mean([a.elapsed_time(b) for a, b in ev])))
     if os.environ.get("RATO_BENCH_TRACE") and not use_graph and two is None and rank == 0:      # per-launch kernel times, to stderr
         ts = [a.elapsed_time(b) for a, b in ev]
