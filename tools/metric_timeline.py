@@ -103,13 +103,20 @@ def curve(label, sets, t0=None, bins=10.0):
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 # ---- one launch, one stream
 torch.cuda.synchronize()
+# the events are queued BEHIND a spin kernel, so that they bracket the launch on the GPU's clock and not the host's time
+# inside the facade call (on an idle GPU the first event is taken at once and the ~35 us of Python before the launch
+# would be counted into the "kernel")
+torch.cuda._sleep(2_000_000)
 a.record()
 d.linearize_device(us, out=outs[0], factored=False)
 b.record()
 torch.cuda.synchronize()
-print(f"one stream: launch by HIP events {a.elapsed_time(b) * 1e3:.1f} us; queue split "
+ev_us = a.elapsed_time(b) * 1e3
+s_one = stamps(outs[0])
+print(f"one stream: launch by HIP events (queued behind a spin kernel) {ev_us:.1f} us; first unit start -> last record "
+      f"{s_one[0][:, 5].max() - s_one[0][:, 0].min():.1f} us; queue split "
       f"{os.environ.get('RATO_DYN_TAIL_SPLIT', 'default (last 128 tiles as quarters)')}")
-curve("one launch, one stream", [stamps(outs[0])])
+curve("one launch, one stream", [s_one])
 
 # ---- back to back on one stream (what `value` times): the gap between two launches
 torch.cuda.synchronize()
