@@ -907,6 +907,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     float* __restrict__ W, float* __restrict__ A22, float* __restrict__ g_up, float* __restrict__ Z,
     float* __restrict__ part, const rato_sel::StatsTail tail, int flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#if RATO_DIAG == 4
+  const unsigned long long tl_kernel_in = wall_clock64();   // the workgroup's first instruction
+  int tl_last_tile = -1;
+#endif
   // Statistics in the same launch (rato_saa.h: params.stats_*): the workgroups behind the producer's own wait until every
   // tile's Z has been counted in, then run the exact selection on it -- beside the workgroups still storing the Jacobian.
   const int n_prod = tail.ws ? tail.n_prod : (int)gridDim.x;
@@ -1277,6 +1281,9 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
     tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = tl_issued;
     tl[4] = *tl_first;
     tl[6] = wall_clock64();
+    tl[7] = tl_kernel_in;
+    tl[8] = 0;
+    tl_last_tile = tile;
     tl[5] = (unsigned long long)bid | ((unsigned long long)(xcc & 0xf) << 32) | ((unsigned long long)part_id << 40);
   }
 #endif
@@ -1302,6 +1309,10 @@ __global__ __launch_bounds__(ROWS_NW* RATO_WAVE, RATO_ROWS_MINW) void drone_line
       __hip_atomic_store(tile_queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#if RATO_DIAG == 4
+  if (threadIdx.x == 0 && tl_last_tile >= 0)   // the workgroup's last instruction, into the record of its last unit
+    reinterpret_cast<unsigned long long*>(part + (size_t)tl_last_tile * (6 * P.S + 6))[8] = wall_clock64();
+#endif
 }
 
 

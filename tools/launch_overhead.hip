@@ -29,6 +29,20 @@ __global__ __launch_bounds__(512) void probe_kernel(float* out, size_t floats_pe
   }
 }
 
+// the same probe with 768 bytes of kernel arguments (the row kernels take their parameter structs by value)
+struct BigArgs { double v[88]; };
+__global__ __launch_bounds__(512) void probe_bigargs_kernel(float* out, size_t floats_per_wg, int mode, unsigned long long* stamps,
+                                                           const BigArgs a) {
+  extern __shared__ float lds[];
+  const unsigned long long t0 = wclk();
+  if (threadIdx.x == 0 && lds) lds[0] = (float)a.v[blockIdx.x % 88];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t0;
+    stamps[2 * blockIdx.x + 1] = wclk();
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main() {
@@ -43,16 +57,22 @@ int main() {
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_bigargs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   struct Case { const char* name; int g; int lds; int mode; size_t mb; };
   const Case cases[] = {{"empty, 256 wg, no LDS", 256, 0, 0, 0},        {"empty, 256 wg, 64.6 KB LDS", 256, 64600, 0, 0},
                         {"empty, 2048 wg, no LDS", 2048, 0, 0, 0},      {"nt stores 64 MB, 256 wg", 256, 0, 1, 64},
                         {"nt stores 512 MB, 256 wg", 256, 0, 1, 512},   {"nt stores 3 GB, 256 wg", 256, 0, 1, 3072},
                         {"nt stores 3 GB, 256 wg, 64.6 KB LDS", 256, 64600, 1, 3072},
                         {"plain stores 512 MB, 256 wg", 256, 0, 2, 512}, {"plain stores 3 GB, 256 wg", 256, 0, 2, 3072},
-                        {"nt stores 800 MB, 512 wg", 512, 0, 1, 800}};
+                        {"nt stores 800 MB, 512 wg", 512, 0, 1, 800},
+                        {"empty, 256 wg, 64.6 KB LDS, 768 B of arguments", 256, 64600, 9, 0}};
   for (const Case& c : cases) {
     const size_t fpw = c.mb ? ((size_t)c.mb << 20) / 4 / c.g / 512 * 512 : 0;
-    auto launch = [&]() { hipLaunchKernelGGL(probe_kernel, dim3(c.g), dim3(512), c.lds, 0, out, fpw, c.mode, stamps); };
+    BigArgs big = {};
+    auto launch = [&]() {
+      if (c.mode == 9) hipLaunchKernelGGL(probe_bigargs_kernel, dim3(c.g), dim3(512), c.lds, 0, out, fpw, 0, stamps, big);
+      else hipLaunchKernelGGL(probe_kernel, dim3(c.g), dim3(512), c.lds, 0, out, fpw, c.mode, stamps);
+    };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     double ev = 0, span = 0;

@@ -35,8 +35,11 @@ TILE_BYTES = 3 * S * (S - 1) * 64 * 4 + 3 * S * 64 * 4
 
 def stamps(o):
     raw = o["part"].cpu().numpy()
-    tl = np.ascontiguousarray(raw[:, :14]).view(np.uint64)                 # (tiles, 7)
+    tl = np.ascontiguousarray(raw[:, :18]).view(np.uint64)                 # (tiles, 9)
     meta = tl[:, 5]
+    global KERNEL_IN_OUT
+    k_out = tl[:, 8][tl[:, 8] > 0]
+    KERNEL_IN_OUT = (tl[:, 7].min() * 1e-2, (k_out.max() if len(k_out) else 0) * 1e-2, tl[:, 0].min() * 1e-2, tl[:, 6].max() * 1e-2)
     # columns: start, staged, rolled, first store, all row tasks issued, [all stores acknowledged | = issued]
     cols = tl[:, [0, 1, 2, 4, 3, 6]].astype(np.float64) * 1e-2
     return cols, (meta & 0xffffffff).astype(np.int64), ((meta >> 32) & 0xf).astype(np.int64)
@@ -116,6 +119,10 @@ s_one = stamps(outs[0])
 print(f"one stream: launch by HIP events (queued behind a spin kernel) {ev_us:.1f} us; first unit start -> last record "
       f"{s_one[0][:, 5].max() - s_one[0][:, 0].min():.1f} us; queue split "
       f"{os.environ.get('RATO_DYN_TAIL_SPLIT', 'default (last 128 tiles as quarters)')}")
+ki, ko, u0, r1 = KERNEL_IN_OUT
+print(f"            first instruction of any workgroup {u0 - ki:.2f} us before the first unit's start stamp; last instruction of any "
+      f"workgroup {ko - r1:.2f} us after the last record; first instruction -> last instruction {ko - ki:.1f} us "
+      f"(events - that = {ev_us - (ko - ki):.1f} us of dispatch + release)")
 curve("one launch, one stream", [s_one])
 
 # ---- back to back on one stream (what `value` times): the gap between two launches
