@@ -10,14 +10,17 @@
 //     columns of the Householder Q of (A_eq D^-1/2)', kept as m reflectors, and every product with it costs O(n m)
 //     (NumPy's complete QR + the dense N cost 0.27 ms per SCP iteration, and a row of the master a 151 x 145 product);
 //   * the problem in v (z = x0 + N (v - c)) is a least-distance problem  min |v|  s.t.  G v >= h, solved through NNLS
-//     (Lawson & Hanson ch. 23) on [G' ; h'/sigma] with the passive set of the previous solve as the start
-//     (rato_nnls_warm, nnls.hip); sigma ~ |v| keeps the KKT tolerance of the NNLS meaningful for optima far out.
+//     (Lawson & Hanson ch. 23) on [G' ; h'/sigma] with the passive set of the previous solve as the start AND its thin QR
+//     factor kept (rato_nnls.h; round 6); sigma ~ |v| (within a factor 4) keeps the KKT tolerance of the NNLS meaningful
+//     for optima far out.
 // The reference hands the whole subproblem to OSQP (drone_risk.py:433-457).
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
+#include "rato_nnls.h"
 #include "rato_saa.h"
 
 struct rato_master {
@@ -33,6 +36,16 @@ struct rato_master {
   double vnorm = 0.0;
   int nrows = 0;
   std::vector<double> work, An, y;
+  // Round 6: the NNLS problem [G' ; h'/sigma] y ~ [0; 1] GROWS by the columns of the rows added between two solves, and the
+  // thin QR factor of the previous solve's passive columns stays valid as long as sigma does -- it is kept (rebuilding it
+  // column by column was ~2/3 of a solve).  sigma is re-chosen only when |v| has left [sigma/4, 4 sigma]; the factor is
+  // rebuilt then, after FACTOR_REFRESH updates / downdates (rounding of the Givens downdates), and after a failed solve.
+  rato_nnls::ThinQR qr;
+  bool factor_ready = false;
+  int an_cols = 0, changes = 0;       // columns of An in place; updates + downdates since the factor was last built
+  double sigma = 0.0, a1 = 0.0;      // the scale An was built with; max column 1-norm of An
+  std::vector<double> nn_s, nn_resid, bn;
+  std::vector<uint8_t> nn_banned;
 
   void apply_Qt(double* t) const {   // t <- Q' t = H_m ... H_1 t
     for (int j = 0; j < m; ++j) {
@@ -170,27 +183,67 @@ extern "C" int rato_master_solve(rato_master* M, double* z, double* lam) {
   const int n = M->n, m = M->m, nk = M->nk, r = M->nrows;
   std::vector<double> v(nk, 0.0);
   if (r > 0) {
+    constexpr int FACTOR_REFRESH = 96;
+    // sigma sticks while |v| stays within a factor SIGMA_STICK of it.  Not wider: near convergence the cuts are nearly
+    // parallel and differ mostly in h; a sigma 3x too large (left over from an earlier, larger |v|) shrank those differences
+    // until the NNLS cycled between near-dependent columns (found on tests/test_gpu_scp.py's M = 40 case with a factor 4).
+    // RATO_MASTER_STICK overrides (1: rescale whenever |v| moves, the behaviour up to round 5).
+    static const double SIGMA_STICK = [] { const char* e = getenv("RATO_MASTER_STICK"); return e ? atof(e) : 1.5; }();
     double hmax = 0.0;
     for (int j = 0; j < r; ++j) hmax = fmax(hmax, M->rows[(size_t)j * (nk + 1) + nk]);
-    const double sigma = fmax(1.0, fmax(M->vnorm, hmax));
+    const double want = fmax(1.0, fmax(M->vnorm, hmax));
     const int mm = nk + 1;
-    M->An.resize((size_t)mm * r);
-    for (int j = 0; j < r; ++j) {
-      const double* row = &M->rows[(size_t)j * mm];
-      double* col = &M->An[(size_t)j * mm];
-      for (int i = 0; i < nk; ++i) col[i] = row[i];
-      col[nk] = row[nk] / sigma;
-    }
-    std::vector<double> bn(mm, 0.0);
-    bn[nk] = 1.0;
+    auto rescale = [&](double sg) {   // every column changes: An is rebuilt, the factor with it
+      M->sigma = sg;
+      M->an_cols = 0;
+      M->a1 = 0.0;
+      M->factor_ready = false;
+    };
+    auto sync_columns = [&]() {       // the columns of the rows added since the last solve (all of them after a rescale)
+      M->An.resize((size_t)mm * r);
+      for (int j = M->an_cols; j < r; ++j) {
+        const double* row = &M->rows[(size_t)j * mm];
+        double* col = &M->An[(size_t)j * mm];
+        double sj = 0.0;
+        for (int i = 0; i < nk; ++i) {
+          col[i] = row[i];
+          sj += fabs(row[i]);
+        }
+        col[nk] = row[nk] / M->sigma;
+        sj += fabs(col[nk]);
+        if (sj > M->a1) M->a1 = sj;
+      }
+      M->an_cols = r;
+    };
+    if (!(M->sigma > 0.0) || want > SIGMA_STICK * M->sigma || want * SIGMA_STICK < M->sigma) rescale(want);
+    sync_columns();
+    if (M->changes > FACTOR_REFRESH) M->factor_ready = false;
+    if (!M->factor_ready) M->changes = 0;
+    M->bn.assign(mm, 0.0);
+    M->bn[nk] = 1.0;
     M->y.assign(r, 0.0);
-    int ok = rato_nnls_warm(M->An.data(), mm, r, bn.data(), M->passive.data(), M->y.data(), 0);
+    int ok = rato_nnls::nnls_core(M->An.data(), mm, r, M->bn.data(), M->passive.data(), M->y.data(), 0, M->a1, M->qr,
+                                  M->factor_ready, M->nn_s, M->nn_resid, M->nn_banned, &M->changes);
+    if (ok != 1 && M->sigma != want) {   // a kept sigma was not good enough: the scale the previous rounds always used
+      rescale(want);
+      sync_columns();
+      M->changes = 0;
+      ok = rato_nnls::nnls_core(M->An.data(), mm, r, M->bn.data(), M->passive.data(), M->y.data(), 0, M->a1, M->qr, false,
+                                M->nn_s, M->nn_resid, M->nn_banned, &M->changes);
+    }
     if (ok != 1) {   // cold restart with a long leash (the NumPy version falls back to scipy's Lawson-Hanson here)
       for (int j = 0; j < r; ++j) M->passive[j] = 0;
-      ok = rato_nnls_warm(M->An.data(), mm, r, bn.data(), M->passive.data(), M->y.data(), 20 * r + 20);
-      if (ok != 1) return ok < 0 ? ok : 0;
+      M->changes = 0;
+      ok = rato_nnls::nnls_core(M->An.data(), mm, r, M->bn.data(), M->passive.data(), M->y.data(), 20 * r + 20, M->a1, M->qr,
+                                false, M->nn_s, M->nn_resid, M->nn_banned, &M->changes);
+      if (ok != 1) {
+        M->factor_ready = false;
+        return ok < 0 ? ok : 0;
+      }
     }
-    std::vector<double> res(mm, 0.0);
+    M->factor_ready = true;   // (qr = the factor of the passive columns of this solve: the next solve starts from it)
+    std::vector<double>& res = M->nn_resid;
+    res.assign(mm, 0.0);
     for (int j = 0; j < r; ++j) {
       const double yj = M->y[j];
       if (yj == 0.0) continue;
@@ -199,6 +252,7 @@ extern "C" int rato_master_solve(rato_master* M, double* z, double* lam) {
     }
     res[nk] -= 1.0;
     if (fabs(res[nk]) < 1e-14) return RATO_EINFEASIBLE;
+    const double sigma = M->sigma;
     double vn = 0.0;
     for (int i = 0; i < nk; ++i) {
       v[i] = -sigma * res[i] / res[nk];

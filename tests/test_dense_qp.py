@@ -234,3 +234,43 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(dense_qp, "_STRICT", [False])
     with pytest.raises(AttributeError):
         dense_qp._native_master()
+
+
+def test_master_with_a_kept_factor_on_a_recorded_cutting_plane_sequence(monkeypatch):
+    """The native master keeps the thin QR factor of the passive set between two solves (the columns of a growing NNLS
+    problem do not change while its scale sigma does not).  Recorded sequence (tests/golden/master_sequence_*.npz: the rows
+    a drone subproblem with M = 40, S = 20 added, in order, and the row counts at which it solved): near its end the cuts
+    are nearly parallel and a sigma kept from an earlier, larger |v| made the NNLS cycle -- every solve must converge, and
+    agree with a master that rescales (and refactors) at every solve."""
+    import ctypes as C
+    import os
+    from riskaversetrajopt_amd import _lib
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "master_sequence_near_parallel_cuts.npz"))
+    lib = _lib.load()
+
+    def run():
+        h = C.c_void_p()
+        q, pd, A, b = (np.ascontiguousarray(f[k]) for k in ("q", "p_diag", "A_eq", "b_eq"))
+        assert lib.rato_master_create(C.byref(h), q.shape[0], pd.ctypes.data, q.ctypes.data, A.shape[0], A.ctypes.data, b.ctypes.data) == 0
+        rows, rhs = np.ascontiguousarray(f["rows"]), np.ascontiguousarray(f["rhs"])
+        z, lam, done, out = np.zeros(q.shape[0]), np.zeros(rows.shape[0]), 0, []
+        for n in f["solve_at"]:
+            if n > done:
+                assert lib.rato_master_add_rows(h, int(n - done), rows[done:n].ctypes.data, rhs[done:n].ctypes.data) == 0
+                done = int(n)
+            assert lib.rato_master_solve(h, z.ctypes.data, lam.ctypes.data) == 1, f"solve with {n} rows did not converge"
+            assert np.all(rows[:done] @ z <= rhs[:done] + 1e-7 * (1.0 + np.abs(rhs[:done])))
+            out.append(z.copy())
+        lib.rato_master_destroy(h)
+        return np.array(out)
+    kept = run()
+    # the reference behaviour: a fresh library state is not needed -- the stickiness is read once per process, so the
+    # comparison leg is the NumPy master (rescales at every solve by construction)
+    m = dense_qp.MasterPy(np.diag(f["p_diag"]), f["q"], f["A_eq"], f["b_eq"])
+    done = 0
+    for k, n in enumerate(f["solve_at"]):
+        if n > done:
+            m.add_rows(f["rows"][done:n], f["rhs"][done:n])
+            done = int(n)
+        x, _ = m.solve()
+        np.testing.assert_allclose(kept[k], x, rtol=0, atol=2e-7 * max(1.0, np.abs(x).max()))
