@@ -25,7 +25,8 @@ def lib():
 def test_header_declares_expected_entry_points():
     fns = header_functions()
     for name in ("rato_drone_eval", "rato_drone_linearize", "rato_car_eval", "rato_car_linearize",
-                 "rato_hopper_slip", "rato_sum_partials", "rato_risk_stats"):
+                 "rato_hopper_slip", "rato_sum_partials", "rato_risk_stats", "rato_scp_run_drone",
+                 "rato_hopper_emit_jacobian_values", "rato_hopper_slip_hessian"):
         assert name in fns
 
 
@@ -69,6 +70,7 @@ def test_cut_loop_struct_layouts_match_the_library(lib):
     from riskaversetrajopt_amd import _lib
     assert ctypes.sizeof(_lib.CutConfig) == lib.rato_cut_config_bytes()
     assert ctypes.sizeof(_lib.CutResult) == lib.rato_cut_result_bytes()
+    assert ctypes.sizeof(_lib.ScpIter) == lib.rato_scp_iter_bytes()          # the per-iteration record of rato_scp_run_drone
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
