@@ -452,12 +452,17 @@ __global__ __launch_bounds__(RATO_BLOCK) void drone_linearize_generators_kernel(
     mP0[a] = 1.0; mP1[a] = 0.0; mV0[a] = 0.0; mV1[a] = 1.0; dP[a] = 0.0; dV[a] = 0.0;
   }
   const float* a22r = A22 + (size_t)(S - 1) * row3;   // row 3 s of the table being read back (stops at row 0)
+  // A lane past the batch reads NOTHING back: its clamped address is the last sample's entry, which ANOTHER wave may not
+  // have written yet when this wave is entirely past the batch (M = 5: waves 1..3; M = 1e5: the last wave of the last
+  // block) -- whatever the buffer held before would then enter the adjoint, and a NaN bit pattern of a fresh allocation
+  // survives the multiplication by dtm_v = 0 below (found by tools/soak.py in round 6: NaN sample sums on the second call
+  // at S = 64, M = 5; with the persistent buffers of the SCP the stale entries were finite and the product zero).
   auto load_e22 = [&](float (&e22b)[TB][3]) {   // the table entries of the next 8 steps down (same lane wrote them: program order)
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-      e22b[i][0] = at(a22r, boff0);
-      e22b[i][1] = at(a22r, boff1);
-      e22b[i][2] = at(a22r, boff2);
+      e22b[i][0] = valid ? at(a22r, boff0) : 0.0f;
+      e22b[i][1] = valid ? at(a22r, boff1) : 0.0f;
+      e22b[i][2] = valid ? at(a22r, boff2) : 0.0f;
       a22r = (a22r != A22) ? a22r - row3 : a22r;
     }
   };

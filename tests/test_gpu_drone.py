@@ -439,3 +439,32 @@ def test_in_place_noise_refill_needs_and_honours_invalidate():
     assert torch.equal(b, c) and not torch.equal(a, b)
     with pytest.raises(ValueError):
         d.set_noise(dW2[:, :2].contiguous())
+
+
+@pytest.mark.parametrize("S,M", [(64, 5), (20, 1), (50, 300), (33, 257)])
+def test_generators_linearization_ignores_what_its_scratch_held(S, M):
+    """rato_drone_linearize_generators reads its step-Jacobian table back in the adjoint pass.  A lane past the batch must
+    not: its clamped address is the last sample's entry, which another wave may not have written yet when the lane's own
+    wave is entirely past the batch, and a NaN left in a fresh buffer survived the multiplication by zero that was meant
+    to silence the lane (round 6, found by tools/soak.py: NaN sample sums on the second call at S = 64, M = 5).  Here the
+    scratch, the outputs and the partial sums are pre-filled with NaN: the results must be finite, identical to a run on
+    zero-filled buffers, and equal to the oracle's sample sums."""
+    import torch
+    from oracle import drone as od
+    from riskaversetrajopt_amd import drone_risk
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(3), 'saa', M=M, S=S)
+    o, d = od.Model(S, DWs, masses, Q, 'saa', 0.1), drone_risk.Model(S, DWs, masses, Q, 'saa', 0.1)
+    t = np.arange(S)[:, None]
+    us = np.hstack([0.6 * np.cos(0.3 * t) + 0.3, 0.15 * np.sin(0.5 * t) + 0.02, 0.05 * np.cos(t)]) * (20.0 / S)
+    ref = d.linearize_generators_device(us)
+    ld = ref["_A22"].shape[-1]
+    for fill in (float("nan"), 0.0, float("inf")):
+        bufs = {"_A22": torch.full((S, 3, ld), fill, device=d.device), "_W": torch.full((3, S, 2, ld), fill, device=d.device),
+                "_g_up": torch.full((3, S, ld), fill, device=d.device), "_Z": torch.full((ld,), fill, device=d.device),
+                "part": torch.full(tuple(ref["part"].shape), fill, device=d.device)}
+        for _ in range(3):
+            r = d.linearize_generators_device(us, out=bufs)
+            assert bool(torch.isfinite(r["sums"]).all()) and bool(torch.isfinite(r["g_up"]).all()), fill
+            assert torch.equal(r["sums"], ref["sums"]) and torch.equal(r["g_up"], ref["g_up"]) and torch.equal(r["Z"], ref["Z"])
+    fdu, flo, _, _, _ = o.get_all_constraints_coeffs(us)
+    np.testing.assert_allclose(d.expand_final_du(ref["du_sum"].cpu().numpy(), 1.0 / M), fdu.mean(0), rtol=1e-5, atol=1e-6)
