@@ -4,6 +4,10 @@ import sys, time, numpy as np, torch, faulthandler
 faulthandler.dump_traceback_later(600, exit=True)
 sys.path.insert(0, '.')
 from riskaversetrajopt_amd import drone_risk, drone_utils, driving
+import os
+if os.environ.get("RATO_POISON") == "1":      # every uninitialised device allocation comes back as NaN (tests/conftest.py)
+    from tests.conftest import _poison_uninitialised_device_memory
+    _poison_uninitialised_device_memory()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(0)
