@@ -1653,7 +1653,8 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
           static const int qslots_env = [] { const char* e = getenv("RATO_ROWS_QSLOTS"); return e ? atoi(e) : 0; }();   // A/B: absolute
           const int qslots = qslots_env > 0 ? qslots_env : ((!W && slots_env < 1 && n_tiles >= 1024) ? cus : slots);
           grid = qslots;
-          // Products output: the LAST slots/2 tiles are handed out as quarter tiles (4 row-interleaved parts each).
+          // Products output: the LAST tiles are handed out in row-interleaved parts (round 3: quarters of the last slots / 2
+          // tiles; round 6: halves of the last `slots` tiles, below).
           // The drain at the end of the launch is bounded per workgroup (~19 GB/s each, whatever the residency), so
           // shorter last units shorten it; the re-staging they cost is paid while the chip is still full.  Same box,
           // alternating, 100 steps (tools/dyn_tail_sweep.sh): 0.5543-0.5576 -> 0.5415-0.5440 ms (-2.4 %, 0.704-0.708
@@ -1662,8 +1663,13 @@ int drone_linearize_impl(const rato_drone_params* p, const float* us, const floa
           // RATO_DYN_TAIL_SPLIT x RATO_DYN_TAIL_TILES override (split 1 = whole tiles only).
           static const int dts = [] { const char* e = getenv("RATO_DYN_TAIL_SPLIT"); return e ? atoi(e) : 0; }();
           static const int dtt = [] { const char* e = getenv("RATO_DYN_TAIL_TILES"); return e ? atoi(e) : 0; }();
-          int want_split = dts > 0 ? dts : (W ? 1 : 4);
-          int want_tiles = dtt > 0 ? dtt : qslots / 2;
+          // Round 6, re-measured on three boards (same board, alternating, kernel ms by events; tools/ab.sh): quarters over
+          // the last 128 tiles (the round-3 choice) 0.5139 / 0.5076 / 0.5135, whole tiles 0.5117 / 0.5036 / 0.5117, HALVES
+          // over the last 128 / 256 / 384 tiles 0.5059 / 0.4980 / 0.5004, 0.5067 / 0.5055 / 0.4986, 0.4984 / 0.5046 / 0.4969;
+          // eighths 0.523-0.538.  Since the streaming stores (round 4) a re-staged unit costs more than it did (its noise is
+          // no longer re-read from HBM by anyone else in between): halves over the last round of tiles are the default.
+          int want_split = dts > 0 ? dts : (W ? 1 : 2);
+          int want_tiles = dtt > 0 ? dtt : qslots;
           if (want_split > max_split) want_split = max_split;
           if (want_split > 1 && want_tiles > 0) {
             split = want_split;
