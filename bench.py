@@ -939,7 +939,8 @@ def c5_rank_local_block(work, args, device, stats, rdist, torch, world=8, K=100)
     """What EVERY rank of the 8-GPU C5 run pays locally per step, measured on this one GPU: its shard's kernel (125,000
     samples) and, for the exchange, everything but the wire -- rato_unpack_records over `world` records and the exact
     selection over all M_total = 1e6 gathered samples -- serially behind the kernel and pipelined beside the next step's
-    kernel (dist.PipelinedSteps, the N > 1 default).  The records of the other ranks are copies of this rank's."""
+    kernel (dist.PipelinedSteps).  `bench.py --gpus N` probes both forms and times the faster one.  The records of the other
+    ranks are copies of this rank's."""
     from riskaversetrajopt_amd import _lib
     lib = _lib.load()
     M, rec = work.M, work.records[0]
