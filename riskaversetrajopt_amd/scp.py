@@ -63,14 +63,15 @@ def run_drone(model, num_scp_iters_max=60, warmup_iters=5, verbose=False, check_
             "cumulative_s": np.cumsum(define_s + solve_s), "L2_error": np.array(err)}
 
 
-def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=True, native_loop=None):
+def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=True, native_loop=None, tol=None):
     """The SCP loop (drone_risk.py:519-532; also used for driving, driving.py:486-513) with every subproblem solved through
     ``Model.solve_reduced`` (device CVaR oracle + host master QP) — the path that scales to M = 1e5.
     "define" = device linearization (+ its small read-backs), "solve" = cutting-plane loop.
     ``native_loop`` (default: whenever the Model offers it -- the drone, one GPU, table-free oracle): the whole loop as ONE
     library call with the per-iteration clocks taken natively (``Model.scp_run_native`` -> rato_scp_run_drone); False: the
     per-iteration Python loop below, which is also the checker of the native one (same iterates bit for bit) and what the
-    native call hands back to when it meets a case only the Python loop recovers."""
+    native call hands back to when it meets a case only the Python loop recovers.
+    ``tol``: stopping violation of the cutting-plane loops (default: ``solve_reduced``'s own, 1e-9)."""
     _finite_guard(model, check_finite)
     if hasattr(model, "_lib"):                 # a device Model: its master QP must be the native one (no silent NumPy leg)
         from . import dense_qp
@@ -78,7 +79,7 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
     us_prev = model.initial_guess_us_mat()
     if native_loop is not False and not verbose and hasattr(model, "scp_run_native"):
         _sync()
-        r = model.scp_run_native(us_prev, num_scp_iters_max)
+        r = model.scp_run_native(us_prev, num_scp_iters_max, **({} if tol is None else {"tol": tol}))
         if r is not None:
             hist = r["us_hist"]
             prev = [np.asarray(us_prev, dtype=np.float64)] + list(hist[:-1])
@@ -95,7 +96,7 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
     for scp_iter in range(num_scp_iters_max):
         _sync()
         t0 = time.perf_counter()
-        us, t_risk, info = model.solve_reduced(us_prev, scp_iter)
+        us, t_risk, info = model.solve_reduced(us_prev, scp_iter, **({} if tol is None else {"tol": tol}))
         _sync()
         dt_total = time.perf_counter() - t0
         solve_s.append(info["oracle_s"] + info["master_s"])

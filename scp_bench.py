@@ -42,11 +42,8 @@ def main():
         if world > 1:
             model.shard()
         model.solve_reduced(model.initial_guess_us_mat(), 2)             # warm-up (allocations, first launches)
-        if args.tol is not None:
-            solve = model.solve_reduced
-            model.solve_reduced = lambda us, it, **kw: solve(us, it, tol=args.tol, **kw)
         t_all = time.perf_counter()
-        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=False)   # (one GPU: rato_scp_run_drone)
+        out = scp.run_drone_reduced(model, num_scp_iters_max=args.iters, verbose=False, tol=args.tol)   # (one GPU: rato_scp_run_drone)
         if rank == 0:
             for k in range(args.iters):
                 print(f"scp {k:3d}  define {out['define_s'][k]:.4f}s  solve {out['solve_s'][k]:.4f}s "

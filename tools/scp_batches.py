@@ -17,10 +17,8 @@ for tol in (1e-8, 1e-9):
         d = drone_risk.Model.from_device(S, dW, mass, Qsym, 'saa', 0.1, M=M)
         d.solve_reduced(d.initial_guess_us_mat(), 2, tol=tol)
         d._cut_solver = None
-        orig = d.solve_reduced
-        d.solve_reduced = lambda u, k, _o=orig: _o(u, k, tol=tol)
         torch.cuda.synchronize()
-        out = scp.run_drone_reduced(d, num_scp_iters_max=60)
+        out = scp.run_drone_reduced(d, num_scp_iters_max=60, tol=tol)
         tot.append(out["cumulative_s"][-1])
         print(f"tol {tol:.0e} seed {seed:2d} cumulative {out['cumulative_s'][-1]:.4f} define {np.median(out['define_s']):.2e} "
               f"solve {np.median(out['solve_s']):.2e} cuts {int(out['cuts'].sum()):4d} max {int(out['cuts'].max()):3d} "
