@@ -210,3 +210,29 @@ def test_host_inputs_entry_rejects_too_many_contacts():
                                           _lib.ptr(Z), None, None, None, None, _lib.current_stream())
     assert rc == 0
     torch.cuda.synchronize()
+
+
+def test_reference_matrices_beyond_the_by_value_contact_limit():
+    """More than RATO_HOPPER_MAX_HOST_CONTACTS (128) contact steps (S = 300: 200 contacts): the chain factors and the contact
+    inputs no longer fit the kernels' argument blocks and travel through device arrays (chain_dev of
+    rato_hopper_emit_jacobian_values, host_inputs = 0 of rato_hopper_slip_hessian) -- same matrices as the oracle's."""
+    S, M = 300, 70
+    o, d = _models(S, M)
+    Z = synthetic_Z(o)
+    px, _ = o.contact_inputs(Z)
+    assert px.shape[0] == 200
+    J, J_o = d.slip_jacobian(Z), o.slip_jacobian(Z)
+    np.testing.assert_array_equal(J.indptr, J_o.indptr)
+    np.testing.assert_array_equal(J.indices, J_o.indices)
+    np.testing.assert_allclose(J.data, J_o.data, rtol=1e-4, atol=3e-5)
+    lam = np.random.RandomState(3).rand(M, 200)
+    H, H_o = d.slip_hessian(Z, lam), o.slip_hessian(Z, lam)
+    np.testing.assert_array_equal(H.indptr, H_o.indptr)
+    np.testing.assert_array_equal(H.indices, H_o.indices)
+    np.testing.assert_allclose(H.data, H_o.data, rtol=1e-4, atol=2e-5 * np.abs(H_o.data).max())
+    # 'baseline' layout through the same path
+    ob, db = _models(S, M, method='baseline') if "method" in _models.__code__.co_varnames else (None, None)
+    if db is not None:
+        Jb, Jb_o = db.slip_jacobian(Z), ob.slip_jacobian(Z)
+        np.testing.assert_array_equal(Jb.indices, Jb_o.indices)
+        np.testing.assert_allclose(Jb.data, Jb_o.data, rtol=1e-4, atol=3e-5)
