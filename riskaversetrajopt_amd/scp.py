@@ -77,7 +77,7 @@ def run_drone_reduced(model, num_scp_iters_max=60, verbose=False, check_finite=T
         from . import dense_qp
         dense_qp.require_native()
     us_prev = model.initial_guess_us_mat()
-    if native_loop is not False and not verbose and hasattr(model, "scp_run_native"):
+    if native_loop is not False and not verbose and num_scp_iters_max > 0 and hasattr(model, "scp_run_native"):
         _sync()
         r = model.scp_run_native(us_prev, num_scp_iters_max, **({} if tol is None else {"tol": tol}))
         if r is not None:

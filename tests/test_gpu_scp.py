@@ -1000,3 +1000,17 @@ def test_native_scp_loop_equals_the_per_iteration_loop_bitwise(M, S, alpha, meth
     ua, ta, ia = a.solve_reduced(ra["us"], iters)
     ub, tb, ib = b.solve_reduced(rb["us"], iters)
     assert np.array_equal(ua, ub) and ta == tb and ia["cuts"] == ib["cuts"]
+
+
+def test_native_scp_loop_edge_iteration_counts():
+    """one iteration (no CVaR rows yet: the relaxed subproblem only), three (the first CVaR subproblem), and zero (nothing
+    runs: the initial guess comes back) -- the native loop and the per-iteration loop agree on each"""
+    from riskaversetrajopt_amd import scp
+    for iters in (1, 3, 0):
+        a, b = _drone(500, 20, alpha=0.1, seed=2)[1], _drone(500, 20, alpha=0.1, seed=2)[1]
+        ra = scp.run_drone_reduced(a, num_scp_iters_max=iters)
+        rb = scp.run_drone_reduced(b, num_scp_iters_max=iters, native_loop=False)
+        assert np.array_equal(np.asarray(ra["us"]), np.asarray(rb["us"])) and len(ra["define_s"]) == len(rb["define_s"]) == iters
+        assert np.array_equal(ra["cuts"], rb["cuts"])
+        if iters:
+            assert ra["loop"].startswith("native") and np.array_equal(ra["us_hist"], rb["us_hist"])
