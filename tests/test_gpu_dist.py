@@ -220,3 +220,36 @@ def test_pipelined_steps_on_the_device_equal_the_serial_order():
     for k in range(K):
         assert np.array_equal(got[k].cpu().numpy(), serial[k]), k
     assert not np.array_equal(serial[0], serial[1])
+
+
+def test_pipelined_steps_keep_fresh_producer_tensors_alive_for_the_side_stream():
+    """``produce`` may return freshly allocated tensors; the consumer reads them on the side stream after
+    PipelinedSteps has dropped its last reference, and the caching allocator would hand the block to the next main-stream
+    allocation while the side stream still reads it.  The tensors are marked in use on the side stream (record_stream): a
+    slow consumer must still see the producer's numbers, not those of the allocations that follow."""
+    import torch
+    from riskaversetrajopt_amd import dist as rdist
+    dev = torch.device("cuda:0")
+    pipe = rdist.PipelinedSteps(2, dev)
+    n_el, K = 1 << 20, 12
+    seen = []
+
+    def produce_n(n):
+        def f(slot):
+            return {"x": torch.full((n_el,), float(n), device=dev), "n": n}      # fresh allocation every step
+        return f
+
+    def consume(slot, out):
+        torch.cuda._sleep(3_000_000)                       # the consumer is slow: the main stream runs far ahead
+        seen.append((out["n"], out["x"].sum()))            # (read on the side stream)
+        return None
+    for n in range(K):
+        pipe.step(produce_n(n), consume)
+        junk = [torch.full((n_el,), -1.0, device=dev) for _ in range(3)]   # main-stream allocations of the same size
+        del junk
+    pipe.drain()
+    torch.cuda.synchronize()
+    assert [n for n, _ in seen] == list(range(K))
+    for n, s in seen:
+        assert float(s) == float(n) * n_el, (n, float(s))
+    assert len(pipe.issued) <= rdist.PipelinedSteps.ISSUED_KEPT
