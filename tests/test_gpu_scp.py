@@ -1014,3 +1014,33 @@ def test_native_scp_loop_edge_iteration_counts():
         assert np.array_equal(ra["cuts"], rb["cuts"])
         if iters:
             assert ra["loop"].startswith("native") and np.array_equal(ra["us_hist"], rb["us_hist"])
+
+
+def test_a_define_that_is_never_solved_does_not_leak_into_the_next_one():
+    """ADVICE r5 (csrc/cutloop.hip): rato_cut_define_drone arms the pinned words of the kept cuts' sums and launches their
+    re-linearization; a second define without a solve in between used to re-arm the words while the first launch could
+    still write into them -- the next solve's wait would then be satisfied by the OLD launch's sums.  Two defines in a row
+    (the first at another point) followed by one solve must give exactly what one define + one solve give."""
+    import ctypes as C
+    from riskaversetrajopt_amd import _lib
+
+    def prepared():
+        d = _drone(4000, 30, alpha=0.1, seed=9)[1]
+        us = d.initial_guess_us_mat()
+        for k in range(4):
+            us, _, _ = d.solve_reduced(us, k)             # leaves kept cuts behind
+        return d, us
+    (a, us_a), (b, us_b) = prepared(), prepared()
+    assert np.array_equal(us_a, us_b) and len(a._cut_solver.keep) > 0
+    # b: an abandoned define at a shifted point first
+    cs = b._cut_solver
+    buf = b._native_define_buffers(cs)
+    h, out = cs._native_solver(), cs._keep_arrays()
+    other = np.ascontiguousarray(us_b * 1.05 + 0.01, dtype=np.float64)
+    rc = b._lib.rato_cut_define_drone(h, other.ctypes.data, buf["us_host"].data_ptr(), buf["us_dev"].data_ptr(),
+                                      buf["A22"].data_ptr(), None, 0, buf["part"].data_ptr(), buf["sums_host"].data_ptr(), None,
+                                      None, out["keep"].ctypes.data, len(cs.keep), _lib.current_stream())
+    assert rc == 0
+    ua, ta, ia = a.solve_reduced(us_a, 4)
+    ub, tb, ib = b.solve_reduced(us_b, 4)
+    assert np.array_equal(ua, ub) and ta == tb and ia["cuts"] == ib["cuts"] and ia["loop"] == ib["loop"] == "native"
