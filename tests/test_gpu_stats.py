@@ -350,3 +350,38 @@ def test_tail_of_less_than_one_sample(M):
     assert st["var"] == ostats.monte_carlo_var(Zh, alpha)
     assert abs(st["cvar"] - ostats.monte_carlo_avar(Zh, alpha)) <= 1e-12 * max(1.0, abs(st["cvar"]))
     assert st["cvar"] == st["var"]                       # empty tail: t + 0 / (alpha M)
+
+
+@pytest.mark.parametrize("M", [3000, 12288, 50000])
+def test_selection_with_nans_of_both_signs_and_a_key_range_near_the_full_word(M):
+    """ADVICE r5 (rato_select.h): the range-normalised selection filtered candidates with the unsigned test ``key - lo <
+    width``; for a key BELOW lo the subtraction wraps and passes when lo - key > 2^32 - width -- possible only when the keys
+    span almost the whole 32-bit word, i.e. when Z holds NaNs of both signs (their keys sit at the two ends of the order).
+    The selection must still return the key of the requested ascending rank: NaNs with the sign bit below -inf, the others
+    above +inf, exactly the order of the kernels' key map, emulated here in NumPy."""
+    from riskaversetrajopt_amd import stats
+    rng = np.random.RandomState(M)
+    Z = (rng.randn(M) * 0.5).astype(np.float32)
+    n_nan = max(M // 100, 2)
+    bits = Z.view(np.uint32).copy()
+    idx = rng.permutation(M)
+    bits[idx[:n_nan]] = 0xffc00001                       # -NaN: the smallest keys
+    bits[idx[n_nan:2 * n_nan]] = 0x7fc00001              # +NaN: the largest keys
+    bits[idx[2 * n_nan]] = 0xff800000                    # -inf
+    bits[idx[2 * n_nan + 1]] = 0x7f800000                # +inf
+    Zb = bits.view(np.float32)
+    u = bits.copy()
+    u[u == 0x80000000] = 0
+    key = np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint32)
+    order = np.sort(key)
+    for alpha in (0.1, 0.3, 0.004):
+        k = max(M - int(np.floor(alpha * M)) - 1, 0)
+        want = order[k]
+        wu = (want & 0x7fffffff) if (want & 0x80000000) else (~want & 0xffffffff)
+        want_val = np.array([wu], dtype=np.uint32).view(np.float32)[0]
+        st = stats.risk_stats(Zb, alpha)
+        assert st["rank"] == k
+        if np.isnan(want_val):
+            assert np.isnan(st["var"])
+        else:
+            assert st["var"] == want_val, (M, alpha, st["var"], want_val)
