@@ -1044,3 +1044,23 @@ def test_a_define_that_is_never_solved_does_not_leak_into_the_next_one():
     ua, ta, ia = a.solve_reduced(us_a, 4)
     ub, tb, ib = b.solve_reduced(us_b, 4)
     assert np.array_equal(ua, ub) and ta == tb and ia["cuts"] == ib["cuts"] and ia["loop"] == ib["loop"] == "native"
+
+
+def test_native_solver_is_rebuilt_when_its_parameter_struct_changes_in_place():
+    """ADVICE r5 (cvar_cuts.py): rato_cut_solver holds the rollout parameters BY VALUE; the cached handle must not survive
+    an in-place edit of the Python-side struct (same object, other bytes), nor a change of keep_max."""
+    d = _drone(600, 20, alpha=0.1, seed=1)[1]
+    us = d.initial_guess_us_mat()
+    for k in range(3):
+        us, _, _ = d.solve_reduced(us, k)
+    cs = d._cut_solver
+    h1 = cs._native_solver()
+    assert cs._native_solver().value == h1.value            # unchanged inputs: the cached handle
+    p = cs.rollout[1]
+    p.drag64 = p.drag64 * (1.0 + 1e-9)                      # in place: same Python object
+    h2 = cs._native_solver()
+    assert cs._native[3][3] == bytes(p) and (h2.value != h1.value or cs._native[0][1] == bytes(p))
+    key_before = cs._native[0]
+    cs.keep_max = cs.keep_max - 1
+    cs._native_solver()
+    assert cs._native[0] != key_before
