@@ -468,3 +468,22 @@ def test_generators_linearization_ignores_what_its_scratch_held(S, M):
             assert torch.equal(r["sums"], ref["sums"]) and torch.equal(r["g_up"], ref["g_up"]) and torch.equal(r["Z"], ref["Z"])
     fdu, flo, _, _, _ = o.get_all_constraints_coeffs(us)
     np.testing.assert_allclose(d.expand_final_du(ref["du_sum"].cpu().numpy(), 1.0 / M), fdu.mean(0), rtol=1e-5, atol=1e-6)
+
+
+def test_eval_device_keeps_the_reusable_g_buffer_across_a_call_without_g():
+    """``eval_device(out=o)`` without ``want_g`` used to overwrite ``o['_g']`` with None, dropping the buffer a later
+    call with ``want_g`` would have reused (drone and driving facades alike)."""
+    from oracle import drone as od, driving as ocar
+    from riskaversetrajopt_amd import drone_risk, driving
+    S, M = 20, 300
+    DWs, masses, Q = od.sample_uncertain_parameters(np.random.RandomState(0), 'saa', M=M, S=S)
+    d = drone_risk.Model(S, DWs, masses, Q, 'saa', 0.1)
+    c = driving.Model(M, 'saa', 0.1, S=S, samples=ocar.sample_uncertain_parameters(np.random.RandomState(0), M, 'saa', S))
+    for m, us in ((d, d.initial_guess_us_mat()), (c, c.initial_guess_us_mat())):
+        o = {}
+        m.eval_device(us, want_g=True, out=o)
+        g_ptr, z_ptr = o["_g"].data_ptr(), o["_Z"].data_ptr()
+        m.eval_device(us, out=o)                               # no g wanted: the buffer stays
+        assert o["_g"] is not None and o["_g"].data_ptr() == g_ptr and o["_Z"].data_ptr() == z_ptr
+        m.eval_device(us, want_g=True, out=o)
+        assert o["_g"].data_ptr() == g_ptr
